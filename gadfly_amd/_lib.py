@@ -1,0 +1,118 @@
+"""
+ctypes binding of ``libgadfly_hip.so`` (C-ABI declared in ``include/gadfly_hip.h``).
+
+This is the ONLY compute backend of the package: there is no CPU fallback.  Loading
+fails loudly if the shared library has not been built (``python -c "import
+__graft_entry__ as g; g.build()"`` or ``gadfly_amd._lib.build()``), and every compute
+call requires a HIP device (``torch.cuda.is_available()``).  PyTorch is used only for
+device buffers and streams; the arguments that cross the boundary are raw device
+pointers and sizes.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libgadfly_hip.so")
+SOURCES = [os.path.join(CSRC, "gadfly_hip.hip")]
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "gadfly_hip.h")
+
+GF_SOLVE_LOWER, GF_SOLVE_UPPER, GF_MATMUL_LOWER = 0, 1, 2
+GF_MAX_WIDTH = 256
+
+_lib = None
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+
+# name -> (restype, argtypes); must list every symbol include/gadfly_hip.h declares
+SIGNATURES = {
+    "gf_version": (_int, []),
+    "gf_last_error": (ctypes.c_char_p, []),
+    "gf_leading_dim": (_int, [_int]),
+    "gf_build_matrices": (_int, [_int, _i64, _int, _int, _int] + [_vp] * 7
+                          + [_vp, _i64, _vp, _i64] + [_vp] * 4 + [_vp]),
+    "gf_factor": (_int, [_int, _i64, _int, _int] + [_vp] * 4 + [_vp, _i64]
+                  + [_vp] * 4 + [_vp]),
+    "gf_reduce_work": (_i64, [_i64]),
+    "gf_loglike_reduce": (_int, [_int, _i64] + [_vp] * 6 + [_vp]),
+    "gf_solve": (_int, [_int, _int, _i64, _int, _int, _int] + [_vp] * 6 + [_vp]),
+    "gf_general_matmul": (_int, [_int, _i64, _i64, _int, _int, _vp,
+                                 _vp, _i64, _vp, _vp,
+                                 _vp, _i64, _vp, _vp, _vp, _vp,
+                                 _vp, _vp, _vp]),
+}
+
+
+class GadflyHipError(RuntimeError):
+    """Raised when the native library is missing or reports an argument/launch error."""
+
+
+def hipcc_command(out=SO_PATH):
+    return ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+            "-o", out] + SOURCES
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library for gfx950 in-tree (cross-compiles without a GPU)."""
+    newest = max(os.path.getmtime(p) for p in SOURCES + [HEADER])
+    if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= newest:
+        return SO_PATH
+    cmd = hipcc_command()
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+def load():
+    """Load the shared library and bind every declared symbol (no GPU needed)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise GadflyHipError(
+            f"{SO_PATH} not found: the HIP extension has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "gadfly_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().gf_last_error().decode()
+
+
+def check(status, what):
+    if status != 0:
+        raise GadflyHipError(f"{what} failed (status {status}): {last_error()}")
+
+
+def require_device():
+    """The product path needs a HIP device; refuse to run anything without one."""
+    import torch
+    if not torch.cuda.is_available():
+        raise GadflyHipError(
+            "no HIP device available: gadfly_amd computes only on an MI355X-class GPU "
+            "(there is deliberately no CPU fallback)."
+        )
+    load()
+    return torch
+
+
+def ptr(tensor):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if tensor is None else tensor.data_ptr()
+
+
+def stream_handle():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,782 @@
+// gadfly_hip.hip -- hand-written HIP kernels for gfx950 (MI355X, CDNA4) + the C-ABI of
+// include/gadfly_hip.h.  float64 throughout; wave = 64 lanes.
+//
+// What is replaced: the celerite2 C++ driver routines behind gadfly's GaussianProcess
+// (/root/reference/gadfly/gp.py:202, :232, :327, :350, :370, :391).
+// The arithmetic follows SURVEY.md Appendix A.4-A.8.
+//
+// Kernel inventory
+//   k_build        A.4 generator rows U, V (+ a, + propagator rows P)         HBM/VALU (sincos, exp)
+//   k_factor       A.5 LDL^T recurrence, state S (W x W) in VGPRs, rows split over NW waves,
+//                  optional fused forward solve (A.6) for the log-likelihood path
+//   k_reduce_*     sum log d, sum z^2/d (deterministic fixed-shape tree)
+//   k_solve_vec    A.6/A.7 sweeps, one right-hand side, state F lane-resident
+//   k_solve_rhs    A.6/A.7 sweeps, one lane per right-hand side, generator rows wave-uniform
+//   k_gmm_*        A.8 conditional mean at new times
+//
+// No CUDA compatibility layer, no Triton, no CPU fallback.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+
+#include "../../include/gadfly_hip.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int set_err(const char *fmt, const char *a = "", long long x = 0, long long y = 0) {
+    snprintf(g_err, sizeof(g_err), fmt, a, x, y);
+    return -1;
+}
+
+int check_launch(const char *what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return -2;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// wave-level primitives (64 lanes, DPP; no LDS traffic)
+// ------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_get(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double read_lane(double v, int l) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// Fixed-shape tree sum over the 64 lanes, result broadcast to every lane (deterministic).
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_get<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v += dpp_get<0x141, 0xf>(v);   // row_half_mirror
+    v += dpp_get<0x140, 0xf>(v);   // row_mirror       -> every lane holds its 16-lane row sum
+    v += dpp_get<0x142, 0xa>(v);   // row_bcast15 into rows 1, 3
+    v += dpp_get<0x143, 0xc>(v);   // row_bcast31 into rows 2, 3 -> lane 63 holds the total
+    return read_lane(v, 63);
+}
+
+// Two independent sums interleaved (same latency chain as one).
+__device__ __forceinline__ void wave_sum2(double &a, double &b) {
+    a += dpp_get<0xB1, 0xf>(a);   b += dpp_get<0xB1, 0xf>(b);
+    a += dpp_get<0x4E, 0xf>(a);   b += dpp_get<0x4E, 0xf>(b);
+    a += dpp_get<0x141, 0xf>(a);  b += dpp_get<0x141, 0xf>(b);
+    a += dpp_get<0x140, 0xf>(a);  b += dpp_get<0x140, 0xf>(b);
+    a += dpp_get<0x142, 0xa>(a);  b += dpp_get<0x142, 0xa>(b);
+    a += dpp_get<0x143, 0xc>(a);  b += dpp_get<0x143, 0xc>(b);
+    a = read_lane(a, 63);
+    b = read_lane(b, 63);
+}
+
+// Order LDS traffic of ONE wave: lane-form writes before uniform (broadcast) reads.
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS operations of one wave execute in issue order, so wavefront scope (a pure
+    // compiler fence, no s_waitcnt) is enough and leaves global prefetches in flight.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------
+// K0: generator rows + propagator rows
+// ------------------------------------------------------------------------------------
+struct BuildArgs {
+    int64_t N;
+    int Jr, Jc, ld, units;          // units per row = Jr + Jc + (ld - W)
+    const double *ar, *cr, *ac, *bc, *cc, *dc, *diag_add;
+    const double *t; int64_t t_bs;
+    const double *diag; int64_t diag_bs;
+    double *a, *U, *V, *P;
+};
+
+__global__ void __launch_bounds__(256) k_build(const BuildArgs A) {
+    const int b = blockIdx.y;
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = id / A.units;
+    if (n >= A.N) return;
+    const int q = (int)(id - n * A.units);
+    const int W = A.Jr + 2 * A.Jc;
+    const double *t = A.t + (size_t)b * A.t_bs;
+    const double tn = t[n];
+    const double dt = (n > 0) ? (t[n - 1] - tn) : 0.0;
+    const size_t row = ((size_t)b * A.N + n) * A.ld;
+    if (q == 0 && A.a) {
+        const double dg = A.diag ? A.diag[(size_t)b * A.diag_bs + n] : 0.0;
+        A.a[(size_t)b * A.N + n] = dg + A.diag_add[b];
+    }
+    if (q < A.Jr) {                                  // real term: one column
+        const double ar = A.ar[(size_t)b * A.Jr + q], cr = A.cr[(size_t)b * A.Jr + q];
+        A.U[row + q] = ar;
+        A.V[row + q] = 1.0;
+        if (A.P) A.P[row + q] = (n > 0) ? exp(cr * dt) : 1.0;
+    } else if (q < A.Jr + A.Jc) {                    // complex term: two columns
+        const int k = q - A.Jr;
+        const size_t ck = (size_t)b * A.Jc + k;
+        const double ac = A.ac[ck], bc = A.bc[ck], cc = A.cc[ck], dc = A.dc[ck];
+        const double arg = dc * tn;                  // ONE rounded multiply (parity hazard i)
+        double si, co;
+        sincos(arg, &si, &co);
+        const int j = A.Jr + 2 * k;
+        A.U[row + j]     = ac * co + bc * si;
+        A.U[row + j + 1] = ac * si - bc * co;
+        A.V[row + j]     = co;
+        A.V[row + j + 1] = si;
+        if (A.P) {
+            const double p = (n > 0) ? exp(cc * dt) : 1.0;
+            A.P[row + j] = p;
+            A.P[row + j + 1] = p;
+        }
+    } else {                                         // pad column
+        const int j = W + (q - A.Jr - A.Jc);
+        A.U[row + j] = 0.0;
+        A.V[row + j] = 0.0;
+        if (A.P) A.P[row + j] = 1.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K1: factor (+ fused forward solve).  One workgroup of NW waves per (problem, chunk).
+//   thread (wave w, lane l) holds S[i][j] for rows i = w*RB + r (r < RB) and
+//   columns j = c*64 + l (c < CT).  Per row n:
+//     S   <- P_n (S + d_{n-1} w_{n-1} w_{n-1}^T) P_n      (fused with the mat-vec below)
+//     tmp  = u_n^T S      (partial over this wave's rows; reduced across waves through LDS)
+//     d_n  = a_n - tmp . u_n        (DPP tree)
+//     w_n  = (v_n - tmp) / d_n
+//   Row-indexed operands (u_i, p_i, w_i) are wave-uniform: each wave stages the lane-form
+//   vectors in its private LDS slice and reads them back as broadcasts.
+// ------------------------------------------------------------------------------------
+struct FactorArgs {
+    int64_t N, chunk_len;
+    int W, ld;
+    const double *a, *U, *V, *P;
+    const double *y; int64_t y_bs;
+    double *d, *Wm, *z;
+    const double *S_in, *F_in;      // per (problem, chunk) state, or NULL = zero
+    double *S_out, *F_out;          // or NULL
+    int32_t *info;
+};
+
+template <int RB, int CT, int NW>
+__global__ void __launch_bounds__(64 * NW) k_factor(const FactorArgs A) {
+    constexpr int WPC = CT * 64;
+    constexpr int RT = RB * NW;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const int nch = gridDim.x;
+    const int64_t n0 = (int64_t)ch * A.chunk_len;
+    const int64_t n1 = (n0 + A.chunk_len < A.N) ? (n0 + A.chunk_len) : A.N;
+    const int ld = A.ld;
+    const size_t pb = (size_t)b * A.N;
+    const double *__restrict__ Ug = A.U + pb * ld;
+    const double *__restrict__ Vg = A.V + pb * ld;
+    const double *__restrict__ Pg = A.P + pb * ld;
+    const double *__restrict__ ag = A.a + pb;
+    const double *__restrict__ yg = A.y ? (A.y + (size_t)b * A.y_bs) : nullptr;
+
+    __shared__ double s_part[2][NW][WPC];
+    __shared__ double s_vec[NW][3][WPC];
+    double *sv_u = s_vec[wave][0], *sv_p = s_vec[wave][1], *sv_w = s_vec[wave][2];
+
+    double S[RB][CT];
+    double Fv[CT], wv[CT];
+    bool colok[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        colok[c] = (c * 64 + lane) < ld;
+        wv[c] = 0.0;
+        Fv[c] = 0.0;
+    }
+    const size_t sidx = (size_t)b * nch + ch;
+    if (A.S_in) {
+        const double *Si = A.S_in + sidx * RT * WPC;
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) S[r][c] = Si[(size_t)(wave * RB + r) * WPC + c * 64 + lane];
+        if (A.F_in) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) Fv[c] = A.F_in[sidx * WPC + c * 64 + lane];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) S[r][c] = 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) sv_w[c * 64 + lane] = 0.0;
+
+    double dprev = 0.0, zprev = 0.0;
+    int32_t fail = 0;
+
+    // software prefetch of row n0
+    double un[CT], vn[CT], pn[CT], an, yn;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const size_t o = (size_t)n0 * ld + c * 64 + lane;
+        un[c] = colok[c] ? Ug[o] : 0.0;
+        vn[c] = colok[c] ? Vg[o] : 0.0;
+        pn[c] = colok[c] ? Pg[o] : 1.0;
+    }
+    an = ag[n0];
+    yn = yg ? yg[n0] : 0.0;
+
+    for (int64_t n = n0; n < n1; ++n) {
+        double u[CT], v[CT], p[CT];
+        const double a_n = an, y_n = yn;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            u[c] = un[c]; v[c] = vn[c]; p[c] = pn[c];
+            sv_u[c * 64 + lane] = u[c];
+            sv_p[c * 64 + lane] = p[c];
+        }
+        // prefetch the next row (clamped: the last iteration re-reads its own row)
+        const int64_t nn = (n + 1 < n1) ? (n + 1) : n;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const size_t o = (size_t)nn * ld + c * 64 + lane;
+            un[c] = colok[c] ? Ug[o] : 0.0;
+            vn[c] = colok[c] ? Vg[o] : 0.0;
+            pn[c] = colok[c] ? Pg[o] : 1.0;
+        }
+        an = ag[nn];
+        yn = yg ? yg[nn] : 0.0;
+
+        wave_lds_fence();
+
+        // fused: pending rank-1 update + decay, then the mat-vec partial for this wave's rows
+        double acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = 0.0;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int i = wave * RB + r;
+            const double ui = sv_u[i], pi = sv_p[i];
+            const double wid = sv_w[i] * dprev;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const double s = (S[r][c] + wid * wv[c]) * (pi * p[c]);
+                S[r][c] = s;
+                acc[c] = fma(ui, s, acc[c]);
+            }
+        }
+        double tmp[CT];
+        if constexpr (NW > 1) {
+            const int buf = (int)(n & 1);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) s_part[buf][wave][c * 64 + lane] = acc[c];
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                double s = s_part[buf][0][c * 64 + lane];
+#pragma unroll
+                for (int w2 = 1; w2 < NW; ++w2) s += s_part[buf][w2][c * 64 + lane];
+                tmp[c] = s;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) tmp[c] = acc[c];
+        }
+        // F_n = P_n (F_{n-1} + w_{n-1} z_{n-1});  two dot products in one DPP tree
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            Fv[c] = p[c] * fma(wv[c], zprev, Fv[c]);
+            s1 = fma(u[c], tmp[c], s1);
+            s2 = fma(u[c], Fv[c], s2);
+        }
+        wave_sum2(s1, s2);
+        const double dn = a_n - s1;
+        const double zn = y_n - s2;
+        if (!(dn > 0.0)) {              // uniform across the whole workgroup
+            fail = (int32_t)(n + 1 > 0x7fffffff ? 0x7fffffff : n + 1);
+            break;
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            wv[c] = (v[c] - tmp[c]) / dn;
+            sv_w[c * 64 + lane] = wv[c];
+        }
+        if (wave == 0) {
+            if (A.Wm) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    if (colok[c]) A.Wm[(pb + n) * ld + c * 64 + lane] = wv[c];
+            }
+            if (lane == 0) {
+                A.d[pb + n] = dn;
+                if (A.z) A.z[pb + n] = zn;
+            }
+        }
+        dprev = dn;
+        zprev = zn;
+    }
+
+    if (wave == 0 && lane == 0) A.info[sidx] = fail;
+
+    if (A.S_out) {                      // state handed to the next chunk: pending update, no decay
+        wave_lds_fence();
+        double *So = A.S_out + sidx * RT * WPC;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int i = wave * RB + r;
+            const double wid = sv_w[i] * dprev;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) So[(size_t)i * WPC + c * 64 + lane] = fma(wid, wv[c], S[r][c]);
+        }
+        if (A.F_out && wave == 0) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) A.F_out[sidx * WPC + c * 64 + lane] = fma(wv[c], zprev, Fv[c]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// log-likelihood reductions: fixed-shape two-stage tree (deterministic)
+//   stage 1: G blocks per problem -> partial (sum log d, sum z^2/d);  stage 2: one wave
+// ------------------------------------------------------------------------------------
+constexpr int RED_BLOCK = 256;
+constexpr int RED_MAXG = 512;
+
+__host__ __device__ inline int red_groups(int64_t N) {
+    int64_t g = (N + 4095) / 4096;
+    if (g < 1) g = 1;
+    if (g > RED_MAXG) g = RED_MAXG;
+    return (int)g;
+}
+
+__global__ void __launch_bounds__(RED_BLOCK) k_reduce1(int64_t N, const double *d, const double *z,
+                                                       double *work) {
+    const int b = blockIdx.y, g = blockIdx.x, G = gridDim.x;
+    const double *dp = d + (size_t)b * N;
+    const double *zp = z ? z + (size_t)b * N : nullptr;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t n = (int64_t)g * RED_BLOCK + threadIdx.x; n < N; n += (int64_t)G * RED_BLOCK) {
+        const double dn = dp[n];
+        s1 += log(dn);
+        if (zp) { const double zn = zp[n]; s2 += zn * zn / dn; }
+    }
+    wave_sum2(s1, s2);
+    __shared__ double sh[2][RED_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sh[0][wave] = s1; sh[1][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int w = 0; w < RED_BLOCK / 64; ++w) { t1 += sh[0][w]; t2 += sh[1][w]; }
+        work[((size_t)b * G + g) * 2] = t1;
+        work[((size_t)b * G + g) * 2 + 1] = t2;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_reduce2(int64_t N, int G, const double *work,
+                                                const int32_t *info, double *out, double *logdet) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int g = lane; g < G; g += 64) {
+        s1 += work[((size_t)b * G + g) * 2];
+        s2 += work[((size_t)b * G + g) * 2 + 1];
+    }
+    wave_sum2(s1, s2);
+    if (lane == 0) {
+        const bool bad = info && info[b] != 0;
+        const double ld = bad ? -INFINITY : s1;
+        if (logdet) logdet[b] = ld;
+        if (out) out[b] = bad ? -INFINITY
+                              : (-0.5 * (s1 + (double)N * 1.8378770664093453) - 0.5 * s2);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K2/K3/K4 with ONE right-hand side: F lane-resident (column j = c*64 + lane), one wave
+// per problem, one DPP tree per row.
+// ------------------------------------------------------------------------------------
+struct SolveArgs {
+    int64_t N;
+    int W, ld, R, mode;
+    const double *U, *Wm, *P, *scale, *Y;
+    double *Z;
+};
+
+template <int CT>
+__global__ void __launch_bounds__(64) k_solve_vec(const SolveArgs A) {
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const int64_t N = A.N;
+    const int ld = A.ld;
+    const size_t pb = (size_t)b * N;
+    const bool up = (A.mode == GF_SOLVE_UPPER);
+    const bool mm = (A.mode == GF_MATMUL_LOWER);
+    // "push" rows multiply the carried value into F; "pull" rows are dotted with F
+    const double *__restrict__ push = (up ? A.U : A.Wm) + pb * ld;
+    const double *__restrict__ pull = (up ? A.Wm : A.U) + pb * ld;
+    const double *__restrict__ Pg = A.P + pb * ld;
+    const double *__restrict__ Y = A.Y + pb;
+    const double *__restrict__ sc = A.scale ? A.scale + pb : nullptr;
+    double *Z = A.Z + pb;
+    bool colok[CT];
+    double F[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) { colok[c] = (c * 64 + lane) < ld; F[c] = 0.0; }
+
+    double carry = 0.0;                 // z_{prev} (solves) or y_{prev} (matmul)
+    for (int64_t s = 0; s < N; ++s) {
+        const int64_t n = up ? (N - 1 - s) : s;
+        const int64_t prev = up ? (n + 1) : (n - 1);
+        const int64_t prow = up ? (n + 1) : n;
+        double yn = Y[n];
+        if (sc) yn = mm ? yn * sqrt(sc[n]) : yn / sc[n];
+        double dot = 0.0;
+        if (s > 0) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                if (colok[c]) {
+                    const int j = c * 64 + lane;
+                    const double pj = Pg[(size_t)prow * ld + j];
+                    const double aj = push[(size_t)prev * ld + j];
+                    const double bj = pull[(size_t)n * ld + j];
+                    F[c] = pj * fma(aj, carry, F[c]);
+                    dot = fma(bj, F[c], dot);
+                }
+            }
+            dot = wave_sum(dot);
+        }
+        const double zn = mm ? (yn + dot) : (yn - dot);
+        if (lane == 0) Z[n] = zn;
+        carry = mm ? yn : zn;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K2/K3/K4 with R right-hand sides: lane r of a wave owns column r of Y/Z and the W-vector
+// F[:, r] in VGPRs; the generator rows are wave-uniform (scalar loads), so there is no
+// cross-lane traffic at all.  Widths above 64 split j over NWV waves (one LDS exchange/row).
+// ------------------------------------------------------------------------------------
+template <int JB, int NWV>
+__global__ void __launch_bounds__(64 * NWV) k_solve_rhs(const SolveArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * 64 + lane;
+    const int R = A.R;
+    const bool rok = r < R;
+    const int64_t N = A.N;
+    const int ld = A.ld;
+    const size_t pb = (size_t)b * N;
+    const bool up = (A.mode == GF_SOLVE_UPPER);
+    const bool mm = (A.mode == GF_MATMUL_LOWER);
+    const double *__restrict__ push = (up ? A.U : A.Wm) + pb * ld;
+    const double *__restrict__ pull = (up ? A.Wm : A.U) + pb * ld;
+    const double *__restrict__ Pg = A.P + pb * ld;
+    const double *__restrict__ Y = A.Y + pb * R;
+    const double *__restrict__ sc = A.scale ? A.scale + pb : nullptr;
+    double *Z = A.Z + pb * R;
+    const int j0 = wave * JB;
+    int jn = ld - j0;                    // valid columns in this wave's slice
+    if (jn > JB) jn = JB;
+    if (jn < 0) jn = 0;
+
+    __shared__ double s_dot[2][NWV][64];
+
+    double F[JB];
+#pragma unroll
+    for (int j = 0; j < JB; ++j) F[j] = 0.0;
+
+    double carry = 0.0;
+    for (int64_t s = 0; s < N; ++s) {
+        const int64_t n = up ? (N - 1 - s) : s;
+        const int64_t prev = up ? (n + 1) : (n - 1);
+        const int64_t prow = up ? (n + 1) : n;
+        double yn = rok ? Y[(size_t)n * R + r] : 0.0;
+        if (sc) { const double sn = sc[n]; yn = mm ? yn * sqrt(sn) : yn / sn; }
+        double dot = 0.0;
+        if (s > 0) {
+            const double *pp = Pg + (size_t)prow * ld + j0;
+            const double *pa = push + (size_t)prev * ld + j0;
+            const double *pl = pull + (size_t)n * ld + j0;
+#pragma unroll
+            for (int j = 0; j < JB; ++j) {
+                if (j < jn) {            // wave-uniform predicate
+                    F[j] = pp[j] * fma(pa[j], carry, F[j]);
+                    dot = fma(pl[j], F[j], dot);
+                }
+            }
+            if constexpr (NWV > 1) {
+                const int buf = (int)(s & 1);
+                s_dot[buf][wave][lane] = dot;
+                __syncthreads();
+                dot = s_dot[buf][0][lane];
+#pragma unroll
+                for (int w2 = 1; w2 < NWV; ++w2) dot += s_dot[buf][w2][lane];
+            }
+        }
+        const double zn = mm ? (yn + dot) : (yn - dot);
+        if (rok && wave == 0) Z[(size_t)n * R + r] = zn;
+        carry = mm ? yn : zn;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K5: conditional mean at new times.  One wave per (problem, direction);
+// F lane-resident; consecutive observed rows advance with the stored propagator rows P2,
+// only the hop from the last observed row to the query time needs an exp.
+//   dir 0 (lower): ascending;  dir 1 (upper): descending.  Partial results go to work[dir].
+// ------------------------------------------------------------------------------------
+struct GmmArgs {
+    int64_t M, N;
+    int W, ld;
+    const double *c;
+    const double *t1; int64_t t1_bs;
+    const double *U1, *V1;
+    const double *t2; int64_t t2_bs;
+    const double *U2, *V2, *P2, *alpha;
+    double *work;
+};
+
+template <int CT>
+__global__ void __launch_bounds__(64) k_gmm(const GmmArgs A) {
+    const int lane = threadIdx.x, b = blockIdx.x, dir = blockIdx.y;
+    const int64_t M = A.M, N = A.N;
+    const int ld = A.ld;
+    const double *t1 = A.t1 + (size_t)b * A.t1_bs;
+    const double *t2 = A.t2 + (size_t)b * A.t2_bs;
+    const double *__restrict__ Q1 = (dir == 0 ? A.U1 : A.V1) + (size_t)b * M * ld;   // query-side rows
+    const double *__restrict__ G2 = (dir == 0 ? A.V2 : A.U2) + (size_t)b * N * ld;   // data-side rows
+    const double *__restrict__ P2 = A.P2 + (size_t)b * N * ld;
+    const double *__restrict__ al = A.alpha + (size_t)b * N;
+    double *out = A.work + ((size_t)b * 2 + dir) * M;
+    bool colok[CT];
+    double F[CT], cj[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int j = c * 64 + lane;
+        colok[c] = j < A.W;
+        F[c] = 0.0;
+        cj[c] = colok[c] ? A.c[(size_t)b * A.W + j] : 0.0;
+    }
+    bool have = false;
+    double last = 0.0;
+    if (dir == 0) {
+        int64_t n = 0;
+        for (int64_t m = 0; m < M; ++m) {
+            const double tm = t1[m];
+            while (n < N && t2[n] <= tm) {
+                const double an = al[n];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    if (colok[c]) {
+                        const size_t o = (size_t)n * ld + c * 64 + lane;
+                        const double pj = have ? P2[o] : 1.0;    // exp(c (t2[n-1] - t2[n]))
+                        F[c] = fma(pj, F[c], G2[o] * an);
+                    }
+                }
+                last = t2[n]; have = true; ++n;
+            }
+            double acc = 0.0;
+            if (have) {
+                const double dt = last - tm;
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    if (colok[c]) acc = fma(Q1[(size_t)m * ld + c * 64 + lane] * exp(cj[c] * dt), F[c], acc);
+                acc = wave_sum(acc);
+            }
+            if (lane == 0) out[m] = acc;
+        }
+    } else {
+        int64_t n = N - 1;
+        for (int64_t m = M - 1; m >= 0; --m) {
+            const double tm = t1[m];
+            while (n >= 0 && t2[n] > tm) {
+                const double an = al[n];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    if (colok[c]) {
+                        const size_t o = (size_t)n * ld + c * 64 + lane;
+                        // exp(c (t2[n] - t2[n+1])) is propagator row n+1
+                        const double pj = have ? P2[o + ld] : 1.0;
+                        F[c] = fma(pj, F[c], G2[o] * an);
+                    }
+                }
+                last = t2[n]; have = true; --n;
+            }
+            double acc = 0.0;
+            if (have) {
+                const double dt = tm - last;
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    if (colok[c]) acc = fma(Q1[(size_t)m * ld + c * 64 + lane] * exp(cj[c] * dt), F[c], acc);
+                acc = wave_sum(acc);
+            }
+            if (lane == 0) out[m] = acc;
+        }
+    }
+}
+
+// mu[b][m] = work[b][0][m] + work[b][1][m]
+__global__ void k_add2(int64_t M, const double *work, double *mu) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t b = blockIdx.y;
+    if (m < M) mu[b * M + m] = work[(b * 2) * M + m] + work[(b * 2 + 1) * M + m];
+}
+
+// ------------------------------------------------------------------------------------
+// dispatch helpers
+// ------------------------------------------------------------------------------------
+template <int RB, int CT, int NW>
+int launch_factor(const FactorArgs &A, int B, int nch, hipStream_t st) {
+    hipLaunchKernelGGL((k_factor<RB, CT, NW>), dim3(nch, B), dim3(64 * NW), 0, st, A);
+    return check_launch("gf_factor");
+}
+
+int dispatch_factor(const FactorArgs &A, int B, int nch, hipStream_t st) {
+    const int W = A.W;
+    if (W <= 16)  return launch_factor<4, 1, 4>(A, B, nch, st);
+    if (W <= 32)  return launch_factor<8, 1, 4>(A, B, nch, st);
+    if (W <= 48)  return launch_factor<12, 1, 4>(A, B, nch, st);
+    if (W <= 64)  return launch_factor<16, 1, 4>(A, B, nch, st);
+    if (W <= 96)  return launch_factor<24, 2, 4>(A, B, nch, st);
+    if (W <= 128) return launch_factor<32, 2, 4>(A, B, nch, st);
+    if (W <= 192) return launch_factor<24, 3, 8>(A, B, nch, st);
+    return launch_factor<32, 4, 8>(A, B, nch, st);
+}
+
+}  // namespace
+
+// ======================================================================================
+// C-ABI
+// ======================================================================================
+extern "C" {
+
+int gf_version(void) { return 100; }
+
+const char *gf_last_error(void) { return g_err; }
+
+int gf_leading_dim(int W) {
+    if (W < 1 || W > GF_MAX_WIDTH) return -1;
+    return (W + 15) / 16 * 16;
+}
+
+int gf_build_matrices(int B, int64_t N, int Jr, int Jc, int ld,
+                      const double *ar, const double *cr, const double *ac,
+                      const double *bc, const double *cc, const double *dc,
+                      const double *diag_add,
+                      const double *t, int64_t t_bs,
+                      const double *diag, int64_t diag_bs,
+                      double *a, double *U, double *V, double *P, void *stream) {
+    const int W = Jr + 2 * Jc;
+    if (B < 1 || N < 1) return set_err("gf_build_matrices: empty problem (B=%s%lld, N=%lld)", "", B, N);
+    if (W < 1 || W > GF_MAX_WIDTH) return set_err("gf_build_matrices: width %s%lld unsupported (max %lld)", "", W, GF_MAX_WIDTH);
+    if (ld < W || (ld & 15)) return set_err("gf_build_matrices: ld=%s%lld must be a multiple of 16 and >= W=%lld", "", ld, W);
+    if (!t || !U || !V || (a && !diag_add)) return set_err("gf_build_matrices: null pointer%s", "");
+    BuildArgs A;
+    A.N = N; A.Jr = Jr; A.Jc = Jc; A.ld = ld; A.units = Jr + Jc + (ld - W);
+    A.ar = ar; A.cr = cr; A.ac = ac; A.bc = bc; A.cc = cc; A.dc = dc; A.diag_add = diag_add;
+    A.t = t; A.t_bs = t_bs; A.diag = diag; A.diag_bs = diag_bs;
+    A.a = a; A.U = U; A.V = V; A.P = P;
+    const int64_t total = N * A.units;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return set_err("gf_build_matrices: problem too large%s", "");
+    hipLaunchKernelGGL(k_build, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, A);
+    return check_launch("gf_build_matrices");
+}
+
+int gf_factor(int B, int64_t N, int W, int ld,
+              const double *a, const double *U, const double *V, const double *P,
+              const double *y, int64_t y_bs,
+              double *d, double *Wm, double *z, int32_t *info, void *stream) {
+    if (B < 1 || N < 1) return set_err("gf_factor: empty problem (B=%s%lld, N=%lld)", "", B, N);
+    if (W < 1 || W > GF_MAX_WIDTH) return set_err("gf_factor: width %s%lld unsupported (max %lld)", "", W, GF_MAX_WIDTH);
+    if (ld < W || (ld & 15)) return set_err("gf_factor: ld=%s%lld must be a multiple of 16 and >= W=%lld", "", ld, W);
+    if (!a || !U || !V || !P || !d || !info) return set_err("gf_factor: null pointer%s", "");
+    if (z && !y) return set_err("gf_factor: z requested without y%s", "");
+    FactorArgs A;
+    A.N = N; A.chunk_len = N; A.W = W; A.ld = ld;
+    A.a = a; A.U = U; A.V = V; A.P = P; A.y = y; A.y_bs = y_bs;
+    A.d = d; A.Wm = Wm; A.z = z;
+    A.S_in = nullptr; A.F_in = nullptr; A.S_out = nullptr; A.F_out = nullptr;
+    A.info = info;
+    return dispatch_factor(A, B, 1, (hipStream_t)stream);
+}
+
+int64_t gf_reduce_work(int64_t N) { return 2 * (int64_t)red_groups(N); }
+
+int gf_loglike_reduce(int B, int64_t N, const double *d, const double *z,
+                      const int32_t *info, double *work, double *out, double *logdet,
+                      void *stream) {
+    if (B < 1 || N < 1) return set_err("gf_loglike_reduce: empty problem (B=%s%lld, N=%lld)", "", B, N);
+    if (!d || !work || (!out && !logdet)) return set_err("gf_loglike_reduce: null pointer%s", "");
+    const int G = red_groups(N);
+    hipLaunchKernelGGL(k_reduce1, dim3(G, B), dim3(RED_BLOCK), 0, (hipStream_t)stream, N, d, z, work);
+    hipLaunchKernelGGL(k_reduce2, dim3(B), dim3(64), 0, (hipStream_t)stream, N, G, work, info, out, logdet);
+    return check_launch("gf_loglike_reduce");
+}
+
+int gf_solve(int mode, int B, int64_t N, int W, int ld, int R,
+             const double *U, const double *Wm, const double *P, const double *scale,
+             const double *Y, double *Z, void *stream) {
+    if (mode < 0 || mode > 2) return set_err("gf_solve: bad mode %s%lld", "", mode);
+    if (B < 1 || N < 1 || R < 1) return set_err("gf_solve: empty problem (N=%s%lld, R=%lld)", "", N, R);
+    if (W < 1 || W > GF_MAX_WIDTH) return set_err("gf_solve: width %s%lld unsupported (max %lld)", "", W, GF_MAX_WIDTH);
+    if (ld < W || (ld & 15)) return set_err("gf_solve: ld=%s%lld must be a multiple of 16 and >= W=%lld", "", ld, W);
+    if (!U || !Wm || !P || !Y || !Z) return set_err("gf_solve: null pointer%s", "");
+    if (mode == GF_MATMUL_LOWER && Y == Z) return set_err("gf_solve: GF_MATMUL_LOWER cannot run in place%s", "");
+    SolveArgs A;
+    A.N = N; A.W = W; A.ld = ld; A.R = R; A.mode = mode;
+    A.U = U; A.Wm = Wm; A.P = P; A.scale = scale; A.Y = Y; A.Z = Z;
+    hipStream_t st = (hipStream_t)stream;
+    if (R == 1) {
+        if (ld <= 64)       hipLaunchKernelGGL(k_solve_vec<1>, dim3(B), dim3(64), 0, st, A);
+        else if (ld <= 128) hipLaunchKernelGGL(k_solve_vec<2>, dim3(B), dim3(64), 0, st, A);
+        else                hipLaunchKernelGGL(k_solve_vec<4>, dim3(B), dim3(64), 0, st, A);
+    } else {
+        const dim3 grid((R + 63) / 64, B);
+        if (ld <= 16)       hipLaunchKernelGGL((k_solve_rhs<16, 1>), grid, dim3(64), 0, st, A);
+        else if (ld <= 32)  hipLaunchKernelGGL((k_solve_rhs<32, 1>), grid, dim3(64), 0, st, A);
+        else if (ld <= 48)  hipLaunchKernelGGL((k_solve_rhs<48, 1>), grid, dim3(64), 0, st, A);
+        else if (ld <= 64)  hipLaunchKernelGGL((k_solve_rhs<64, 1>), grid, dim3(64), 0, st, A);
+        else if (ld <= 96)  hipLaunchKernelGGL((k_solve_rhs<48, 2>), grid, dim3(128), 0, st, A);
+        else if (ld <= 128) hipLaunchKernelGGL((k_solve_rhs<64, 2>), grid, dim3(128), 0, st, A);
+        else if (ld <= 192) hipLaunchKernelGGL((k_solve_rhs<48, 4>), grid, dim3(256), 0, st, A);
+        else                hipLaunchKernelGGL((k_solve_rhs<64, 4>), grid, dim3(256), 0, st, A);
+    }
+    return check_launch("gf_solve");
+}
+
+int gf_general_matmul(int B, int64_t M, int64_t N, int W, int ld,
+                      const double *c,
+                      const double *t1, int64_t t1_bs, const double *U1, const double *V1,
+                      const double *t2, int64_t t2_bs, const double *U2, const double *V2,
+                      const double *P2, const double *alpha,
+                      double *work, double *mu, void *stream) {
+    if (B < 1 || N < 1 || M < 1) return set_err("gf_general_matmul: empty problem (M=%s%lld, N=%lld)", "", M, N);
+    if (W < 1 || W > GF_MAX_WIDTH) return set_err("gf_general_matmul: width %s%lld unsupported (max %lld)", "", W, GF_MAX_WIDTH);
+    if (ld < W || (ld & 15)) return set_err("gf_general_matmul: ld=%s%lld must be a multiple of 16 and >= W=%lld", "", ld, W);
+    if (!c || !t1 || !U1 || !V1 || !t2 || !U2 || !V2 || !P2 || !alpha || !work || !mu)
+        return set_err("gf_general_matmul: null pointer%s", "");
+    GmmArgs A;
+    A.M = M; A.N = N; A.W = W; A.ld = ld; A.c = c;
+    A.t1 = t1; A.t1_bs = t1_bs; A.U1 = U1; A.V1 = V1;
+    A.t2 = t2; A.t2_bs = t2_bs; A.U2 = U2; A.V2 = V2; A.P2 = P2; A.alpha = alpha;
+    A.work = work;
+    hipStream_t st = (hipStream_t)stream;
+    if (W <= 64)       hipLaunchKernelGGL(k_gmm<1>, dim3(B, 2), dim3(64), 0, st, A);
+    else if (W <= 128) hipLaunchKernelGGL(k_gmm<2>, dim3(B, 2), dim3(64), 0, st, A);
+    else               hipLaunchKernelGGL(k_gmm<4>, dim3(B, 2), dim3(64), 0, st, A);
+    hipLaunchKernelGGL(k_add2, dim3((unsigned)((M + 255) / 256), B), dim3(256), 0, st, M, work, mu);
+    return check_launch("gf_general_matmul");
+}
+
+}  // extern "C"

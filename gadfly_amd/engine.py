@@ -1,0 +1,265 @@
+"""
+Device engine: B independent celerite problems resident in HBM.
+
+This is the host-side owner of the device buffers that the C-ABI
+(``include/gadfly_hip.h``) operates on.  It plays the role of celerite2's
+``numpy.GaussianProcess._do_compute/_do_solve/_do_norm/_do_dot_tril`` (reached from
+/root/reference/gadfly/gp.py:202, :350, :370, :327) for a *batch* of problems that
+share N and the term structure (Jr, Jc): independent light curves (own t, y) or MCMC
+walkers (shared t, y; own hyperparameters) -- SURVEY.md 8e.
+
+HBM layout (float64, row-major, all torch tensors on one device):
+    t, diag        (Bt, N)  Bt = 1 when shared
+    a, d, z        (B, N)
+    U, V, P, W     (B, N, ld)   ld = W rounded up to 16 (rows 128-byte aligned; pad cols
+                                hold 0 for U/V/W and 1 for P)
+    c              (B, Wd)      decay rates per column (prediction hops only)
+"""
+import math
+
+import numpy as np
+
+from . import _lib
+
+
+def _coeff_pack(coeffs_list):
+    """list of B (ar, cr, ac, bc, cc, dc, shift) -> stacked float64 arrays."""
+    Jr = len(coeffs_list[0][0])
+    Jc = len(coeffs_list[0][2])
+    B = len(coeffs_list)
+    real = np.zeros((2, B, max(Jr, 1)))
+    comp = np.zeros((4, B, max(Jc, 1)))
+    diag_add = np.zeros(B)
+    c = np.zeros((B, Jr + 2 * Jc))
+    for b, (ar, cr, ac, bc, cc, dc, shift) in enumerate(coeffs_list):
+        if len(ar) != Jr or len(ac) != Jc:
+            raise ValueError("all problems of a batch must share the term structure")
+        real[0, b, :Jr], real[1, b, :Jr] = ar, cr
+        comp[0, b, :Jc], comp[1, b, :Jc] = ac, bc
+        comp[2, b, :Jc], comp[3, b, :Jc] = cc, dc
+        diag_add[b] = float(np.sum(ar) + np.sum(ac) + shift)
+        c[b, :Jr] = cr
+        c[b, Jr::2] = cc
+        c[b, Jr + 1::2] = cc
+    return Jr, Jc, real, comp, diag_add, c
+
+
+class DeviceBatch:
+    """B problems on one GPU.  Every method only *enqueues* work on the current stream;
+    results stay on the device until the caller reads them."""
+
+    def __init__(self, coeffs_list, t, diag=None, device=None):
+        torch = _lib.require_device()
+        self.torch = torch
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self.B = len(coeffs_list)
+        self.Jr, self.Jc, real, comp, diag_add, c = _coeff_pack(coeffs_list)
+        self.W = self.Jr + 2 * self.Jc
+        self._dev = None
+        if self.W < 1 or self.W > _lib.GF_MAX_WIDTH:
+            raise ValueError(
+                f"celerite width {self.W} unsupported (1..{_lib.GF_MAX_WIDTH})")
+        self.ld = self.lib.gf_leading_dim(self.W)
+        f64 = dict(dtype=torch.float64, device=self.device)
+
+        def dev(x):
+            if isinstance(x, torch.Tensor):
+                return x.to(**f64).contiguous()
+            return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64)).to(self.device)
+
+        self._dev = dev
+        self.t = dev(t)
+        if self.t.ndim == 1:
+            self.t = self.t[None, :]
+        self.N = int(self.t.shape[1])
+        if self.t.shape[0] not in (1, self.B):
+            raise ValueError("dimension mismatch")
+        self.diag = None
+        if diag is not None:
+            self.diag = dev(diag)
+            if self.diag.ndim == 1:
+                self.diag = self.diag[None, :]
+            if self.diag.shape[1] != self.N or self.diag.shape[0] not in (1, self.B):
+                raise ValueError("dimension mismatch")
+        self._real = dev(real)
+        self._comp = dev(comp)
+        self._diag_add = dev(diag_add)
+        self.c = dev(c)
+        B, N, ld = self.B, self.N, self.ld
+        self.a = torch.empty((B, N), **f64)
+        self.U = torch.empty((B, N, ld), **f64)
+        self.V = torch.empty((B, N, ld), **f64)
+        self.P = torch.empty((B, N, ld), **f64)
+        self.d = None
+        self.Wm = None
+        self.z = None
+        self.info = torch.zeros((B,), dtype=torch.int32, device=self.device)
+        self._build()
+
+    # -- fresh hyperparameters (MCMC walkers): O(J) upload + matrix rebuild ---
+    def pack_coefficients(self, coeffs_list):
+        """Upload a new set of B coefficient tuples; returns an opaque device pack that
+        :meth:`use_coefficients` switches to without further host work."""
+        Jr, Jc, real, comp, diag_add, c = _coeff_pack(coeffs_list)
+        if (Jr, Jc) != (self.Jr, self.Jc) or len(coeffs_list) != self.B:
+            raise ValueError("coefficient pack does not match the batch structure")
+        dev = self._dev
+        return dev(real), dev(comp), dev(diag_add), dev(c)
+
+    def use_coefficients(self, pack, rebuild=True):
+        self._real, self._comp, self._diag_add, self.c = pack
+        if rebuild:
+            self._build()
+
+    def set_coefficients(self, coeffs_list):
+        self.use_coefficients(self.pack_coefficients(coeffs_list))
+
+    # -- helpers ---------------------------------------------------------
+    @staticmethod
+    def _bs(x):
+        """batch stride in elements (0 = shared)."""
+        return 0 if x.shape[0] == 1 else x.stride(0)
+
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def _build(self):
+        p = _lib.ptr
+        st = self.lib.gf_build_matrices(
+            self.B, self.N, self.Jr, self.Jc, self.ld,
+            p(self._real[0]), p(self._real[1]),
+            p(self._comp[0]), p(self._comp[1]), p(self._comp[2]), p(self._comp[3]),
+            p(self._diag_add),
+            p(self.t), self._bs(self.t),
+            p(self.diag), 0 if self.diag is None else self._bs(self.diag),
+            p(self.a), p(self.U), p(self.V), p(self.P), self._stream())
+        _lib.check(st, "gf_build_matrices")
+
+    def matrices_at(self, tstar):
+        """U*, V* at new times (M,) or (B, M) with zero diagonal (prediction)."""
+        torch = self.torch
+        ts = tstar if isinstance(tstar, torch.Tensor) else torch.as_tensor(
+            np.ascontiguousarray(tstar, dtype=np.float64))
+        ts = ts.to(dtype=torch.float64, device=self.device).contiguous()
+        if ts.ndim == 1:
+            ts = ts[None, :]
+        M = int(ts.shape[1])
+        Us = torch.empty((self.B, M, self.ld), dtype=torch.float64, device=self.device)
+        Vs = torch.empty_like(Us)
+        p = _lib.ptr
+        st = self.lib.gf_build_matrices(
+            self.B, M, self.Jr, self.Jc, self.ld,
+            p(self._real[0]), p(self._real[1]),
+            p(self._comp[0]), p(self._comp[1]), p(self._comp[2]), p(self._comp[3]),
+            p(self._diag_add), p(ts), self._bs(ts), None, 0,
+            None, p(Us), p(Vs), None, self._stream())
+        _lib.check(st, "gf_build_matrices")
+        return ts, Us, Vs
+
+    # -- factor / log-likelihood ------------------------------------------
+    def factor(self, y=None, keep_W=True):
+        """LDL^T factor; with ``y`` (resid, (N,) | (1,N) | (B,N) device tensor) also the
+        forward solve z = L^-1 y in the same sweep."""
+        torch = self.torch
+        B, N, ld = self.B, self.N, self.ld
+        f64 = dict(dtype=torch.float64, device=self.device)
+        if self.d is None:
+            self.d = torch.empty((B, N), **f64)
+        if keep_W and self.Wm is None:
+            self.Wm = torch.empty((B, N, ld), **f64)
+        yb = 0
+        if y is not None:
+            if y.ndim == 1:
+                y = y[None, :]
+            if y.shape[1] != N or y.shape[0] not in (1, B):
+                raise ValueError("dimension mismatch")
+            y = y.contiguous()
+            yb = self._bs(y)
+            if self.z is None:
+                self.z = torch.empty((B, N), **f64)
+        p = _lib.ptr
+        st = self.lib.gf_factor(
+            B, N, self.W, ld, p(self.a), p(self.U), p(self.V), p(self.P),
+            p(y), yb, p(self.d), p(self.Wm) if keep_W else None,
+            p(self.z) if y is not None else None, p(self.info), self._stream())
+        _lib.check(st, "gf_factor")
+        return self.info
+
+    def reduce(self, with_quad):
+        """(loglike (B,), logdet (B,)) device tensors from d (and z when with_quad)."""
+        torch = self.torch
+        B, N = self.B, self.N
+        f64 = dict(dtype=torch.float64, device=self.device)
+        work = torch.empty((B * int(self.lib.gf_reduce_work(N)),), **f64)
+        out = torch.empty((B,), **f64)
+        logdet = torch.empty((B,), **f64)
+        p = _lib.ptr
+        st = self.lib.gf_loglike_reduce(
+            B, N, p(self.d), p(self.z) if with_quad else None, p(self.info),
+            p(work), p(out), p(logdet), self._stream())
+        _lib.check(st, "gf_loglike_reduce")
+        return out, logdet
+
+    def log_likelihood(self, y, keep_W=False):
+        """One full evaluation per problem: factor + forward solve + reductions."""
+        self.factor(y=y, keep_W=keep_W)
+        out, _ = self.reduce(with_quad=True)
+        return out
+
+    # -- sweeps with a stored factor ---------------------------------------
+    def _sweep(self, mode, Y, scale=None, out=None):
+        """Y: (B, N, R) contiguous device tensor."""
+        torch = self.torch
+        if self.Wm is None:
+            raise RuntimeError("factor(keep_W=True) must run before solves")
+        B, N, R = Y.shape
+        Z = out if out is not None else torch.empty_like(Y)
+        p = _lib.ptr
+        st = self.lib.gf_solve(mode, B, N, self.W, self.ld, R, p(self.U), p(self.Wm),
+                               p(self.P), p(scale), p(Y), p(Z), self._stream())
+        _lib.check(st, "gf_solve")
+        return Z
+
+    def solve_lower(self, Y):
+        return self._sweep(_lib.GF_SOLVE_LOWER, Y)
+
+    def solve_upper(self, Y, scale=None):
+        return self._sweep(_lib.GF_SOLVE_UPPER, Y, scale=scale)
+
+    def apply_inverse(self, Y):
+        """K^-1 Y = L^-T D^-1 L^-1 Y (division by d fused into the upper sweep)."""
+        Z = self._sweep(_lib.GF_SOLVE_LOWER, Y)
+        return self._sweep(_lib.GF_SOLVE_UPPER, Z, scale=self.d, out=Z)
+
+    def dot_tril(self, Y):
+        """L D^{1/2} Y (sqrt(d) fused into the sweep)."""
+        return self._sweep(_lib.GF_MATMUL_LOWER, Y, scale=self.d)
+
+    def predict_at(self, alpha, ts, Us, Vs, other=None):
+        """Conditional mean at new times; ``other`` supplies (c, U, V, P) of a different
+        kernel evaluated at the observed times (celerite2's ``kernel=`` argument)."""
+        torch = self.torch
+        src = other if other is not None else self
+        B, N = self.B, self.N
+        M = int(ts.shape[1])
+        f64 = dict(dtype=torch.float64, device=self.device)
+        work = torch.empty((B * 2 * M,), **f64)
+        mu = torch.empty((B, M), **f64)
+        p = _lib.ptr
+        st = self.lib.gf_general_matmul(
+            B, M, N, src.W, src.ld, p(src.c),
+            p(ts), self._bs(ts), p(Us), p(Vs),
+            p(self.t), self._bs(self.t), p(src.U), p(src.V), p(src.P), p(alpha),
+            p(work), p(mu), self._stream())
+        _lib.check(st, "gf_general_matmul")
+        return mu
+
+    @property
+    def nbytes_algorithmic_loglike(self):
+        """ALGORITHMIC bytes of one log-likelihood evaluation, SURVEY.md 8d:
+        8 N (3 W + 4) per problem (celerite2-equivalent data flow, each array once)."""
+        return 8 * self.N * (3 * self.W + 4) * self.B
+
+
+LOG_2PI = math.log(2.0 * math.pi)

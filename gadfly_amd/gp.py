@@ -1,0 +1,383 @@
+"""
+``GaussianProcess``: gadfly's units-aware GP interface, computed on an MI355X.
+
+API mirror of /root/reference/gadfly/gp.py:13-395 (``GaussianProcess`` subclassing
+``celerite2.GaussianProcess``).  The reference's methods strip astropy units and call
+``super()``; here the ``super()`` part -- celerite2's ``BaseGaussianProcess`` state
+machine (compute / recompute / log_likelihood / apply_inverse / dot_tril / sample /
+condition / predict) -- is restated in this class and every O(N)
+operation runs through the HIP C-ABI (:mod:`gadfly_amd.engine`).  There is no CPU
+compute path.
+
+Error behaviour follows celerite2: unsorted ``t`` -> ``ValueError``; both ``yerr`` and
+``diag`` -> ``ValueError``; a method before ``compute`` -> ``RuntimeError``; a
+non-positive pivot -> ``LinAlgError`` unless ``quiet=True``, in which case the
+log-determinant is ``-inf`` and the log-likelihood ``-inf`` (gp.py:188-192).
+"""
+import numpy as np
+
+from . import units as _units
+from .engine import DeviceBatch, LOG_2PI
+
+__all__ = ["GaussianProcess", "ConditionalDistribution", "LinAlgError"]
+
+
+class LinAlgError(np.linalg.LinAlgError):
+    """celerite2.driver.LinAlgError equivalent: 'failed to factorize or solve matrix'."""
+
+
+class _ConstantMean:
+    def __init__(self, value=0.0):
+        self.value = value
+
+    def __call__(self, x):
+        return np.full(np.shape(x), self.value, dtype=np.float64)
+
+
+class ConditionalDistribution:
+    """Conditional (predictive) distribution (celerite2 ``ConditionalDistribution``;
+    built at /root/reference/gadfly/gp.py:232).  ``mean`` runs on the device; ``variance`` /
+    ``covariance`` use the dense K(t, t*) construction celerite2 uses (O(N M W), small M --
+    the scalable version is SURVEY.md 8f rank 1) with the solves on the device."""
+
+    def __init__(self, gp, y, t=None, *, include_mean=True, kernel=None):
+        self.gp = gp
+        self.y = gp._process_input(y, require_vector=True)
+        self.t = None if t is None else np.ascontiguousarray(t, dtype=np.float64)
+        if self.t is not None and self.t.ndim != 1:
+            raise ValueError("dimension mismatch")
+        self.include_mean = include_mean
+        self.kernel = kernel
+        self._alpha = None
+
+    def _get_alpha(self):
+        if self._alpha is None:
+            gp = self.gp
+            resid = gp._to_device(self.y - gp._mean_value)
+            self._alpha = gp._engine.apply_inverse(resid.reshape(1, -1, 1))
+        return self._alpha
+
+    @property
+    def mean(self):
+        gp = self.gp
+        alpha = self._get_alpha()
+        if self.t is None and self.kernel is None:
+            mu = self.y - gp._diag * alpha.reshape(-1).cpu().numpy()
+            if not self.include_mean:
+                mu = mu - gp._mean_value
+            return mu
+        xs = gp._t if self.t is None else self.t
+        if np.any(np.diff(xs) < 0.0):
+            raise ValueError("The input coordinates must be sorted")
+        if self.kernel is None:
+            eng, other = gp._engine, None
+        else:
+            # different kernel: its generator matrices at the observed times and at t*
+            other = DeviceBatch([self.kernel.get_device_coefficients()], gp._engine.t,
+                                device=gp._engine.device)
+            eng = other
+        ts, Us, Vs = eng.matrices_at(xs)
+        mu = gp._engine.predict_at(alpha.reshape(1, -1), ts, Us, Vs, other=other)
+        mu = mu.reshape(-1).cpu().numpy()
+        if self.include_mean:
+            mu = mu + gp._mean(xs)
+        return mu
+
+    def _dense_cross(self):
+        gp = self.gp
+        kernel = gp.kernel if self.kernel is None else self.kernel
+        xs = gp._t if self.t is None else self.t
+        KxsT = kernel.get_value(xs[None, :] - gp._t[:, None])          # (N, M)
+        sol = gp._engine.apply_inverse(gp._to_device(KxsT)[None, :, :])
+        return kernel, xs, KxsT, sol[0].cpu().numpy()
+
+    @property
+    def variance(self):
+        kernel, xs, KxsT, KinvK = self._dense_cross()
+        return kernel.get_value(np.zeros(1))[0] - np.sum(KxsT * KinvK, axis=0)
+
+    @property
+    def covariance(self):
+        kernel, xs, KxsT, KinvK = self._dense_cross()
+        return kernel.get_value(xs[:, None] - xs[None, :]) - KxsT.T @ KinvK
+
+    def sample(self, *, size=None, regularize=None):
+        mu = self.mean
+        cov = self.covariance
+        if regularize is not None:
+            cov[np.diag_indices_from(cov)] += regularize
+        return np.random.multivariate_normal(mu, cov, size=size)
+
+
+class GaussianProcess:
+    """
+    The ``gadfly`` interface to the GP solver, on the GPU.
+
+    Parameters follow /root/reference/gadfly/gp.py:22-59: ``kernel`` (a
+    :class:`~gadfly_amd.terms.Term`, e.g. ``StellarOscillatorKernel``), ``t`` (astropy
+    Quantity/Time, or an ndarray already in 1/uHz), ``mean`` (scalar or callable),
+    ``light_curve`` (lightkurve-like object with ``time``, ``flux``, ``flux_err``) and
+    ``**kwargs`` forwarded to :meth:`compute`.  ``device`` selects the GPU.
+    """
+
+    conditional_distribution = ConditionalDistribution
+
+    def __init__(self, kernel, t=None, mean=0.0, light_curve=None, device=None,
+                 **kwargs):
+        self._original_flux_median = None
+        self.kernel = kernel
+        self.mean = mean
+        self._device = device
+        self._engine = None
+        self._t = None
+        self._mean_value = None
+        self._diag = None
+        self._size = None
+        self._log_det = -np.inf
+        self._norm = np.inf
+
+        if t is not None:
+            t = self._time_to_freq(t)
+
+        if light_curve is not None:
+            t = self._time_to_freq(light_curve.time)
+            flux = light_curve.flux
+            if hasattr(flux, "unmasked"):
+                median_flux = np.nanmedian(flux.unmasked)
+            else:
+                median_flux = np.median(flux)
+            self._original_flux_median = median_flux
+            kwargs["yerr"] = self._flux_to_ppm(light_curve.flux_err, is_error=True)
+
+        if t is not None:
+            self.compute(t, **kwargs)
+
+    # ---- mean function (celerite2 BaseGaussianProcess.mean) ---------------
+    @property
+    def mean(self):
+        return self._mean
+
+    @mean.setter
+    def mean(self, mean):
+        self._mean = mean if callable(mean) else _ConstantMean(mean)
+
+    @property
+    def mean_value(self):
+        if self._mean_value is None:
+            raise RuntimeError(
+                "'compute' must be executed before accessing mean_value")
+        return self._mean_value
+
+    # ---- unit handling (reference gp.py:61-165) ----------------------------
+    @staticmethod
+    def _time_to_freq(time, freq_unit=None):
+        """Times -> 1/uHz.  ndarrays pass through untouched (gp.py:82-84)."""
+        if _units.is_time(time):
+            time = time.jd * _units.u.day
+        if not _units.has_unit(time):
+            return time
+        _units.require_astropy("a Quantity time axis")
+        unit = _units.u.uHz if freq_unit is None else freq_unit
+        return time.to(1 / unit).value
+
+    def _flux_to_ppm(self, flux, flux_unit=None, is_error=False):
+        """Fluxes -> ppm.  ndarrays pass through untouched (gp.py:111-113)."""
+        if isinstance(flux, np.ndarray) and not _units.has_unit(flux):
+            return flux
+        if not _units.has_unit(flux):
+            return np.asarray(flux, dtype=np.float64)
+        _units.require_astropy("a Quantity flux")
+        u = _units.u
+        if flux.unit.is_equivalent(u.electron / u.s):
+            # lightkurve fluxes: normalise by the cached median (gp.py:115-124)
+            if is_error:
+                return 1e6 * (flux / self._original_flux_median).value
+            return 1e6 * (flux / self._original_flux_median - 1).value
+        return flux.to(u.cds.ppm if flux_unit is None else flux_unit).value
+
+    def _ppm_to_flux(self, value_in_ppm, power=1):
+        """ppm -> the light curve's original units (gp.py:128-165), quirks kept."""
+        if self._original_flux_median is not None and power == 1:
+            return (1e-6 * value_in_ppm + 1) * self._original_flux_median
+        elif self._original_flux_median is not None and power == 2:
+            return ((1e-6 * value_in_ppm) * self._original_flux_median
+                    * self._original_flux_median.unit)
+        _units.require_astropy("return_quantity=True")
+        return _units.u.Quantity(value_in_ppm, unit=_units.u.cds.ppm)
+
+    # ---- helpers ------------------------------------------------------------
+    def _to_device(self, x):
+        eng = self._engine
+        return eng.torch.as_tensor(
+            np.ascontiguousarray(x, dtype=np.float64)).to(eng.device)
+
+    def _process_input(self, y, *, require_vector=False):
+        if self._t is None:
+            raise RuntimeError("The process must be initialized with compute")
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if y.ndim == 0 or self._t.shape[0] != y.shape[0]:
+            raise ValueError("dimension mismatch")
+        if require_vector and y.ndim != 1:
+            raise ValueError("'y' must be one dimensional")
+        if y.ndim > 2:
+            raise ValueError("dimension mismatch")
+        return y
+
+    # ---- compute (reference gp.py:167-204 + celerite2 base compute) ----------
+    def compute(self, t, yerr=None, diag=None, check_sorted=True, quiet=False):
+        """Build the generator matrices and factorise K on the device."""
+        if _units.is_time(t) or _units.has_unit(t):
+            t = self._time_to_freq(t)
+        if yerr is not None and _units.has_unit(yerr):
+            yerr = self._flux_to_ppm(yerr, is_error=True)
+        # reference quirk (gp.py:200): diag is converted only if *yerr* has a unit
+        if diag is not None and _units.has_unit(yerr):
+            diag = self._flux_to_ppm(diag)
+
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        if t.ndim != 1:
+            raise ValueError("dimension mismatch")
+        if check_sorted and np.any(np.diff(t) < 0.0):
+            raise ValueError("The input coordinates must be sorted")
+        N = t.shape[0]
+        self._t = t
+        self._size = N
+        self._mean_value = self._mean(t)
+        self._diag = np.zeros(N, dtype=np.float64)
+        if yerr is not None:
+            if diag is not None:
+                raise ValueError("only one of 'diag' and 'yerr' can be provided")
+            self._diag += np.broadcast_to(np.asarray(yerr, dtype=np.float64), (N,)) ** 2
+        elif diag is not None:
+            self._diag += np.broadcast_to(np.asarray(diag, dtype=np.float64), (N,))
+
+        self._engine = DeviceBatch([self.kernel.get_device_coefficients()], t,
+                                   diag=self._diag, device=self._device)
+        self._do_compute(quiet)
+
+    def recompute(self, *, quiet=False):
+        if self._t is None:
+            raise RuntimeError("The process must be initialized with compute")
+        self._do_compute(quiet)
+
+    def _do_compute(self, quiet):
+        eng = self._engine
+        info = eng.factor(keep_W=True)
+        _, logdet = eng.reduce(with_quad=False)
+        failed = int(info[0].item())
+        if failed:
+            if not quiet:
+                raise LinAlgError(
+                    f"failed to factorize or solve matrix (pivot {failed} of "
+                    f"{self._size} is not positive)")
+            self._log_det = -np.inf
+            self._norm = np.inf
+        else:
+            self._log_det = float(logdet[0].item())
+            self._norm = 0.5 * (self._log_det + self._size * LOG_2PI)
+
+    # ---- celerite2 _do_* equivalents ----------------------------------------
+    def _do_solve(self, y):
+        Y = self._to_device(y).reshape(1, self._size, -1)
+        Z = self._engine.apply_inverse(Y)
+        return Z.reshape(y.shape).cpu().numpy()
+
+    def _do_dot_tril(self, y):
+        Y = self._to_device(y).reshape(1, self._size, -1)
+        Z = self._engine.dot_tril(Y)
+        return Z.reshape(y.shape).cpu().numpy()
+
+    def _do_norm(self, y):
+        eng = self._engine
+        Y = self._to_device(y).reshape(1, self._size, 1)
+        z = eng.solve_lower(Y).reshape(-1)
+        return float((z * z / eng.d[0]).sum().item())
+
+    # ---- public numerical API (reference gp.py:308-395) ------------------------
+    def dot_tril(self, y, *, inplace=False):
+        """``L D^{1/2} y`` with K = L D L^T (the mean is not applied)."""
+        if _units.has_unit(y):
+            y = self._flux_to_ppm(y)
+        y_in = y
+        y = self._process_input(y)
+        out = self._do_dot_tril(y)
+        if inplace and isinstance(y_in, np.ndarray) and y_in.dtype == np.float64:
+            y_in[...] = out
+            return y_in
+        return out
+
+    def log_likelihood(self, y, *, inplace=False):
+        """Marginalised log-likelihood of ``y`` under the factorised model."""
+        if _units.has_unit(y):
+            y = self._flux_to_ppm(y)
+        y = self._process_input(y, require_vector=True)
+        if not np.isfinite(self._log_det):
+            return -np.inf
+        return -0.5 * self._do_norm(y - self._mean_value) - self._norm
+
+    def apply_inverse(self, y, *, inplace=False):
+        """``K^-1 y`` (the mean is not applied)."""
+        if _units.has_unit(y):
+            y = self._flux_to_ppm(y)
+        y_in = y
+        y = self._process_input(y)
+        out = self._do_solve(y)
+        if inplace and isinstance(y_in, np.ndarray) and y_in.dtype == np.float64:
+            y_in[...] = out
+            return y_in
+        return out
+
+    def sample(self, *, size=None, include_mean=True, return_quantity=False):
+        """Prior draws (reference gp.py:372-395, including its mean-subtraction quirk:
+        the across-realisation mean is removed for ``size`` draws, the time-mean for one)."""
+        if self._t is None:
+            raise RuntimeError("The process must be initialized with compute")
+        # celerite2 draws from numpy's legacy global RNG (tests seed np.random.seed(42))
+        if size is None:
+            n = np.random.randn(self._size)
+        else:
+            n = np.random.randn(self._size, size)
+        result = self._do_dot_tril(n).T
+        if include_mean:
+            result = result + self._mean_value
+        result -= result.mean(axis=0 if result.ndim == 2 else None)
+        if return_quantity:
+            return self._ppm_to_flux(result)
+        return result
+
+    def condition(self, y, t=None, include_mean=True, kernel=None,
+                  return_quantity=False):
+        """Condition the GP on observations ``y`` (reference gp.py:206-239)."""
+        if t is not None and (_units.is_time(t) or _units.has_unit(t)):
+            t = self._time_to_freq(t)
+        if _units.has_unit(y):
+            y = self._flux_to_ppm(y)
+        result = self.conditional_distribution(
+            self, y, t=t, include_mean=include_mean, kernel=kernel)
+        if return_quantity:
+            return self._ppm_to_flux(result.mean)
+        return result
+
+    def predict(self, y, t=None, return_cov=False, return_var=False,
+                include_mean=True, kernel=None, return_quantity=False):
+        """Conditional mean (and variance / covariance) (reference gp.py:241-306)."""
+        if _units.has_unit(y):
+            y = self._flux_to_ppm(y)
+        if _units.is_time(t) or _units.has_unit(t):
+            t = self._time_to_freq(t)
+
+        cond = self.condition(y, t=t, include_mean=include_mean, kernel=kernel)
+
+        if return_var and return_quantity:
+            return (self._ppm_to_flux(cond.mean),
+                    self._ppm_to_flux(cond.variance, power=2))
+        elif return_cov and return_quantity:
+            return (self._ppm_to_flux(cond.mean),
+                    self._ppm_to_flux(cond.covariance, power=2))
+        elif return_quantity:
+            return self._ppm_to_flux(cond.mean)
+        elif return_var:
+            return cond.mean, cond.variance
+        elif return_cov:
+            return cond.mean, cond.covariance
+        return cond.mean
