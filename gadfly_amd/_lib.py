@@ -32,12 +32,15 @@ SIGNATURES = {
     "gf_version": (_int, []),
     "gf_last_error": (ctypes.c_char_p, []),
     "gf_leading_dim": (_int, [_int]),
-    "gf_build_matrices": (_int, [_int, _i64, _int, _int, _int] + [_vp] * 7
+    "gf_build_matrices": (_int, [_int, _i64, _i64, _int, _int, _int] + [_vp] * 7
                           + [_vp, _i64, _vp, _i64] + [_vp] * 4 + [_vp]),
-    "gf_factor": (_int, [_int, _i64, _int, _int] + [_vp] * 4 + [_vp, _i64]
-                  + [_vp] * 4 + [_vp]),
+    "gf_state_size": (_i64, [_int]),
+    "gf_state_cols": (_int, [_int]),
+    "gf_factor": (_int, [_int, _i64, _i64, _int, _int] + [_vp] * 4 + [_vp, _i64]
+                  + [_vp] * 6 + [_vp]),
     "gf_reduce_work": (_i64, [_i64]),
-    "gf_loglike_reduce": (_int, [_int, _i64] + [_vp] * 6 + [_vp]),
+    "gf_reduce_tile": (_int, [_int, _i64] + [_vp] * 4 + [_int, _vp]),
+    "gf_loglike_finish": (_int, [_int, _i64] + [_vp] * 4 + [_vp]),
     "gf_solve": (_int, [_int, _int, _i64, _int, _int, _int] + [_vp] * 6 + [_vp]),
     "gf_general_matmul": (_int, [_int, _i64, _i64, _int, _int, _vp,
                                  _vp, _i64, _vp, _vp,

@@ -12,7 +12,7 @@ Two batch shapes:
 """
 import numpy as np
 
-from .engine import DeviceBatch
+from .engine import StreamingBatch
 
 __all__ = ["BatchedLogLikelihood", "log_likelihood_batch"]
 
@@ -21,7 +21,8 @@ class BatchedLogLikelihood:
     """Reusable evaluator: device buffers are allocated once; each :meth:`evaluate` with new
     kernels costs an O(B J) coefficient upload plus the device work."""
 
-    def __init__(self, kernels, t, y, yerr=None, diag=None, mean=0.0, device=None):
+    def __init__(self, kernels, t, y, yerr=None, diag=None, mean=0.0, device=None,
+                 tile_rows=8192):
         if yerr is not None and diag is not None:
             raise ValueError("only one of 'diag' and 'yerr' can be provided")
         t = np.ascontiguousarray(t, dtype=np.float64)
@@ -37,11 +38,8 @@ class BatchedLogLikelihood:
             d = np.asarray(diag, dtype=np.float64)
         if d is not None and d.ndim == 0:
             d = np.full(t.shape[-1], float(d))
-        self.engine = DeviceBatch([k.get_device_coefficients() for k in kernels], t,
-                                  diag=d, device=device)
-        eng = self.engine
-        resid = y - mean
-        self.resid = eng.torch.as_tensor(np.ascontiguousarray(resid)).to(eng.device)
+        self.engine = StreamingBatch([k.get_device_coefficients() for k in kernels], t,
+                                     y - mean, diag=d, tile_rows=tile_rows, device=device)
 
     @property
     def B(self):
@@ -56,7 +54,7 @@ class BatchedLogLikelihood:
         eng = self.engine
         if pack is not None:
             eng.use_coefficients(pack)
-        return eng.log_likelihood(self.resid, keep_W=False)
+        return eng.log_likelihood()
 
     def evaluate(self, kernels=None):
         out = self.evaluate_device(None if kernels is None else self.pack(kernels))

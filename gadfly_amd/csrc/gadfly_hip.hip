@@ -94,7 +94,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // K0: generator rows + propagator rows
 // ------------------------------------------------------------------------------------
 struct BuildArgs {
-    int64_t N;
+    int64_t N, n_first;             // rows built: global n_first .. n_first + N - 1
     int Jr, Jc, ld, units;          // units per row = Jr + Jc + (ld - W)
     const double *ar, *cr, *ac, *bc, *cc, *dc, *diag_add;
     const double *t; int64_t t_bs;
@@ -110,18 +110,19 @@ __global__ void __launch_bounds__(256) k_build(const BuildArgs A) {
     const int q = (int)(id - n * A.units);
     const int W = A.Jr + 2 * A.Jc;
     const double *t = A.t + (size_t)b * A.t_bs;
-    const double tn = t[n];
-    const double dt = (n > 0) ? (t[n - 1] - tn) : 0.0;
+    const int64_t ng = A.n_first + n;                // global row (t, diag are global arrays)
+    const double tn = t[ng];
+    const double dt = (ng > 0) ? (t[ng - 1] - tn) : 0.0;
     const size_t row = ((size_t)b * A.N + n) * A.ld;
     if (q == 0 && A.a) {
-        const double dg = A.diag ? A.diag[(size_t)b * A.diag_bs + n] : 0.0;
+        const double dg = A.diag ? A.diag[(size_t)b * A.diag_bs + ng] : 0.0;
         A.a[(size_t)b * A.N + n] = dg + A.diag_add[b];
     }
     if (q < A.Jr) {                                  // real term: one column
         const double ar = A.ar[(size_t)b * A.Jr + q], cr = A.cr[(size_t)b * A.Jr + q];
         A.U[row + q] = ar;
         A.V[row + q] = 1.0;
-        if (A.P) A.P[row + q] = (n > 0) ? exp(cr * dt) : 1.0;
+        if (A.P) A.P[row + q] = (ng > 0) ? exp(cr * dt) : 1.0;
     } else if (q < A.Jr + A.Jc) {                    // complex term: two columns
         const int k = q - A.Jr;
         const size_t ck = (size_t)b * A.Jc + k;
@@ -135,7 +136,7 @@ __global__ void __launch_bounds__(256) k_build(const BuildArgs A) {
         A.V[row + j]     = co;
         A.V[row + j + 1] = si;
         if (A.P) {
-            const double p = (n > 0) ? exp(cc * dt) : 1.0;
+            const double p = (ng > 0) ? exp(cc * dt) : 1.0;
             A.P[row + j] = p;
             A.P[row + j + 1] = p;
         }
@@ -159,7 +160,7 @@ __global__ void __launch_bounds__(256) k_build(const BuildArgs A) {
 //   vectors in its private LDS slice and reads them back as broadcasts.
 // ------------------------------------------------------------------------------------
 struct FactorArgs {
-    int64_t N, chunk_len;
+    int64_t N, chunk_len, n_first;  // n_first: global index of row 0 (tile streaming), for info
     int W, ld;
     const double *a, *U, *V, *P;
     const double *y; int64_t y_bs;
@@ -201,6 +202,7 @@ __global__ void __launch_bounds__(64 * NW) k_factor(const FactorArgs A) {
         Fv[c] = 0.0;
     }
     const size_t sidx = (size_t)b * nch + ch;
+    if (A.info[sidx] != 0) return;      // an earlier tile of this problem already failed
     if (A.S_in) {
         const double *Si = A.S_in + sidx * RT * WPC;
 #pragma unroll
@@ -303,7 +305,8 @@ __global__ void __launch_bounds__(64 * NW) k_factor(const FactorArgs A) {
         const double dn = a_n - s1;
         const double zn = y_n - s2;
         if (!(dn > 0.0)) {              // uniform across the whole workgroup
-            fail = (int32_t)(n + 1 > 0x7fffffff ? 0x7fffffff : n + 1);
+            const int64_t ng = A.n_first + n + 1;
+            fail = (int32_t)(ng > 0x7fffffff ? 0x7fffffff : ng);
             break;
         }
 #pragma unroll
@@ -326,7 +329,8 @@ __global__ void __launch_bounds__(64 * NW) k_factor(const FactorArgs A) {
         zprev = zn;
     }
 
-    if (wave == 0 && lane == 0) A.info[sidx] = fail;
+    if (fail && wave == 0 && lane == 0) A.info[sidx] = fail;
+    if (fail) return;
 
     if (A.S_out) {                      // state handed to the next chunk: pending update, no decay
         wave_lds_fence();
@@ -383,8 +387,8 @@ __global__ void __launch_bounds__(RED_BLOCK) k_reduce1(int64_t N, const double *
     }
 }
 
-__global__ void __launch_bounds__(64) k_reduce2(int64_t N, int G, const double *work,
-                                                const int32_t *info, double *out, double *logdet) {
+// acc[b] = {sum log d, sum z^2/d}; init != 0 overwrites, else adds (tile streaming, fixed order)
+__global__ void __launch_bounds__(64) k_reduce2(int G, const double *work, double *acc, int init) {
     const int b = blockIdx.x, lane = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
     for (int g = lane; g < G; g += 64) {
@@ -393,12 +397,20 @@ __global__ void __launch_bounds__(64) k_reduce2(int64_t N, int G, const double *
     }
     wave_sum2(s1, s2);
     if (lane == 0) {
-        const bool bad = info && info[b] != 0;
-        const double ld = bad ? -INFINITY : s1;
-        if (logdet) logdet[b] = ld;
-        if (out) out[b] = bad ? -INFINITY
-                              : (-0.5 * (s1 + (double)N * 1.8378770664093453) - 0.5 * s2);
+        if (!init) { s1 += acc[2 * b]; s2 += acc[2 * b + 1]; }
+        acc[2 * b] = s1;
+        acc[2 * b + 1] = s2;
     }
+}
+
+__global__ void k_finish(int B, int64_t N, const double *acc, const int32_t *info,
+                         double *out, double *logdet) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const bool bad = info && info[b] != 0;
+    const double s1 = acc[2 * b], s2 = acc[2 * b + 1];
+    if (logdet) logdet[b] = bad ? -INFINITY : s1;
+    if (out) out[b] = bad ? -INFINITY : (-0.5 * (s1 + (double)N * 1.8378770664093453) - 0.5 * s2);
 }
 
 // ------------------------------------------------------------------------------------
@@ -669,7 +681,7 @@ int gf_leading_dim(int W) {
     return (W + 15) / 16 * 16;
 }
 
-int gf_build_matrices(int B, int64_t N, int Jr, int Jc, int ld,
+int gf_build_matrices(int B, int64_t N, int64_t n_first, int Jr, int Jc, int ld,
                       const double *ar, const double *cr, const double *ac,
                       const double *bc, const double *cc, const double *dc,
                       const double *diag_add,
@@ -682,7 +694,8 @@ int gf_build_matrices(int B, int64_t N, int Jr, int Jc, int ld,
     if (ld < W || (ld & 15)) return set_err("gf_build_matrices: ld=%s%lld must be a multiple of 16 and >= W=%lld", "", ld, W);
     if (!t || !U || !V || (a && !diag_add)) return set_err("gf_build_matrices: null pointer%s", "");
     BuildArgs A;
-    A.N = N; A.Jr = Jr; A.Jc = Jc; A.ld = ld; A.units = Jr + Jc + (ld - W);
+    if (n_first < 0) return set_err("gf_build_matrices: negative n_first%s", "");
+    A.N = N; A.n_first = n_first; A.Jr = Jr; A.Jc = Jc; A.ld = ld; A.units = Jr + Jc + (ld - W);
     A.ar = ar; A.cr = cr; A.ac = ac; A.bc = bc; A.cc = cc; A.dc = dc; A.diag_add = diag_add;
     A.t = t; A.t_bs = t_bs; A.diag = diag; A.diag_bs = diag_bs;
     A.a = a; A.U = U; A.V = V; A.P = P;
@@ -693,35 +706,61 @@ int gf_build_matrices(int B, int64_t N, int Jr, int Jc, int ld,
     return check_launch("gf_build_matrices");
 }
 
-int gf_factor(int B, int64_t N, int W, int ld,
+int64_t gf_state_size(int W) {
+    if (W < 1 || W > GF_MAX_WIDTH) return -1;
+    if (W <= 16)  return 16 * 64;
+    if (W <= 32)  return 32 * 64;
+    if (W <= 48)  return 48 * 64;
+    if (W <= 64)  return 64 * 64;
+    if (W <= 96)  return 96 * 128;
+    if (W <= 128) return 128 * 128;
+    if (W <= 192) return 192 * 192;
+    return 256 * 256;
+}
+
+int gf_state_cols(int W) {
+    if (W < 1 || W > GF_MAX_WIDTH) return -1;
+    return (W + 63) / 64 * 64;
+}
+
+int gf_factor(int B, int64_t N, int64_t n_first, int W, int ld,
               const double *a, const double *U, const double *V, const double *P,
               const double *y, int64_t y_bs,
-              double *d, double *Wm, double *z, int32_t *info, void *stream) {
+              double *d, double *Wm, double *z,
+              double *S_state, double *F_state, int32_t *info, void *stream) {
     if (B < 1 || N < 1) return set_err("gf_factor: empty problem (B=%s%lld, N=%lld)", "", B, N);
     if (W < 1 || W > GF_MAX_WIDTH) return set_err("gf_factor: width %s%lld unsupported (max %lld)", "", W, GF_MAX_WIDTH);
     if (ld < W || (ld & 15)) return set_err("gf_factor: ld=%s%lld must be a multiple of 16 and >= W=%lld", "", ld, W);
     if (!a || !U || !V || !P || !d || !info) return set_err("gf_factor: null pointer%s", "");
     if (z && !y) return set_err("gf_factor: z requested without y%s", "");
     FactorArgs A;
-    A.N = N; A.chunk_len = N; A.W = W; A.ld = ld;
+    if (F_state && !S_state) return set_err("gf_factor: F_state without S_state%s", "");
+    A.N = N; A.chunk_len = N; A.n_first = n_first; A.W = W; A.ld = ld;
     A.a = a; A.U = U; A.V = V; A.P = P; A.y = y; A.y_bs = y_bs;
     A.d = d; A.Wm = Wm; A.z = z;
-    A.S_in = nullptr; A.F_in = nullptr; A.S_out = nullptr; A.F_out = nullptr;
+    A.S_in = S_state; A.F_in = F_state; A.S_out = S_state; A.F_out = F_state;
     A.info = info;
     return dispatch_factor(A, B, 1, (hipStream_t)stream);
 }
 
 int64_t gf_reduce_work(int64_t N) { return 2 * (int64_t)red_groups(N); }
 
-int gf_loglike_reduce(int B, int64_t N, const double *d, const double *z,
-                      const int32_t *info, double *work, double *out, double *logdet,
-                      void *stream) {
-    if (B < 1 || N < 1) return set_err("gf_loglike_reduce: empty problem (B=%s%lld, N=%lld)", "", B, N);
-    if (!d || !work || (!out && !logdet)) return set_err("gf_loglike_reduce: null pointer%s", "");
+int gf_reduce_tile(int B, int64_t N, const double *d, const double *z,
+                   double *work, double *acc, int init, void *stream) {
+    if (B < 1 || N < 1) return set_err("gf_reduce_tile: empty problem (B=%s%lld, N=%lld)", "", B, N);
+    if (!d || !work || !acc) return set_err("gf_reduce_tile: null pointer%s", "");
     const int G = red_groups(N);
     hipLaunchKernelGGL(k_reduce1, dim3(G, B), dim3(RED_BLOCK), 0, (hipStream_t)stream, N, d, z, work);
-    hipLaunchKernelGGL(k_reduce2, dim3(B), dim3(64), 0, (hipStream_t)stream, N, G, work, info, out, logdet);
-    return check_launch("gf_loglike_reduce");
+    hipLaunchKernelGGL(k_reduce2, dim3(B), dim3(64), 0, (hipStream_t)stream, G, work, acc, init);
+    return check_launch("gf_reduce_tile");
+}
+
+int gf_loglike_finish(int B, int64_t N, const double *acc, const int32_t *info,
+                      double *out, double *logdet, void *stream) {
+    if (B < 1 || N < 1) return set_err("gf_loglike_finish: empty problem (B=%s%lld, N=%lld)", "", B, N);
+    if (!acc || (!out && !logdet)) return set_err("gf_loglike_finish: null pointer%s", "");
+    hipLaunchKernelGGL(k_finish, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, N, acc, info, out, logdet);
+    return check_launch("gf_loglike_finish");
 }
 
 int gf_solve(int mode, int B, int64_t N, int W, int ld, int R,

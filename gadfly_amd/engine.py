@@ -95,6 +95,9 @@ class DeviceBatch:
         self.Wm = None
         self.z = None
         self.info = torch.zeros((B,), dtype=torch.int32, device=self.device)
+        # optional HIP-event timing of the factor launch (bench.py roofline leg)
+        self.time_factor = False
+        self.factor_events = []
         self._build()
 
     # -- fresh hyperparameters (MCMC walkers): O(J) upload + matrix rebuild ---
@@ -127,7 +130,7 @@ class DeviceBatch:
     def _build(self):
         p = _lib.ptr
         st = self.lib.gf_build_matrices(
-            self.B, self.N, self.Jr, self.Jc, self.ld,
+            self.B, self.N, 0, self.Jr, self.Jc, self.ld,
             p(self._real[0]), p(self._real[1]),
             p(self._comp[0]), p(self._comp[1]), p(self._comp[2]), p(self._comp[3]),
             p(self._diag_add),
@@ -149,7 +152,7 @@ class DeviceBatch:
         Vs = torch.empty_like(Us)
         p = _lib.ptr
         st = self.lib.gf_build_matrices(
-            self.B, M, self.Jr, self.Jc, self.ld,
+            self.B, M, 0, self.Jr, self.Jc, self.ld,
             p(self._real[0]), p(self._real[1]),
             p(self._comp[0]), p(self._comp[1]), p(self._comp[2]), p(self._comp[3]),
             p(self._diag_add), p(ts), self._bs(ts), None, 0,
@@ -179,10 +182,19 @@ class DeviceBatch:
             if self.z is None:
                 self.z = torch.empty((B, N), **f64)
         p = _lib.ptr
+        if self.time_factor:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self.info.zero_()
         st = self.lib.gf_factor(
-            B, N, self.W, ld, p(self.a), p(self.U), p(self.V), p(self.P),
+            B, N, 0, self.W, ld, p(self.a), p(self.U), p(self.V), p(self.P),
             p(y), yb, p(self.d), p(self.Wm) if keep_W else None,
-            p(self.z) if y is not None else None, p(self.info), self._stream())
+            p(self.z) if y is not None else None, None, None, p(self.info),
+            self._stream())
+        if self.time_factor:
+            e1.record()
+            self.factor_events.append((e0, e1))
         _lib.check(st, "gf_factor")
         return self.info
 
@@ -192,13 +204,16 @@ class DeviceBatch:
         B, N = self.B, self.N
         f64 = dict(dtype=torch.float64, device=self.device)
         work = torch.empty((B * int(self.lib.gf_reduce_work(N)),), **f64)
+        acc = torch.empty((B, 2), **f64)
         out = torch.empty((B,), **f64)
         logdet = torch.empty((B,), **f64)
         p = _lib.ptr
-        st = self.lib.gf_loglike_reduce(
-            B, N, p(self.d), p(self.z) if with_quad else None, p(self.info),
-            p(work), p(out), p(logdet), self._stream())
-        _lib.check(st, "gf_loglike_reduce")
+        st = self.lib.gf_reduce_tile(B, N, p(self.d), p(self.z) if with_quad else None,
+                                     p(work), p(acc), 1, self._stream())
+        _lib.check(st, "gf_reduce_tile")
+        st = self.lib.gf_loglike_finish(B, N, p(acc), p(self.info), p(out), p(logdet),
+                                        self._stream())
+        _lib.check(st, "gf_loglike_finish")
         return out, logdet
 
     def log_likelihood(self, y, keep_W=False):
@@ -263,3 +278,158 @@ class DeviceBatch:
 
 
 LOG_2PI = math.log(2.0 * math.pi)
+
+
+class StreamingBatch:
+    """
+    B independent log-likelihood evaluations streamed through fixed-size tile buffers.
+
+    The time axis is cut into tiles of ``tile_rows`` rows.  For each tile the generator rows
+    (U, V, P: B x tile_rows x ld) are built, the factor + forward-solve sweep advances every
+    problem by one tile (recurrence state handed over in HBM: S (W x W) and F (W) per
+    problem), and the tile's sum log d / sum z^2/d are accumulated.  U/V/P therefore never
+    exist for the whole series: a walker costs ~3 * 8 * tile_rows * ld bytes of HBM instead
+    of 3 * 8 * N * ld, which is what lets hundreds of N = 1e6 evaluations share one GPU.
+    Two tile buffers and two streams overlap the build of tile k+1 with the sweep of tile k.
+    """
+
+    def __init__(self, coeffs_list, t, y, diag=None, tile_rows=8192, device=None):
+        torch = _lib.require_device()
+        self.torch = torch
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self.B = len(coeffs_list)
+        self.Jr, self.Jc, real, comp, diag_add, c = _coeff_pack(coeffs_list)
+        self.W = self.Jr + 2 * self.Jc
+        if self.W < 1 or self.W > _lib.GF_MAX_WIDTH:
+            raise ValueError(
+                f"celerite width {self.W} unsupported (1..{_lib.GF_MAX_WIDTH})")
+        self.ld = self.lib.gf_leading_dim(self.W)
+        f64 = dict(dtype=torch.float64, device=self.device)
+
+        def dev(x):
+            if isinstance(x, torch.Tensor):
+                return x.to(**f64).contiguous()
+            return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64)).to(self.device)
+
+        self._dev = dev
+
+        def rows(x, name):
+            x = dev(x)
+            if x.ndim == 1:
+                x = x[None, :]
+            if x.shape[0] not in (1, self.B):
+                raise ValueError("dimension mismatch")
+            return x
+
+        self.t = rows(t, "t")
+        self.N = int(self.t.shape[1])
+        self.y = rows(y, "y")
+        if self.y.shape[1] != self.N:
+            raise ValueError("dimension mismatch")
+        self.diag = None
+        if diag is not None:
+            self.diag = rows(diag, "diag")
+            if self.diag.shape[1] != self.N:
+                raise ValueError("dimension mismatch")
+        self._pack = (dev(real), dev(comp), dev(diag_add), dev(c))
+        B, ld = self.B, self.ld
+        self.tile_rows = T = int(min(max(int(tile_rows), 1), self.N))
+        self.bufs = [dict(a=torch.empty((B, T), **f64), U=torch.empty((B, T, ld), **f64),
+                          V=torch.empty((B, T, ld), **f64), P=torch.empty((B, T, ld), **f64))
+                     for _ in range(2 if T < self.N else 1)]
+        self.d = torch.empty((B, T), **f64)
+        self.z = torch.empty((B, T), **f64)
+        self.S_state = torch.empty((B, int(self.lib.gf_state_size(self.W))), **f64)
+        self.F_state = torch.empty((B, int(self.lib.gf_state_cols(self.W))), **f64)
+        self.acc = torch.empty((B, 2), **f64)
+        self.work = torch.empty((B * int(self.lib.gf_reduce_work(T)),), **f64)
+        self.info = torch.zeros((B,), dtype=torch.int32, device=self.device)
+        self.out = torch.empty((B,), **f64)
+        self.side = torch.cuda.Stream(device=self.device)
+        self.time_factor = False
+        self.factor_events = []
+
+    @staticmethod
+    def _bs(x):
+        return 0 if x.shape[0] == 1 else x.stride(0)
+
+    def pack_coefficients(self, coeffs_list):
+        Jr, Jc, real, comp, diag_add, c = _coeff_pack(coeffs_list)
+        if (Jr, Jc) != (self.Jr, self.Jc) or len(coeffs_list) != self.B:
+            raise ValueError("coefficient pack does not match the batch structure")
+        dev = self._dev
+        return dev(real), dev(comp), dev(diag_add), dev(c)
+
+    def use_coefficients(self, pack):
+        self._pack = pack
+
+    def _build_tile(self, k, buf, stream):
+        n0 = k * self.tile_rows
+        rows = min(self.tile_rows, self.N - n0)
+        real, comp, diag_add, _ = self._pack
+        p = _lib.ptr
+        st = self.lib.gf_build_matrices(
+            self.B, rows, n0, self.Jr, self.Jc, self.ld,
+            p(real[0]), p(real[1]), p(comp[0]), p(comp[1]), p(comp[2]), p(comp[3]),
+            p(diag_add), p(self.t), self._bs(self.t),
+            p(self.diag), 0 if self.diag is None else self._bs(self.diag),
+            p(buf["a"]), p(buf["U"]), p(buf["V"]), p(buf["P"]), stream.cuda_stream)
+        _lib.check(st, "gf_build_matrices")
+
+    def log_likelihood(self):
+        """Enqueue one evaluation per problem; returns the (B,) device tensor (no sync)."""
+        torch = self.torch
+        lib, p = self.lib, _lib.ptr
+        main = torch.cuda.current_stream(self.device)
+        side = self.side
+        T, N, B = self.tile_rows, self.N, self.B
+        ntiles = (N + T - 1) // T
+        self.S_state.zero_()
+        self.F_state.zero_()
+        self.info.zero_()
+        nb = len(self.bufs)
+        built = [None] * nb          # event: tile in buffer i is built
+        freed = [None] * nb          # event: sweep that used buffer i is done
+        side.wait_stream(main)
+        for k in range(min(nb, ntiles)):
+            with torch.cuda.stream(side):
+                self._build_tile(k, self.bufs[k % nb], side)
+                built[k % nb] = side.record_event()
+        for k in range(ntiles):
+            i = k % nb
+            buf = self.bufs[i]
+            n0 = k * T
+            rows = min(T, N - n0)
+            main.wait_event(built[i])
+            if self.time_factor:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+            st = lib.gf_factor(
+                B, rows, n0, self.W, self.ld, p(buf["a"]), p(buf["U"]), p(buf["V"]),
+                p(buf["P"]), self.y.data_ptr() + 8 * n0, self._bs(self.y),
+                p(self.d), None, p(self.z), p(self.S_state), p(self.F_state),
+                p(self.info), main.cuda_stream)
+            _lib.check(st, "gf_factor")
+            if self.time_factor:
+                e1.record(main)
+                self.factor_events.append((e0, e1, rows))
+            freed[i] = main.record_event()
+            if k + nb < ntiles:          # refill this buffer with tile k + nb on the side stream
+                side.wait_event(freed[i])
+                with torch.cuda.stream(side):
+                    self._build_tile(k + nb, buf, side)
+                    built[i] = side.record_event()
+            st = lib.gf_reduce_tile(B, rows, p(self.d), p(self.z), p(self.work), p(self.acc),
+                                    1 if k == 0 else 0, main.cuda_stream)
+            _lib.check(st, "gf_reduce_tile")
+        out = torch.empty((B,), dtype=torch.float64, device=self.device)
+        st = lib.gf_loglike_finish(B, N, p(self.acc), p(self.info), p(out), None,
+                                   main.cuda_stream)
+        _lib.check(st, "gf_loglike_finish")
+        return out
+
+    @property
+    def nbytes_algorithmic_loglike(self):
+        return 8 * self.N * (3 * self.W + 4) * self.B

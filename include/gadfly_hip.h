@@ -9,7 +9,8 @@
  *
  *   gf_build_matrices   driver.get_celerite_matrices   <- gp.py:202 (compute)
  *   gf_factor           driver.factor                  <- gp.py:202 (compute)
- *   gf_loglike_reduce   numpy glue in celerite2.core   <- gp.py:350 (_norm - 0.5 sum z^2/d)
+ *   gf_reduce_tile /
+ *   gf_loglike_finish   numpy glue in celerite2.core   <- gp.py:350 (_norm - 0.5 sum z^2/d)
  *   gf_solve            driver.solve_lower / solve_upper / matmul_lower
  *                                                      <- gp.py:350, :370, :232, :327, :391
  *   gf_general_matmul   driver.general_matmul_lower + general_matmul_upper
@@ -52,16 +53,17 @@ const char *gf_last_error(void);
 int gf_leading_dim(int W);
 
 /*
- * Matrix build + propagator rows.
+ * Matrix build + propagator rows, for the N rows n_first .. n_first+N-1 of a
+ * longer series (tile streaming; n_first = 0 and N = series length for a whole series).
  *   coefficients: ar, cr [B][Jr]; ac, bc, cc, dc [B][Jc]   (W = Jr + 2 Jc)
  *   diag_add [B]  : sum(ar) + sum(ac) + TermConvolution diagonal shift, added to diag
- *   t    [B|1][N] : times, batch stride t_bs (0 = shared)
- *   diag [B|1][N] : user diagonal (yerr^2), batch stride diag_bs; NULL = 0
- * outputs
- *   a [B][N];  U, V, P [B][N][ld];  P[n][j] = exp(c_j (t[n-1] - t[n])), P[0][:] = 1
- *   (P may be NULL when only U, V are wanted, e.g. at prediction times)
+ *   t    [B|1][*] : times of the WHOLE series (indexed with the global row), batch stride t_bs
+ *   diag [B|1][*] : user diagonal (yerr^2) of the whole series, batch stride diag_bs; NULL = 0
+ * outputs (tile-local row index)
+ *   a [B][N] (NULL ok);  U, V, P [B][N][ld];  P[n][j] = exp(c_j (t[g-1] - t[g])), g = n_first+n,
+ *   P row of global row 0 = 1  (P may be NULL when only U, V are wanted, e.g. at prediction times)
  */
-int gf_build_matrices(int B, int64_t N, int Jr, int Jc, int ld,
+int gf_build_matrices(int B, int64_t N, int64_t n_first, int Jr, int Jc, int ld,
                       const double *ar, const double *cr, const double *ac,
                       const double *bc, const double *cc, const double *dc,
                       const double *diag_add,
@@ -70,26 +72,41 @@ int gf_build_matrices(int B, int64_t N, int Jr, int Jc, int ld,
                       double *a, double *U, double *V, double *P, void *stream);
 
 /*
- * Semiseparable LDL^T factor, optionally fused with the forward solve of one
- * right-hand side (the log-likelihood path).
- *   inputs : a [B][N]; U, V, P [B][N][ld]; y [B|1][N] (batch stride y_bs) or NULL
+ * Semiseparable LDL^T factor of N consecutive rows, optionally fused with the
+ * forward solve of one right-hand side (the log-likelihood path).
+ *   inputs : a [B][N]; U, V, P [B][N][ld]; y [B|1][N] (pointer to the tile's first row,
+ *            batch stride y_bs) or NULL
  *   outputs: d [B][N]; Wm [B][N][ld] or NULL (not stored); z [B][N] (= L^-1 y) or NULL
- *            info [B] (0 ok, else 1-based row of the first non-positive pivot)
+ *   state  : S_state [B][gf_state_size(W)], F_state [B][gf_state_cols(W)] or NULL.
+ *            When given, the recurrence state (S + d w w^T and F + w z of the last row, before
+ *            the next propagator is applied) is READ at entry and WRITTEN at exit, so a series
+ *            can be streamed tile by tile through fixed-size U/V/P buffers; zero both before
+ *            the first tile.  NULL = start from zero, final state not stored.
+ *   info [B]: must be zeroed by the caller before the first tile; the kernel only ever writes
+ *            a non-zero value (1-based GLOBAL row n_first+n+1 of the first non-positive pivot),
+ *            and a problem whose info is already non-zero is skipped.
  */
-int gf_factor(int B, int64_t N, int W, int ld,
+int64_t gf_state_size(int W);
+int gf_state_cols(int W);
+int gf_factor(int B, int64_t N, int64_t n_first, int W, int ld,
               const double *a, const double *U, const double *V, const double *P,
               const double *y, int64_t y_bs,
-              double *d, double *Wm, double *z, int32_t *info, void *stream);
+              double *d, double *Wm, double *z,
+              double *S_state, double *F_state, int32_t *info, void *stream);
 
 /*
- * out[b] = -0.5 (sum log d + N log 2pi) - 0.5 sum z^2/d ;  logdet[b] = sum log d  (NULL ok)
- * (z == NULL: out[b] = the normalisation constant only).  If info[b] != 0: out = -inf,
- * logdet = -inf.  work must hold B * gf_reduce_work(N) doubles.
+ * Log-likelihood reductions (fixed-shape tree, deterministic):
+ *   gf_reduce_tile   : acc[b] = {sum log d, sum z^2/d} over N rows; init != 0 overwrites acc,
+ *                      init == 0 adds to it (tiles in order).  z == NULL: second sum is 0.
+ *                      work must hold B * gf_reduce_work(N) doubles.
+ *   gf_loglike_finish: out[b] = -0.5 (acc0 + Ntot log 2pi) - 0.5 acc1; logdet[b] = acc0
+ *                      (either may be NULL); info[b] != 0 -> -inf for both.
  */
 int64_t gf_reduce_work(int64_t N);
-int gf_loglike_reduce(int B, int64_t N, const double *d, const double *z,
-                      const int32_t *info, double *work, double *out, double *logdet,
-                      void *stream);
+int gf_reduce_tile(int B, int64_t N, const double *d, const double *z,
+                   double *work, double *acc, int init, void *stream);
+int gf_loglike_finish(int B, int64_t N, const double *acc, const int32_t *info,
+                      double *out, double *logdet, void *stream);
 
 /*
  * Triangular sweeps with R right-hand sides, Y and Z are [B][N][R] row-major (Z may alias Y
