@@ -35,11 +35,11 @@ FP64_VALU_PEAK_TF = 78.6   # vector FP64 peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=1_000_000, help="cadences per light curve")
     ap.add_argument("--j", type=int, default=30, help="SHO terms (celerite width = 2J)")
-    ap.add_argument("--evals", type=int, default=512,
+    ap.add_argument("--evals", type=int, default=1024,
                     help="independent evaluations (walkers) per rank per step")
     ap.add_argument("--tile-rows", type=int, default=8192, help="rows per streamed tile")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -85,9 +85,11 @@ __device__ __forceinline__ void wave_sum2(double &a, double &b) {
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS operations of one wave execute in issue order, so wavefront scope (a pure
     // compiler fence, no s_waitcnt) is enough and leaves global prefetches in flight.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // The fences name the LDS address space only, so global loads stay provably unclobbered
+    // (which is what lets hipcc turn wave-uniform row loads into s_load).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
 // ------------------------------------------------------------------------------------
@@ -347,6 +349,240 @@ __global__ void __launch_bounds__(64 * NW) k_factor(const FactorArgs A) {
             for (int c = 0; c < CT; ++c) A.F_out[sidx * WPC + c * 64 + lane] = fma(wv[c], zprev, Fv[c]);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------
+// v2 log-likelihood path (W <= 64): block-scaled coordinates, one wave per problem.
+//
+// Within a block of rows [r, r') (r = "reset row") the state is kept in coordinates scaled by
+// rho_n = exp(-c (t_n - t_r)):   S_n = rho_n T_n rho_n,  u~_n = u_n o rho_n,  v~_n = v_n / rho_n,
+// w~_n = w_n / rho_n.  In these coordinates the celerite recurrence has NO per-row decay:
+//     T   <- T + d_{n-1} w~_{n-1} w~_{n-1}^T
+//     tmp  = T u~_n ;  d_n = a_n - u~_n . tmp ;  w~_n = (v~_n - tmp) / d_n
+//     F~  <- F~ + w~_{n-1} z_{n-1} ;  z_n = y_n - u~_n . F~
+// i.e. 2 FMAs per element of T per row instead of an update, two decays and a mat-vec.  At a
+// reset row the accumulated decay E = exp(-c (t_r' - t_r)) is applied once (T <- E T E).  This is
+// the un-preconditioned celerite (2017) recurrence made safe by bounding the block span:
+// reset(n) = (n % 8 == 0) or cmax (t_n - t_{n-1}) > 4  =>  |log rho| <= 28 inside a block.
+// k_build2 writes u~, v~ (and E at reset rows); k_factor2 reads the row operands u~_i as
+// wave-uniform scalar loads (SGPR operands of v_fma_f64), so only w~ needs an LDS broadcast.
+// ------------------------------------------------------------------------------------
+constexpr int SC_BLOCK = 8;
+constexpr double SC_GAP = 4.0;
+
+struct Build2Args {
+    int64_t N, n_first;
+    int Jr, Jc, ld, units;
+    const double *ar, *cr, *ac, *bc, *cc, *dc, *diag_add, *cmax;
+    const double *t; int64_t t_bs;
+    const double *diag; int64_t diag_bs;
+    double *a, *Ut, *Vt, *de;       // de[n] = t_ref(n) - t_ref(n-1) at reset rows, -1 elsewhere
+};
+
+__device__ __forceinline__ bool sc_is_reset(const double *t, int64_t g, double cmax) {
+    return (g % SC_BLOCK) == 0 || cmax * (t[g] - t[g - 1]) > SC_GAP;
+}
+
+// latest reset row <= g (bounded walk: g - g % SC_BLOCK is always a reset)
+__device__ __forceinline__ int64_t sc_ref(const double *t, int64_t g, double cmax) {
+    while (!sc_is_reset(t, g, cmax)) --g;
+    return g;
+}
+
+__global__ void __launch_bounds__(256) k_build2(const Build2Args A) {
+    const int b = blockIdx.y;
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = id / A.units;
+    if (n >= A.N) return;
+    const int q = (int)(id - n * A.units);
+    const int W = A.Jr + 2 * A.Jc;
+    const double *t = A.t + (size_t)b * A.t_bs;
+    const double cmax = A.cmax[b];
+    const int64_t g = A.n_first + n;
+    const double tn = t[g];
+    const bool reset = sc_is_reset(t, g, cmax);
+    const int64_t ref = reset ? g : sc_ref(t, g, cmax);
+    const double ds = tn - t[ref];                               // >= 0, 0 at a reset row
+    const double de = (reset && g > 0) ? (tn - t[sc_ref(t, g - 1, cmax)]) : 0.0;
+    const size_t row = ((size_t)b * A.N + n) * A.ld;
+    if (q == 0) {
+        const double dg = A.diag ? A.diag[(size_t)b * A.diag_bs + g] : 0.0;
+        A.a[(size_t)b * A.N + n] = dg + A.diag_add[b];
+        A.de[(size_t)b * A.N + n] = reset ? de : -1.0;
+    }
+    if (q < A.Jr) {
+        const double ar = A.ar[(size_t)b * A.Jr + q], cr = A.cr[(size_t)b * A.Jr + q];
+        A.Ut[row + q] = ar * exp(-cr * ds);
+        A.Vt[row + q] = exp(cr * ds);
+    } else if (q < A.Jr + A.Jc) {
+        const int k = q - A.Jr;
+        const size_t ck = (size_t)b * A.Jc + k;
+        const double ac = A.ac[ck], bc = A.bc[ck], cc = A.cc[ck], dc = A.dc[ck];
+        const double arg = dc * tn;                  // ONE rounded multiply (parity hazard i)
+        double si, co;
+        sincos(arg, &si, &co);
+        const double rho = exp(-cc * ds), irho = exp(cc * ds);
+        const int j = A.Jr + 2 * k;
+        A.Ut[row + j]     = (ac * co + bc * si) * rho;
+        A.Ut[row + j + 1] = (ac * si - bc * co) * rho;
+        A.Vt[row + j]     = co * irho;
+        A.Vt[row + j + 1] = si * irho;
+    } else {
+        const int j = W + (q - A.Jr - A.Jc);
+        A.Ut[row + j] = 0.0;
+        A.Vt[row + j] = 0.0;
+    }
+}
+
+// One sweep over the ROWS register-resident rows of T with wave-uniform row operands read
+// from LDS (xa[i], xw[i]), software-pipelined: batches of 4 rows (2 + 2 ds_read_b128), AHEAD
+// batches in flight ahead of the FMAs, so the LDS latency is paid once per sweep and not once
+// per read (hipcc otherwise parks every read right in front of its use).
+//   RESET = false:  T_i += xw_i * dwv ;  acc += xa_i * T_i          (update + mat-vec)
+//   RESET = true :  T_i  = (T_i + xw_i * dwv) * (xa_i * el)        (fold pending, decay)
+template <int ROWS, bool RESET>
+__device__ __forceinline__ double t_sweep(double (&T)[ROWS], const double *xa, const double *xw,
+                                          const double dwv, const double el) {
+    constexpr int BR = 4, NB = ROWS / BR, AHEAD = 2;
+    static_assert(ROWS % BR == 0, "ROWS must be a multiple of 4");
+    double ab[AHEAD + 1][BR], wb[AHEAD + 1][BR];
+#pragma unroll
+    for (int k = 0; k < AHEAD && k < NB; ++k) {
+#pragma unroll
+        for (int r = 0; r < BR; ++r) { ab[k][r] = xa[k * BR + r]; wb[k][r] = xw[k * BR + r]; }
+    }
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        if (k + AHEAD < NB) {
+#pragma unroll
+            for (int r = 0; r < BR; ++r) {
+                ab[(k + AHEAD) % (AHEAD + 1)][r] = xa[(k + AHEAD) * BR + r];
+                wb[(k + AHEAD) % (AHEAD + 1)][r] = xw[(k + AHEAD) * BR + r];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int c = k % (AHEAD + 1);
+        if constexpr (RESET) {
+#pragma unroll
+            for (int r = 0; r < BR; ++r)
+                T[k * BR + r] = fma(wb[c][r], dwv, T[k * BR + r]) * (ab[c][r] * el);
+        } else {
+            T[k * BR + 0] = fma(wb[c][0], dwv, T[k * BR + 0]);
+            T[k * BR + 1] = fma(wb[c][1], dwv, T[k * BR + 1]);
+            T[k * BR + 2] = fma(wb[c][2], dwv, T[k * BR + 2]);
+            T[k * BR + 3] = fma(wb[c][3], dwv, T[k * BR + 3]);
+            acc0 = fma(ab[c][0], T[k * BR + 0], acc0);
+            acc1 = fma(ab[c][1], T[k * BR + 1], acc1);
+            acc2 = fma(ab[c][2], T[k * BR + 2], acc2);
+            acc3 = fma(ab[c][3], T[k * BR + 3], acc3);
+            // pin the partial sums to this batch: LLVM otherwise sinks all the mat-vec FMAs
+            // to the end of the sweep and keeps every row operand alive (register blow-up)
+            asm volatile("" : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return (acc0 + acc2) + (acc1 + acc3);
+}
+
+template <int ROWS>
+__global__ void __launch_bounds__(64, 2)     // 2 waves/SIMD: one wave alone gets half the VALU issue rate
+k_factor2(const int64_t N, const int64_t n_first, const int ld, const int W,
+          const double *__restrict__ c_,
+          const double *__restrict__ a_, const double *__restrict__ Ut_,
+          const double *__restrict__ Vt_, const double *__restrict__ de_,
+          const double *__restrict__ y_, const int64_t y_bs,
+          double *__restrict__ d_, double *__restrict__ z_,
+          double *__restrict__ S_state, double *__restrict__ F_state,
+          int32_t *__restrict__ info) {
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    if (info[b] != 0) return;
+    const size_t pb = (size_t)b * N;
+    const double *__restrict__ ag = a_ + pb;
+    const double *__restrict__ Ug = Ut_ + pb * ld;
+    const double *__restrict__ Vg = Vt_ + pb * ld;
+    const double *__restrict__ eg = de_ + pb;
+    const double *__restrict__ yg = y_ + (size_t)b * y_bs;
+    double *__restrict__ dg = d_ + pb;
+    double *__restrict__ zg = z_ + pb;
+    // state layout [lane][64 rows]: one base address per lane, immediate offsets per row
+    double *__restrict__ Sg = S_state + (size_t)b * (64 * 64) + (size_t)lane * 64;
+    double *__restrict__ Fg = F_state + (size_t)b * 64;
+
+    __shared__ double s_w[64];
+    __shared__ double s_u[64];
+    const bool colok = lane < ld;
+    const double cj = (lane < W) ? c_[(size_t)b * W + lane] : 0.0;
+
+    double T[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) T[i] = Sg[i];
+    double Fv = Fg[lane];
+    double wv = 0.0, dwv = 0.0, zprev = 0.0;
+    s_w[lane] = 0.0;
+    int32_t fail = 0;
+
+    // Everything a row needs is prefetched one row ahead, unconditionally (the caller pads
+    // every buffer, y included, by one row/element): a clamped index makes hipcc give up its
+    // scalarisation of uniform loads, and an un-prefetched scalar costs a full memory round
+    // trip per row.  Pad lanes (>= ld) re-read column ld-1 and are masked in registers.
+    const int lanec = colok ? lane : (ld - 1);
+    double ut_n = Ug[lanec];
+    double vt_n = Vg[lanec];
+    double a_nx = ag[0], y_nx = yg[0], e_nx = eg[0];
+
+    for (int64_t n = 0; n < N; ++n) {
+        const double ut = colok ? ut_n : 0.0, vt = colok ? vt_n : 0.0;
+        const double a_n = a_nx, y_n = y_nx, e_n = e_nx;
+        ut_n = Ug[(size_t)(n + 1) * ld + lanec];
+        vt_n = Vg[(size_t)(n + 1) * ld + lanec];
+        a_nx = ag[n + 1];
+        y_nx = yg[n + 1];
+        e_nx = eg[n + 1];
+        if (e_n >= 0.0) {                   // wave-uniform: reset row
+            // fold the pending update, then decay by E = exp(-c * de) (de = t_ref - t_ref_prev)
+            const double el = exp(-cj * e_n);
+            wave_lds_fence();
+            s_u[lane] = el;
+            wave_lds_fence();
+            (void)t_sweep<ROWS, true>(T, s_u, s_w, dwv, el);
+            Fv = el * fma(wv, zprev, Fv);
+            dwv = 0.0;
+            zprev = 0.0;
+        }
+        // Row operands u~_i must be wave-uniform.  Scalar loads (s_load) of the row work but
+        // stream through the scalar cache's slow miss path (measured 2.4 us/row); the LDS
+        // broadcast of the prefetched lane-form row costs ~2 LDS cycles per operand.
+        wave_lds_fence();
+        s_u[lane] = ut;
+        wave_lds_fence();
+        const double tmp = t_sweep<ROWS, false>(T, s_u, s_w, dwv, 0.0);
+        Fv = fma(wv, zprev, Fv);
+        double s1 = ut * tmp, s2 = ut * Fv;
+        wave_sum2(s1, s2);
+        const double dn = a_n - s1;
+        const double zn = y_n - s2;
+        if (!(dn > 0.0)) {
+            const int64_t gg = n_first + n + 1;
+            fail = (int32_t)(gg > 0x7fffffff ? 0x7fffffff : gg);
+            break;
+        }
+        wv = (vt - tmp) / dn;
+        dwv = dn * wv;
+        wave_lds_fence();
+        s_w[lane] = wv;
+        if (lane == 0) { dg[n] = dn; zg[n] = zn; }
+        zprev = zn;
+    }
+    if (fail) {
+        if (lane == 0) info[b] = fail;
+        return;
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) Sg[i] = fma(s_w[i], dwv, T[i]);
+    Fg[lane] = fma(wv, zprev, Fv);
 }
 
 // ------------------------------------------------------------------------------------
@@ -741,6 +977,55 @@ int gf_factor(int B, int64_t N, int64_t n_first, int W, int ld,
     A.S_in = S_state; A.F_in = F_state; A.S_out = S_state; A.F_out = F_state;
     A.info = info;
     return dispatch_factor(A, B, 1, (hipStream_t)stream);
+}
+
+int gf_scaled_supported(int W) { return (W >= 1 && W <= 64) ? 1 : 0; }
+
+int gf_build_scaled(int B, int64_t N, int64_t n_first, int Jr, int Jc, int ld,
+                    const double *ar, const double *cr, const double *ac,
+                    const double *bc, const double *cc, const double *dc,
+                    const double *diag_add, const double *cmax,
+                    const double *t, int64_t t_bs,
+                    const double *diag, int64_t diag_bs,
+                    double *a, double *Ut, double *Vt, double *de, void *stream) {
+    const int W = Jr + 2 * Jc;
+    if (B < 1 || N < 1) return set_err("gf_build_scaled: empty problem (B=%s%lld, N=%lld)", "", B, N);
+    if (!gf_scaled_supported(W)) return set_err("gf_build_scaled: width %s%lld unsupported (max 64)", "", W);
+    if (ld < W || (ld & 15)) return set_err("gf_build_scaled: ld=%s%lld must be a multiple of 16 and >= W=%lld", "", ld, W);
+    if (n_first < 0 || (n_first % SC_BLOCK) != 0) return set_err("gf_build_scaled: n_first=%s%lld must be a non-negative multiple of 8", "", n_first);
+    if (!t || !a || !Ut || !Vt || !de || !diag_add || !cmax) return set_err("gf_build_scaled: null pointer%s", "");
+    Build2Args A;
+    A.N = N; A.n_first = n_first; A.Jr = Jr; A.Jc = Jc; A.ld = ld; A.units = Jr + Jc + (ld - W);
+    A.ar = ar; A.cr = cr; A.ac = ac; A.bc = bc; A.cc = cc; A.dc = dc; A.diag_add = diag_add; A.cmax = cmax;
+    A.t = t; A.t_bs = t_bs; A.diag = diag; A.diag_bs = diag_bs;
+    A.a = a; A.Ut = Ut; A.Vt = Vt; A.de = de;
+    const int64_t blocks = (N * A.units + 255) / 256;
+    if (blocks > 0x7fffffffLL) return set_err("gf_build_scaled: problem too large%s", "");
+    hipLaunchKernelGGL(k_build2, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, A);
+    return check_launch("gf_build_scaled");
+}
+
+#define GF_F2_CASE(R) case R: hipLaunchKernelGGL((k_factor2<R>), dim3(B), dim3(64), 0, st, N, n_first, ld, W, c, a, Ut, Vt, de, y, y_bs, d, z, S_state, F_state, info); break;
+
+int gf_factor_scaled(int B, int64_t N, int64_t n_first, int W, int ld, const double *c,
+                     const double *a, const double *Ut, const double *Vt, const double *de,
+                     const double *y, int64_t y_bs,
+                     double *d, double *z, double *S_state, double *F_state,
+                     int32_t *info, void *stream) {
+    if (B < 1 || N < 1) return set_err("gf_factor_scaled: empty problem (B=%s%lld, N=%lld)", "", B, N);
+    if (!gf_scaled_supported(W)) return set_err("gf_factor_scaled: width %s%lld unsupported (max 64)", "", W);
+    if (ld < W || (ld & 15)) return set_err("gf_factor_scaled: ld=%s%lld must be a multiple of 16 and >= W=%lld", "", ld, W);
+    if (!c || !a || !Ut || !Vt || !de || !y || !d || !z || !S_state || !F_state || !info)
+        return set_err("gf_factor_scaled: null pointer%s", "");
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = (W + 3) / 4 * 4;
+    switch (rows) {
+        GF_F2_CASE(4) GF_F2_CASE(8) GF_F2_CASE(12) GF_F2_CASE(16) GF_F2_CASE(20) GF_F2_CASE(24)
+        GF_F2_CASE(28) GF_F2_CASE(32) GF_F2_CASE(36) GF_F2_CASE(40) GF_F2_CASE(44) GF_F2_CASE(48)
+        GF_F2_CASE(52) GF_F2_CASE(56) GF_F2_CASE(60) GF_F2_CASE(64)
+        default: return set_err("gf_factor_scaled: internal dispatch error%s", "");
+    }
+    return check_launch("gf_factor_scaled");
 }
 
 int64_t gf_reduce_work(int64_t N) { return 2 * (int64_t)red_groups(N); }

@@ -293,7 +293,8 @@ class StreamingBatch:
     Two tile buffers and two streams overlap the build of tile k+1 with the sweep of tile k.
     """
 
-    def __init__(self, coeffs_list, t, y, diag=None, tile_rows=8192, device=None):
+    def __init__(self, coeffs_list, t, y, diag=None, tile_rows=8192, device=None,
+                 force_v1=False):
         torch = _lib.require_device()
         self.torch = torch
         self.lib = _lib.load()
@@ -324,24 +325,42 @@ class StreamingBatch:
 
         self.t = rows(t, "t")
         self.N = int(self.t.shape[1])
-        self.y = rows(y, "y")
-        if self.y.shape[1] != self.N:
+        y = rows(y, "y")
+        if y.shape[1] != self.N:
             raise ValueError("dimension mismatch")
+        # one spare element at the very end: the sweep prefetches row n+1 unconditionally
+        ypad = torch.zeros((y.shape[0] * self.N + 1,), **f64)
+        ypad[:y.shape[0] * self.N] = y.reshape(-1)
+        self.y = ypad[:y.shape[0] * self.N].view(y.shape[0], self.N)
+        self._ypad = ypad
         self.diag = None
         if diag is not None:
             self.diag = rows(diag, "diag")
             if self.diag.shape[1] != self.N:
                 raise ValueError("dimension mismatch")
-        self._pack = (dev(real), dev(comp), dev(diag_add), dev(c))
+        self._pack = self._make_pack(real, comp, diag_add, c)
         B, ld = self.B, self.ld
-        self.tile_rows = T = int(min(max(int(tile_rows), 1), self.N))
-        self.bufs = [dict(a=torch.empty((B, T), **f64), U=torch.empty((B, T, ld), **f64),
-                          V=torch.empty((B, T, ld), **f64), P=torch.empty((B, T, ld), **f64))
+        # W <= 64: block-scaled one-wave-per-problem kernels (k_build2 / k_factor2)
+        self.scaled = bool(self.lib.gf_scaled_supported(self.W)) and not force_v1
+        T = int(min(max(int(tile_rows), 1), self.N))
+        if T < self.N:
+            T = max(8, T // 8 * 8)            # tiles start on a reset row (multiple of 8)
+        self.tile_rows = T
+
+        def rows_buf():
+            # one spare row: the sweep prefetches row n+1 unconditionally
+            return torch.zeros((B * T + 1, ld), **f64)
+
+        self.bufs = [dict(a=torch.zeros((B * T + 1,), **f64), U=rows_buf(), V=rows_buf(),
+                          P=None if self.scaled else rows_buf(),
+                          de=torch.zeros((B * T + 1,), **f64))
                      for _ in range(2 if T < self.N else 1)]
         self.d = torch.empty((B, T), **f64)
         self.z = torch.empty((B, T), **f64)
-        self.S_state = torch.empty((B, int(self.lib.gf_state_size(self.W))), **f64)
-        self.F_state = torch.empty((B, int(self.lib.gf_state_cols(self.W))), **f64)
+        nS = 64 * 64 if self.scaled else int(self.lib.gf_state_size(self.W))
+        nF = 64 if self.scaled else int(self.lib.gf_state_cols(self.W))
+        self.S_state = torch.empty((B, nS), **f64)
+        self.F_state = torch.empty((B, nF), **f64)
         self.acc = torch.empty((B, 2), **f64)
         self.work = torch.empty((B * int(self.lib.gf_reduce_work(T)),), **f64)
         self.info = torch.zeros((B,), dtype=torch.int32, device=self.device)
@@ -354,12 +373,16 @@ class StreamingBatch:
     def _bs(x):
         return 0 if x.shape[0] == 1 else x.stride(0)
 
+    def _make_pack(self, real, comp, diag_add, c):
+        dev = self._dev
+        cmax = np.max(c, axis=1)
+        return dev(real), dev(comp), dev(diag_add), dev(c), dev(cmax)
+
     def pack_coefficients(self, coeffs_list):
         Jr, Jc, real, comp, diag_add, c = _coeff_pack(coeffs_list)
         if (Jr, Jc) != (self.Jr, self.Jc) or len(coeffs_list) != self.B:
             raise ValueError("coefficient pack does not match the batch structure")
-        dev = self._dev
-        return dev(real), dev(comp), dev(diag_add), dev(c)
+        return self._make_pack(real, comp, diag_add, c)
 
     def use_coefficients(self, pack):
         self._pack = pack
@@ -367,8 +390,17 @@ class StreamingBatch:
     def _build_tile(self, k, buf, stream):
         n0 = k * self.tile_rows
         rows = min(self.tile_rows, self.N - n0)
-        real, comp, diag_add, _ = self._pack
+        real, comp, diag_add, _, cmax = self._pack
         p = _lib.ptr
+        if self.scaled:
+            st = self.lib.gf_build_scaled(
+                self.B, rows, n0, self.Jr, self.Jc, self.ld,
+                p(real[0]), p(real[1]), p(comp[0]), p(comp[1]), p(comp[2]), p(comp[3]),
+                p(diag_add), p(cmax), p(self.t), self._bs(self.t),
+                p(self.diag), 0 if self.diag is None else self._bs(self.diag),
+                p(buf["a"]), p(buf["U"]), p(buf["V"]), p(buf["de"]), stream.cuda_stream)
+            _lib.check(st, "gf_build_scaled")
+            return
         st = self.lib.gf_build_matrices(
             self.B, rows, n0, self.Jr, self.Jc, self.ld,
             p(real[0]), p(real[1]), p(comp[0]), p(comp[1]), p(comp[2]), p(comp[3]),
@@ -406,11 +438,18 @@ class StreamingBatch:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(main)
-            st = lib.gf_factor(
-                B, rows, n0, self.W, self.ld, p(buf["a"]), p(buf["U"]), p(buf["V"]),
-                p(buf["P"]), self.y.data_ptr() + 8 * n0, self._bs(self.y),
-                p(self.d), None, p(self.z), p(self.S_state), p(self.F_state),
-                p(self.info), main.cuda_stream)
+            if self.scaled:
+                st = lib.gf_factor_scaled(
+                    B, rows, n0, self.W, self.ld, p(self._pack[3]), p(buf["a"]),
+                    p(buf["U"]), p(buf["V"]), p(buf["de"]), self.y.data_ptr() + 8 * n0,
+                    self._bs(self.y), p(self.d), p(self.z), p(self.S_state),
+                    p(self.F_state), p(self.info), main.cuda_stream)
+            else:
+                st = lib.gf_factor(
+                    B, rows, n0, self.W, self.ld, p(buf["a"]), p(buf["U"]), p(buf["V"]),
+                    p(buf["P"]), self.y.data_ptr() + 8 * n0, self._bs(self.y),
+                    p(self.d), None, p(self.z), p(self.S_state), p(self.F_state),
+                    p(self.info), main.cuda_stream)
             _lib.check(st, "gf_factor")
             if self.time_factor:
                 e1.record(main)

@@ -95,6 +95,34 @@ int gf_factor(int B, int64_t N, int64_t n_first, int W, int ld,
               double *S_state, double *F_state, int32_t *info, void *stream);
 
 /*
+ * Log-likelihood fast path for W <= 64 in block-scaled coordinates (see the derivation above
+ * k_build2 in gadfly_hip.hip).  Same role as gf_build_matrices + gf_factor on the
+ * log-likelihood path (gp.py:202 + gp.py:350); U~, V~ are u o rho and v / rho with
+ * rho = exp(-c (t_n - t_ref)); de[n] = t_ref(n) - t_ref(n-1) >= 0 at reset rows (where the
+ * accumulated decay exp(-c de) is applied once) and -1 elsewhere.
+ *   cmax [B] : max_j c_j of each problem (sets the reset rule); c [B][W] decay rate per column;
+ *   n_first must be a multiple of 8.
+ *   outputs of gf_build_scaled: a, de [B][N]; Ut, Vt [B][N][ld]
+ *   gf_factor_scaled: y (tile pointer), d, z, S_state [B][64*64], F_state [B][64], info as in
+ *   gf_factor (state mandatory; zero it and info before the first tile).  Wm is not produced.
+ *   The sweep prefetches row n+1 unconditionally: a, de, y, Ut, Vt must each be readable one
+ *   row (element) past the last row of the last problem.
+ */
+int gf_scaled_supported(int W);
+int gf_build_scaled(int B, int64_t N, int64_t n_first, int Jr, int Jc, int ld,
+                    const double *ar, const double *cr, const double *ac,
+                    const double *bc, const double *cc, const double *dc,
+                    const double *diag_add, const double *cmax,
+                    const double *t, int64_t t_bs,
+                    const double *diag, int64_t diag_bs,
+                    double *a, double *Ut, double *Vt, double *de, void *stream);
+int gf_factor_scaled(int B, int64_t N, int64_t n_first, int W, int ld, const double *c,
+                     const double *a, const double *Ut, const double *Vt, const double *de,
+                     const double *y, int64_t y_bs,
+                     double *d, double *z, double *S_state, double *F_state,
+                     int32_t *info, void *stream);
+
+/*
  * Log-likelihood reductions (fixed-shape tree, deterministic):
  *   gf_reduce_tile   : acc[b] = {sum log d, sum z^2/d} over N rows; init != 0 overwrites acc,
  *                      init == 0 adds to it (tiles in order).  z == NULL: second sum is 0.

@@ -215,3 +215,69 @@ def test_edge_sizes(hip):
         ref = dense.log_likelihood(co[:6], t, np.full(N, 0.04), y)
         assert abs(gp.log_likelihood(y) - ref) <= RTOL_LL * abs(ref)
         assert _relmax(gp.apply_inverse(y), dense.apply_inverse(co[:6], t, np.full(N, 0.04), y)) < TOL_VEC
+
+
+STREAM_CASES = [
+    ("solar", dict(J=6, N=3000), 256),
+    ("solar", dict(J=20, N=2500, jitter_t=True), 512),
+    ("solar", dict(J=30, N=3000, gaps=True), 1000),      # gap rule resets + ragged last tile
+    ("solar", dict(J=30, N=2048, yerr=0.0), 8192),       # single tile
+    ("solar", dict(J=32, N=1000), 64),                   # W = 64: no pad lanes
+    ("solar", dict(J=40, N=1500), 256),                  # W = 80: v1 kernels (multi-wave)
+    ("generic", dict(kind="overdamped", N=700), 128),    # real terms
+    ("generic", dict(kind="mixed", N=900), 64),
+    ("generic", dict(kind="sho_q100", N=512), 100),      # tile_rows not a multiple of 8
+]
+
+
+@pytest.mark.parametrize("case", STREAM_CASES, ids=lambda c: f"{c[0]}-{c[1]}-T{c[2]}")
+@pytest.mark.parametrize("force_v1", [False, True], ids=["scaled", "v1"])
+def test_streaming_loglike(hip, case, force_v1):
+    """Tile-streamed evaluation (both kernel families) against the oracle, including the
+    state hand-off between tiles and the block-scaled coordinates' reset rows."""
+    from gadfly_amd.engine import StreamingBatch
+    from oracle import cref
+    kind, kw, tile = case
+    prob = _make((kind, kw))
+    k, t, y = prob["kernel"], prob["t"], prob["y"]
+    co = k.get_device_coefficients()
+    eng = StreamingBatch([co], t, y, diag=prob["diag_user"], tile_rows=tile, force_v1=force_v1)
+    ll = float(eng.log_likelihood()[0])
+    ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y)
+    assert info == 0
+    assert abs(ll - ref) <= RTOL_LL * abs(ref), (ll, ref)
+    # a second evaluation re-uses the buffers (state must be re-zeroed)
+    assert float(eng.log_likelihood()[0]) == ll
+
+
+def test_streaming_fast_term_resets_every_row(hip):
+    """A shot-noise-like term (c dt >> 4) forces a reset on every row of the scaled path."""
+    import gadfly_amd
+    from gadfly_amd.engine import StreamingBatch
+    from oracle import cref
+    prob = util.solar_problem(6, 1500)
+    k = prob["kernel"] + gadfly_amd.ShotNoiseKernel(S0=1e-3, w0=2.0e5, Q=0.5)
+    co = k.get_device_coefficients()
+    assert np.max(co[4]) * 60e-6 > 4.0
+    t, y = prob["t"], prob["y"]
+    ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y)
+    assert info == 0
+    for force_v1 in (False, True):
+        eng = StreamingBatch([co], t, y, diag=prob["diag_user"], tile_rows=512, force_v1=force_v1)
+        ll = float(eng.log_likelihood()[0])
+        assert abs(ll - ref) <= RTOL_LL * abs(ref), (force_v1, ll, ref)
+
+
+def test_streaming_not_positive_definite(hip):
+    from gadfly_amd.engine import StreamingBatch
+    prob = util.generic_problem("mixed", 300)
+    co = prob["kernel"].get_device_coefficients()
+    bad = prob["diag_user"].copy()
+    bad[137:] = -5.0 * prob["kernel"].get_value(np.zeros(1))[0]
+    for force_v1 in (False, True):
+        eng = StreamingBatch([co, co], np.stack([prob["t"]] * 2), np.stack([prob["y"]] * 2),
+                             diag=np.stack([prob["diag_user"], bad]), tile_rows=64,
+                             force_v1=force_v1)
+        ll = eng.log_likelihood().cpu().numpy()
+        assert np.isfinite(ll[0]) and ll[1] == -np.inf
+        assert int(eng.info[0]) == 0 and int(eng.info[1]) == 138
