@@ -1,0 +1,98 @@
+"""CPU: host-side term algebra and the kernel classes' API surface."""
+import warnings
+
+import numpy as np
+import pytest
+from scipy.integrate import quad
+
+import gadfly_amd
+from gadfly_amd.terms import SHOTerm, TermSum, TermConvolution
+from gadfly_amd.synth import solar_like_hyperparameters
+
+
+def test_sho_coefficients_branches():
+    ar, cr, ac, bc, cc, dc = SHOTerm(S0=2.0, w0=1.5, Q=0.3).get_coefficients()
+    assert len(ar) == 2 and len(ac) == 0
+    f = np.sqrt(1 - 4 * 0.09)
+    np.testing.assert_allclose(ar, 0.5 * 2.0 * 1.5 * 0.3 * np.array([1 + 1 / f, 1 - 1 / f]))
+    np.testing.assert_allclose(cr, 0.5 * 1.5 / 0.3 * np.array([1 - f, 1 + f]))
+    # Q = 0.5 takes the underdamped branch with f = sqrt(eps)
+    ar, cr, ac, bc, cc, dc = SHOTerm(S0=1.0, w0=2.0, Q=0.5).get_coefficients()
+    assert len(ar) == 0 and len(ac) == 1
+    np.testing.assert_allclose(dc, cc * np.sqrt(1e-5))
+    # sigma / rho / tau parameterisation
+    t1 = SHOTerm(sigma=1.3, rho=2.0, tau=5.0)
+    assert np.isclose(t1.w0, np.pi) and np.isclose(t1.Q, 0.5 * np.pi * 5.0)
+    assert np.isclose(t1.S0, 1.3 ** 2 / (t1.w0 * t1.Q))
+
+
+@pytest.mark.parametrize("Q", [0.3, 0.6, 5.0, 1500.0])
+def test_psd_is_fourier_pair_of_kernel(Q):
+    """generic coefficient PSD == closed-form SHO PSD (reference core.py:33-41)."""
+    term = SHOTerm(S0=0.7, w0=3.0, Q=Q)
+    w = np.linspace(0.01, 12, 200)
+    from gadfly_amd.terms import Term
+    np.testing.assert_allclose(Term.get_psd(term, w), term.get_psd(w), rtol=1e-4 if Q < 0.5 else 1e-11)
+    from gadfly_amd.core import _sho_psd
+    np.testing.assert_allclose(term.get_psd(w), _sho_psd(w, 0.7, 3.0, Q), rtol=1e-14)
+
+
+def test_term_convolution_against_quadrature():
+    base = TermSum(SHOTerm(S0=1.0, w0=3.0, Q=5.0), SHOTerm(S0=0.5, w0=1.0, Q=0.3))
+    delta = 0.05
+    k = TermConvolution(base, delta)
+    for tau in [0.0, 0.013, 0.05, 0.0731, 0.4, 2.3]:
+        f = lambda s: (delta - abs(s)) * base.get_value(np.array(tau + s))   # noqa: E731
+        val = quad(f, -delta, delta, points=[0.0, -tau] if tau < delta else None,
+                   epsabs=1e-14, epsrel=1e-13)[0] / delta ** 2
+        assert abs(k.get_value(np.array(tau)) - val) < 1e-11 * abs(val)
+    # solver view: transformed coefficients + diagonal shift reproduce k(0) and k(tau >= delta)
+    K = k.to_dense(np.array([0.0, delta, 1.0]), np.zeros(3))
+    assert abs(K[0, 0] - k.get_value(np.zeros(1))[0]) < 1e-12 * K[0, 0]
+    assert abs(K[0, 2] - k.get_value(np.array(1.0))) < 1e-12 * abs(K[0, 2])
+    # PSD picks up sinc^2
+    w = np.array([0.0, 1.0, 40.0])
+    np.testing.assert_allclose(k.get_psd(w), base.get_psd(w) * np.sinc(0.5 * delta * w / np.pi) ** 2)
+
+
+def test_term_convolution_overflow_is_reproduced_not_hidden():
+    """cosh(c delta) overflows for c delta > ~710 (ShotNoiseKernel w0 = 1e7 with a long exposure,
+    SURVEY.md section 7 hazard ii): celerite2's formulas give inf/nan and so do these."""
+    k = gadfly_amd.StellarOscillatorKernel(
+        terms=[gadfly_amd.ShotNoiseKernel(S0=1.0, w0=1e7, Q=0.5)], delta=100e-6)
+    co = k.get_coefficients()
+    assert not np.all(np.isfinite(co[2]))
+
+
+def test_kernel_api_surface():
+    hp = solar_like_hyperparameters(6)
+    assert isinstance(hp, gadfly_amd.Hyperparameters) and len(hp) == 6
+    assert "showing 1 of 6" in repr(hp)
+    k = gadfly_amd.StellarOscillatorKernel(hp, texp=60.0)
+    assert k.name == hp.name and k.hyperparameters is hp
+    assert np.isclose(k.delta, 60e-6) and len(k.term.terms) == 6 and len(k) == 12
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        k0 = gadfly_amd.StellarOscillatorKernel(hp)
+        assert np.isclose(k0.delta, 60e-6) and any("exposure time" in str(x.message) for x in w)
+    # __add__ bookkeeping (reference core.py:405-427)
+    k2 = k + gadfly_amd.ShotNoiseKernel(S0=1e-3, w0=1e5, Q=0.5)
+    assert k2.name == hp.name + " + Shot noise" and len(k2.term.terms) == 7 and k2.delta == k.delta
+    assert gadfly_amd.ShotNoiseKernel.w0 == 1e7 and gadfly_amd.ShotNoiseKernel.Q == 0.5
+    # from_soho_virgo returns the raw 9-entry fit whose oscillation entries lack w0
+    raw = gadfly_amd.Hyperparameters.from_soho_virgo()
+    assert len(raw) == 9 and raw.name == "SOHO VIRGO/PMO6"
+    assert "w0" not in raw[5]["hyperparameters"]
+    with pytest.raises(NotImplementedError):
+        gadfly_amd.SolarOscillatorKernel(texp=60.0)
+    lo, up = gadfly_amd.ShotNoiseKernel.kepler_mag_to_noise_amplitude(12.0)
+    assert 0 < lo < up
+
+
+def test_get_psd_matches_sum_of_sho_with_exposure():
+    hp = solar_like_hyperparameters(8)
+    k = gadfly_amd.StellarOscillatorKernel(hp, texp=60.0)
+    from gadfly_amd.core import _sho_psd
+    w = 2 * np.pi * np.linspace(3.0, 4000.0, 300)
+    ref = sum(_sho_psd(w, **p["hyperparameters"]) for p in hp) * np.sinc(0.5 * k.delta * w / np.pi) ** 2
+    np.testing.assert_allclose(k.get_psd(w), ref, rtol=1e-12)
