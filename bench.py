@@ -39,9 +39,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=1_000_000, help="cadences per light curve")
     ap.add_argument("--j", type=int, default=30, help="SHO terms (celerite width = 2J)")
-    ap.add_argument("--evals", type=int, default=1024,
+    ap.add_argument("--evals", type=int, default=2048,
                     help="independent evaluations (walkers) per rank per step")
     ap.add_argument("--tile-rows", type=int, default=8192, help="rows per streamed tile")
+    ap.add_argument("--overlap", action="store_true",
+                    help="build tile k+1 on a side stream during the sweep of tile k (slower: "
+                         "the build waves displace one of the two sweep waves per SIMD)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=0,
                     help="rows of the CPU-baseline sample (0 = full N, one evaluation)")
@@ -89,7 +92,8 @@ def main():
 
     nsteps = args.warmup + args.steps
     ev = gadfly_amd.BatchedLogLikelihood(walkers(0), t, y, yerr=yerr, device=device,
-                                         tile_rows=args.tile_rows)
+                                         tile_rows=args.tile_rows,
+                                         overlap_build=args.overlap)
     packs = [ev.pack(walkers(s)) for s in range(nsteps)]
     eng = ev.engine
     eng.time_factor = True

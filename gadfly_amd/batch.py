@@ -22,7 +22,7 @@ class BatchedLogLikelihood:
     kernels costs an O(B J) coefficient upload plus the device work."""
 
     def __init__(self, kernels, t, y, yerr=None, diag=None, mean=0.0, device=None,
-                 tile_rows=8192):
+                 tile_rows=8192, overlap_build=False):
         if yerr is not None and diag is not None:
             raise ValueError("only one of 'diag' and 'yerr' can be provided")
         t = np.ascontiguousarray(t, dtype=np.float64)
@@ -39,7 +39,8 @@ class BatchedLogLikelihood:
         if d is not None and d.ndim == 0:
             d = np.full(t.shape[-1], float(d))
         self.engine = StreamingBatch([k.get_device_coefficients() for k in kernels], t,
-                                     y - mean, diag=d, tile_rows=tile_rows, device=device)
+                                     y - mean, diag=d, tile_rows=tile_rows, device=device,
+                                     overlap_build=overlap_build)
 
     @property
     def B(self):

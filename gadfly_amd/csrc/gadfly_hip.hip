@@ -367,90 +367,141 @@ __global__ void __launch_bounds__(64 * NW) k_factor(const FactorArgs A) {
 // k_build2 writes u~, v~ (and E at reset rows); k_factor2 reads the row operands u~_i as
 // wave-uniform scalar loads (SGPR operands of v_fma_f64), so only w~ needs an LDS broadcast.
 // ------------------------------------------------------------------------------------
-constexpr int SC_BLOCK = 8;
-constexpr double SC_GAP = 4.0;
+// reset(n) = (n % block == 0) or cmax (t_n - t_{n-1}) > gap, with (block - 1) * gap <= 28
+constexpr double SC_SPAN = 28.0;
 
 struct Build2Args {
     int64_t N, n_first;
-    int Jr, Jc, ld, units;
+    int Jr, Jc, ld, units, block;   // block: power of two, rows between forced resets
+    double gap;                     // cmax * dt above which a row is a reset of its own
     const double *ar, *cr, *ac, *bc, *cc, *dc, *diag_add, *cmax;
     const double *t; int64_t t_bs;
     const double *diag; int64_t diag_bs;
     double *a, *Ut, *Vt, *de;       // de[n] = t_ref(n) - t_ref(n-1) at reset rows, -1 elsewhere
 };
 
-__device__ __forceinline__ bool sc_is_reset(const double *t, int64_t g, double cmax) {
-    return (g % SC_BLOCK) == 0 || cmax * (t[g] - t[g - 1]) > SC_GAP;
+__device__ __forceinline__ bool sc_is_reset(const double *t, int64_t g, double cmax, int block,
+                                            double gap) {
+    return (g & (block - 1)) == 0 || cmax * (t[g] - t[g - 1]) > gap;
 }
 
-// latest reset row <= g (bounded walk: g - g % SC_BLOCK is always a reset)
-__device__ __forceinline__ int64_t sc_ref(const double *t, int64_t g, double cmax) {
-    while (!sc_is_reset(t, g, cmax)) --g;
+// latest reset row <= g (bounded walk: g - g % block is always a reset)
+__device__ __forceinline__ int64_t sc_ref(const double *t, int64_t g, double cmax, int block,
+                                          double gap) {
+    while (!sc_is_reset(t, g, cmax, block, gap)) --g;
     return g;
 }
 
+constexpr int B2_ROWS = 32;         // rows per workgroup of k_build2
+
 __global__ void __launch_bounds__(256) k_build2(const Build2Args A) {
     const int b = blockIdx.y;
-    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t n = id / A.units;
-    if (n >= A.N) return;
-    const int q = (int)(id - n * A.units);
+    const int64_t n0 = (int64_t)blockIdx.x * B2_ROWS;          // first tile-local row of the block
+    const int nrows = (int)((A.N - n0 < B2_ROWS) ? (A.N - n0) : B2_ROWS);
     const int W = A.Jr + 2 * A.Jc;
     const double *t = A.t + (size_t)b * A.t_bs;
     const double cmax = A.cmax[b];
-    const int64_t g = A.n_first + n;
-    const double tn = t[g];
-    const bool reset = sc_is_reset(t, g, cmax);
-    const int64_t ref = reset ? g : sc_ref(t, g, cmax);
-    const double ds = tn - t[ref];                               // >= 0, 0 at a reset row
-    const double de = (reset && g > 0) ? (tn - t[sc_ref(t, g - 1, cmax)]) : 0.0;
-    const size_t row = ((size_t)b * A.N + n) * A.ld;
-    if (q == 0) {
+
+    // phase 1: one thread per row -- reset rule, distance to the block reference, block decay
+    __shared__ double s_t[B2_ROWS], s_ds[B2_ROWS];
+    if ((int)threadIdx.x < nrows) {
+        const int r = threadIdx.x;
+        const int64_t g = A.n_first + n0 + r;
+        const double tn = t[g];
+        const bool reset = sc_is_reset(t, g, cmax, A.block, A.gap);
+        const int64_t ref = reset ? g : sc_ref(t, g, cmax, A.block, A.gap);
+        const double de = reset ? ((g > 0) ? (tn - t[sc_ref(t, g - 1, cmax, A.block, A.gap)]) : 0.0)
+                                : -1.0;
+        s_t[r] = tn;
+        s_ds[r] = tn - t[ref];                                   // >= 0, 0 at a reset row
+        const size_t o = (size_t)b * A.N + n0 + r;
         const double dg = A.diag ? A.diag[(size_t)b * A.diag_bs + g] : 0.0;
-        A.a[(size_t)b * A.N + n] = dg + A.diag_add[b];
-        A.de[(size_t)b * A.N + n] = reset ? de : -1.0;
+        A.a[o] = dg + A.diag_add[b];
+        A.de[o] = de;
     }
-    if (q < A.Jr) {
-        const double ar = A.ar[(size_t)b * A.Jr + q], cr = A.cr[(size_t)b * A.Jr + q];
-        A.Ut[row + q] = ar * exp(-cr * ds);
-        A.Vt[row + q] = exp(cr * ds);
-    } else if (q < A.Jr + A.Jc) {
-        const int k = q - A.Jr;
-        const size_t ck = (size_t)b * A.Jc + k;
-        const double ac = A.ac[ck], bc = A.bc[ck], cc = A.cc[ck], dc = A.dc[ck];
-        const double arg = dc * tn;                  // ONE rounded multiply (parity hazard i)
-        double si, co;
-        sincos(arg, &si, &co);
-        const double rho = exp(-cc * ds), irho = exp(cc * ds);
-        const int j = A.Jr + 2 * k;
-        A.Ut[row + j]     = (ac * co + bc * si) * rho;
-        A.Ut[row + j + 1] = (ac * si - bc * co) * rho;
-        A.Vt[row + j]     = co * irho;
-        A.Vt[row + j + 1] = si * irho;
-    } else {
-        const int j = W + (q - A.Jr - A.Jc);
-        A.Ut[row + j] = 0.0;
-        A.Vt[row + j] = 0.0;
+    __syncthreads();
+
+    // phase 2: one thread per (row, term); the first (ld - W) units of a row also zero a pad column
+    const unsigned units = (unsigned)(A.Jr + A.Jc);
+    const unsigned total = (unsigned)nrows * units;
+    const int npad = A.ld - W;
+    for (unsigned idx = threadIdx.x; idx < total; idx += 256) {
+        const unsigned r = idx / units;
+        const int q = (int)(idx - r * units);
+        const double tn = s_t[r], ds = s_ds[r];
+        const size_t row = ((size_t)b * A.N + n0 + r) * A.ld;
+        if (q < A.Jr) {
+            const double ar = A.ar[(size_t)b * A.Jr + q], cr = A.cr[(size_t)b * A.Jr + q];
+            const double rho = exp(-cr * ds);
+            A.Ut[row + q] = ar * rho;
+            A.Vt[row + q] = 1.0 / rho;
+        } else {
+            const int k = q - A.Jr;
+            const size_t ck = (size_t)b * A.Jc + k;
+            const double ac = A.ac[ck], bc = A.bc[ck], cc = A.cc[ck], dc = A.dc[ck];
+            const double arg = dc * tn;              // ONE rounded multiply (parity hazard i)
+            double si, co;
+            sincos(arg, &si, &co);
+            const double rho = exp(-cc * ds), irho = 1.0 / rho;
+            const int j = A.Jr + 2 * k;
+            double2 u2, v2;
+            u2.x = (ac * co + bc * si) * rho;
+            u2.y = (ac * si - bc * co) * rho;
+            v2.x = co * irho;
+            v2.y = si * irho;
+            if ((j & 1) == 0) {                      // 16-byte aligned pair
+                *reinterpret_cast<double2 *>(A.Ut + row + j) = u2;
+                *reinterpret_cast<double2 *>(A.Vt + row + j) = v2;
+            } else {
+                A.Ut[row + j] = u2.x; A.Ut[row + j + 1] = u2.y;
+                A.Vt[row + j] = v2.x; A.Vt[row + j + 1] = v2.y;
+            }
+        }
+        if (q < npad) {
+            A.Ut[row + W + q] = 0.0;
+            A.Vt[row + W + q] = 0.0;
+        }
+    }
+    // more pad columns than units (tiny kernels only)
+    if (npad > (int)units) {
+        for (unsigned idx = threadIdx.x; idx < (unsigned)nrows * (unsigned)npad; idx += 256) {
+            const unsigned r = idx / (unsigned)npad;
+            const int q = (int)(idx - r * (unsigned)npad);
+            const size_t row = ((size_t)b * A.N + n0 + r) * A.ld;
+            A.Ut[row + W + q] = 0.0;
+            A.Vt[row + W + q] = 0.0;
+        }
     }
 }
 
-// One sweep over the ROWS register-resident rows of T with wave-uniform row operands read
-// from LDS (xa[i], xw[i]), software-pipelined: batches of 4 rows (2 + 2 ds_read_b128), AHEAD
+// Sweeps over the ROWS register-resident rows of T with wave-uniform row operands read from
+// LDS (xa[i], xw[i]), software-pipelined: batches of 4 rows (2 + 2 ds_read_b128), SW_AHEAD
 // batches in flight ahead of the FMAs, so the LDS latency is paid once per sweep and not once
 // per read (hipcc otherwise parks every read right in front of its use).
-//   RESET = false:  T_i += xw_i * dwv ;  acc += xa_i * T_i          (update + mat-vec)
-//   RESET = true :  T_i  = (T_i + xw_i * dwv) * (xa_i * el)        (fold pending, decay)
-template <int ROWS, bool RESET>
-__device__ __forceinline__ double t_sweep(double (&T)[ROWS], const double *xa, const double *xw,
-                                          const double dwv, const double el) {
-    constexpr int BR = 4, NB = ROWS / BR, AHEAD = 2;
-    static_assert(ROWS % BR == 0, "ROWS must be a multiple of 4");
-    double ab[AHEAD + 1][BR], wb[AHEAD + 1][BR];
+constexpr int SW_BR = 4, SW_AHEAD = 2;
+
+// issue the reads of the first SW_AHEAD batches (done early, under the reduction of the
+// previous row: the operands do not depend on it)
+template <int ROWS>
+__device__ __forceinline__ void sweep_preload(double (&ab)[SW_AHEAD + 1][SW_BR],
+                                              double (&wb)[SW_AHEAD + 1][SW_BR],
+                                              const double *xa, const double *xw) {
+    constexpr int NB = ROWS / SW_BR;
 #pragma unroll
-    for (int k = 0; k < AHEAD && k < NB; ++k) {
+    for (int k = 0; k < SW_AHEAD && k < NB; ++k) {
 #pragma unroll
-        for (int r = 0; r < BR; ++r) { ab[k][r] = xa[k * BR + r]; wb[k][r] = xw[k * BR + r]; }
+        for (int r = 0; r < SW_BR; ++r) { ab[k][r] = xa[k * SW_BR + r]; wb[k][r] = xw[k * SW_BR + r]; }
     }
+}
+
+//   RESET = false:  T_i += xw_i * q ;  acc += xa_i * T_i            (update + mat-vec)
+//   RESET = true :  T_i  = (T_i + xw_i * q) * (xa_i * el)          (fold pending, decay)
+template <int ROWS, bool RESET>
+__device__ __forceinline__ double sweep_run(double (&T)[ROWS], double (&ab)[SW_AHEAD + 1][SW_BR],
+                                            double (&wb)[SW_AHEAD + 1][SW_BR], const double *xa,
+                                            const double *xw, const double q, const double el) {
+    constexpr int BR = SW_BR, NB = ROWS / BR, AHEAD = SW_AHEAD;
+    static_assert(ROWS % BR == 0, "ROWS must be a multiple of 4");
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
@@ -466,12 +517,12 @@ __device__ __forceinline__ double t_sweep(double (&T)[ROWS], const double *xa, c
         if constexpr (RESET) {
 #pragma unroll
             for (int r = 0; r < BR; ++r)
-                T[k * BR + r] = fma(wb[c][r], dwv, T[k * BR + r]) * (ab[c][r] * el);
+                T[k * BR + r] = fma(wb[c][r], q, T[k * BR + r]) * (ab[c][r] * el);
         } else {
-            T[k * BR + 0] = fma(wb[c][0], dwv, T[k * BR + 0]);
-            T[k * BR + 1] = fma(wb[c][1], dwv, T[k * BR + 1]);
-            T[k * BR + 2] = fma(wb[c][2], dwv, T[k * BR + 2]);
-            T[k * BR + 3] = fma(wb[c][3], dwv, T[k * BR + 3]);
+            T[k * BR + 0] = fma(wb[c][0], q, T[k * BR + 0]);
+            T[k * BR + 1] = fma(wb[c][1], q, T[k * BR + 1]);
+            T[k * BR + 2] = fma(wb[c][2], q, T[k * BR + 2]);
+            T[k * BR + 3] = fma(wb[c][3], q, T[k * BR + 3]);
             acc0 = fma(ab[c][0], T[k * BR + 0], acc0);
             acc1 = fma(ab[c][1], T[k * BR + 1], acc1);
             acc2 = fma(ab[c][2], T[k * BR + 2], acc2);
@@ -485,6 +536,16 @@ __device__ __forceinline__ double t_sweep(double (&T)[ROWS], const double *xa, c
     return (acc0 + acc2) + (acc1 + acc3);
 }
 
+// Per row n (scaled coordinates; r = v~ - tmp, so w~ = r/d and d w~ = r):
+//     sweep :  T_i += r_{n-1,i} * q_{n-1}  (q = r/d, lane-form) ;  tmp = sum_i u~_{n,i} T_i
+//     r_n = v~_n - tmp ;  stage r_n and u~_{n+1} in LDS, start reading the next row's operands
+//     d_n = a_n - u~_n . tmp ;  z_n = y_n - u~_n . F~ ;  q_n = r_n / d_n
+// The division and the DPP reduction sit between two sweeps; staging r (not w~) lets the LDS
+// traffic of the next sweep start before they finish.
+// Forward solve for free (W < 64): lane 63 is a pad column of T; loading it with F~ (as
+// T[i][63] = F~_i) and giving it the multiplier q_63 = z/d makes the sweep's rank-1 update
+// perform F~ += r z/d and its mat-vec return u~ . F~ in lane 63's partial sum, so the
+// solve needs neither its own recurrence nor a second DPP reduction.
 template <int ROWS>
 __global__ void __launch_bounds__(64, 2)     // 2 waves/SIMD: one wave alone gets half the VALU issue rate
 k_factor2(const int64_t N, const int64_t n_first, const int ld, const int W,
@@ -510,57 +571,81 @@ k_factor2(const int64_t N, const int64_t n_first, const int ld, const int W,
     double *__restrict__ Sg = S_state + (size_t)b * (64 * 64) + (size_t)lane * 64;
     double *__restrict__ Fg = F_state + (size_t)b * 64;
 
-    __shared__ double s_w[64];
-    __shared__ double s_u[64];
+    __shared__ double s_w[64];      // r_{n-1}  (pending rank-1 update, row form)
+    __shared__ double s_u[64];      // u~_n
+    __shared__ double s_e[64];      // block decay E at reset rows
     const bool colok = lane < ld;
     const double cj = (lane < W) ? c_[(size_t)b * W + lane] : 0.0;
 
+    // PADF: the forward solve rides in pad lane 63 (needs W < 64, i.e. ld <= 64 and lane 63 unused)
+    const bool PADF = (ROWS < 64) || (W < 64);   // compile-time true except for ROWS == 64
+    const bool fl = PADF && lane == 63;
     double T[ROWS];
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) T[i] = Sg[i];
-    double Fv = Fg[lane];
-    double wv = 0.0, dwv = 0.0, zprev = 0.0;
-    s_w[lane] = 0.0;
+    double Fv = Fg[lane];                       // only used when !PADF
+    if (PADF) {
+        // F~ (row form in F_state) becomes lane 63's column of T
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) T[i] = fl ? Fg[i] : T[i];
+    }
+    double rprev = 0.0, q = 0.0, zq = 0.0;      // pending: T += r r^T/d, F~ += r z/d
     int32_t fail = 0;
 
-    // Everything a row needs is prefetched one row ahead, unconditionally (the caller pads
-    // every buffer, y included, by one row/element): a clamped index makes hipcc give up its
+    // Everything a row needs is prefetched two rows ahead, unconditionally (the caller pads
+    // every buffer, y included, by two rows/elements): a clamped index makes hipcc give up its
     // scalarisation of uniform loads, and an un-prefetched scalar costs a full memory round
     // trip per row.  Pad lanes (>= ld) re-read column ld-1 and are masked in registers.
     const int lanec = colok ? lane : (ld - 1);
-    double ut_n = Ug[lanec];
-    double vt_n = Vg[lanec];
+    double ut_n = Ug[lanec], ut_n2 = Ug[ld + lanec];
+    double vt_n = Vg[lanec], vt_n2 = Vg[ld + lanec];
     double a_nx = ag[0], y_nx = yg[0], e_nx = eg[0];
+    double a_nx2 = ag[1], y_nx2 = yg[1], e_nx2 = eg[1];
+
+    double ab[SW_AHEAD + 1][SW_BR], wb[SW_AHEAD + 1][SW_BR];
+    s_w[lane] = 0.0;
+    s_u[lane] = colok ? ut_n : 0.0;
+    wave_lds_fence();
+    sweep_preload<ROWS>(ab, wb, s_u, s_w);
 
     for (int64_t n = 0; n < N; ++n) {
         const double ut = colok ? ut_n : 0.0, vt = colok ? vt_n : 0.0;
         const double a_n = a_nx, y_n = y_nx, e_n = e_nx;
-        ut_n = Ug[(size_t)(n + 1) * ld + lanec];
-        vt_n = Vg[(size_t)(n + 1) * ld + lanec];
-        a_nx = ag[n + 1];
-        y_nx = yg[n + 1];
-        e_nx = eg[n + 1];
+        ut_n = ut_n2; vt_n = vt_n2; a_nx = a_nx2; y_nx = y_nx2; e_nx = e_nx2;
+        ut_n2 = Ug[(size_t)(n + 2) * ld + lanec];
+        vt_n2 = Vg[(size_t)(n + 2) * ld + lanec];
+        a_nx2 = ag[n + 2];
+        y_nx2 = yg[n + 2];
+        e_nx2 = eg[n + 2];
         if (e_n >= 0.0) {                   // wave-uniform: reset row
             // fold the pending update, then decay by E = exp(-c * de) (de = t_ref - t_ref_prev)
-            const double el = exp(-cj * e_n);
+            const double el = colok ? exp(-cj * e_n) : 1.0;
+            s_e[lane] = el;
             wave_lds_fence();
-            s_u[lane] = el;
-            wave_lds_fence();
-            (void)t_sweep<ROWS, true>(T, s_u, s_w, dwv, el);
-            Fv = el * fma(wv, zprev, Fv);
-            dwv = 0.0;
-            zprev = 0.0;
+            double eb[SW_AHEAD + 1][SW_BR], fb[SW_AHEAD + 1][SW_BR];
+            sweep_preload<ROWS>(eb, fb, s_e, s_w);
+            (void)sweep_run<ROWS, true>(T, eb, fb, s_e, s_w, q, el);
+            Fv = el * fma(rprev, zq, Fv);
+            q = 0.0;
+            zq = 0.0;
         }
-        // Row operands u~_i must be wave-uniform.  Scalar loads (s_load) of the row work but
-        // stream through the scalar cache's slow miss path (measured 2.4 us/row); the LDS
-        // broadcast of the prefetched lane-form row costs ~2 LDS cycles per operand.
+        const double tmp = sweep_run<ROWS, false>(T, ab, wb, s_u, s_w, q, 0.0);
+        const double r = fl ? 0.0 : (vt - tmp); // pad lanes: 0 - 0; lane 63 carries u~ . F~
+        Fv = fma(rprev, zq, Fv);
+        // stage the next row's operands and start fetching them under the reduction
         wave_lds_fence();
-        s_u[lane] = ut;
+        s_w[lane] = r;
+        s_u[lane] = colok ? ut_n : 0.0;
         wave_lds_fence();
-        const double tmp = t_sweep<ROWS, false>(T, s_u, s_w, dwv, 0.0);
-        Fv = fma(wv, zprev, Fv);
-        double s1 = ut * tmp, s2 = ut * Fv;
-        wave_sum2(s1, s2);
+        sweep_preload<ROWS>(ab, wb, s_u, s_w);
+        double s1 = ut * tmp, s2;
+        if (PADF) {                             // wave-uniform
+            s1 = wave_sum(s1);                  // ut = 0 in lane 63
+            s2 = read_lane(tmp, 63);
+        } else {
+            s2 = ut * Fv;
+            wave_sum2(s1, s2);
+        }
         const double dn = a_n - s1;
         const double zn = y_n - s2;
         if (!(dn > 0.0)) {
@@ -568,12 +653,11 @@ k_factor2(const int64_t N, const int64_t n_first, const int ld, const int W,
             fail = (int32_t)(gg > 0x7fffffff ? 0x7fffffff : gg);
             break;
         }
-        wv = (vt - tmp) / dn;
-        dwv = dn * wv;
-        wave_lds_fence();
-        s_w[lane] = wv;
+        const double inv = 1.0 / dn;
+        zq = zn * inv;
+        q = fl ? zq : r * inv;
+        rprev = r;
         if (lane == 0) { dg[n] = dn; zg[n] = zn; }
-        zprev = zn;
     }
     if (fail) {
         if (lane == 0) info[b] = fail;
@@ -581,8 +665,11 @@ k_factor2(const int64_t N, const int64_t n_first, const int ld, const int W,
     }
     wave_lds_fence();
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) Sg[i] = fma(s_w[i], dwv, T[i]);
-    Fg[lane] = fma(wv, zprev, Fv);
+    for (int i = 0; i < ROWS; ++i) {
+        const double v = fma(s_w[i], q, T[i]);
+        if (fl) Fg[i] = v; else Sg[i] = v;
+    }
+    if (!PADF) Fg[lane] = fma(rprev, zq, Fv);
 }
 
 // ------------------------------------------------------------------------------------
@@ -984,7 +1071,7 @@ int gf_scaled_supported(int W) { return (W >= 1 && W <= 64) ? 1 : 0; }
 int gf_build_scaled(int B, int64_t N, int64_t n_first, int Jr, int Jc, int ld,
                     const double *ar, const double *cr, const double *ac,
                     const double *bc, const double *cc, const double *dc,
-                    const double *diag_add, const double *cmax,
+                    const double *diag_add, const double *cmax, int block,
                     const double *t, int64_t t_bs,
                     const double *diag, int64_t diag_bs,
                     double *a, double *Ut, double *Vt, double *de, void *stream) {
@@ -992,14 +1079,16 @@ int gf_build_scaled(int B, int64_t N, int64_t n_first, int Jr, int Jc, int ld,
     if (B < 1 || N < 1) return set_err("gf_build_scaled: empty problem (B=%s%lld, N=%lld)", "", B, N);
     if (!gf_scaled_supported(W)) return set_err("gf_build_scaled: width %s%lld unsupported (max 64)", "", W);
     if (ld < W || (ld & 15)) return set_err("gf_build_scaled: ld=%s%lld must be a multiple of 16 and >= W=%lld", "", ld, W);
-    if (n_first < 0 || (n_first % SC_BLOCK) != 0) return set_err("gf_build_scaled: n_first=%s%lld must be a non-negative multiple of 8", "", n_first);
+    if (block < 1 || block > 64 || (block & (block - 1))) return set_err("gf_build_scaled: block=%s%lld must be a power of two in 1..64", "", block);
+    if (n_first < 0 || (n_first % block) != 0) return set_err("gf_build_scaled: n_first=%s%lld must be a non-negative multiple of block=%lld", "", n_first, block);
     if (!t || !a || !Ut || !Vt || !de || !diag_add || !cmax) return set_err("gf_build_scaled: null pointer%s", "");
     Build2Args A;
     A.N = N; A.n_first = n_first; A.Jr = Jr; A.Jc = Jc; A.ld = ld; A.units = Jr + Jc + (ld - W);
+    A.block = block; A.gap = (block > 1) ? SC_SPAN / (double)(block - 1) : 0.0;
     A.ar = ar; A.cr = cr; A.ac = ac; A.bc = bc; A.cc = cc; A.dc = dc; A.diag_add = diag_add; A.cmax = cmax;
     A.t = t; A.t_bs = t_bs; A.diag = diag; A.diag_bs = diag_bs;
     A.a = a; A.Ut = Ut; A.Vt = Vt; A.de = de;
-    const int64_t blocks = (N * A.units + 255) / 256;
+    const int64_t blocks = (N + B2_ROWS - 1) / B2_ROWS;
     if (blocks > 0x7fffffffLL) return set_err("gf_build_scaled: problem too large%s", "");
     hipLaunchKernelGGL(k_build2, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, A);
     return check_launch("gf_build_scaled");

@@ -294,7 +294,7 @@ class StreamingBatch:
     """
 
     def __init__(self, coeffs_list, t, y, diag=None, tile_rows=8192, device=None,
-                 force_v1=False):
+                 force_v1=False, overlap_build=False):
         torch = _lib.require_device()
         self.torch = torch
         self.lib = _lib.load()
@@ -329,7 +329,7 @@ class StreamingBatch:
         if y.shape[1] != self.N:
             raise ValueError("dimension mismatch")
         # one spare element at the very end: the sweep prefetches row n+1 unconditionally
-        ypad = torch.zeros((y.shape[0] * self.N + 1,), **f64)
+        ypad = torch.zeros((y.shape[0] * self.N + 2,), **f64)
         ypad[:y.shape[0] * self.N] = y.reshape(-1)
         self.y = ypad[:y.shape[0] * self.N].view(y.shape[0], self.N)
         self._ypad = ypad
@@ -338,23 +338,27 @@ class StreamingBatch:
             self.diag = rows(diag, "diag")
             if self.diag.shape[1] != self.N:
                 raise ValueError("dimension mismatch")
-        self._pack = self._make_pack(real, comp, diag_add, c)
+        self._coeff_host = (real, comp, diag_add, c)
         B, ld = self.B, self.ld
         # W <= 64: block-scaled one-wave-per-problem kernels (k_build2 / k_factor2)
         self.scaled = bool(self.lib.gf_scaled_supported(self.W)) and not force_v1
         T = int(min(max(int(tile_rows), 1), self.N))
         if T < self.N:
-            T = max(8, T // 8 * 8)            # tiles start on a reset row (multiple of 8)
+            T = max(64, T // 64 * 64)         # tiles start on a reset row (any block <= 64)
         self.tile_rows = T
+        # typical cadence (median spacing) sets how many rows a scaled block may span
+        tt = self.t[0]
+        self._dt_med = float(torch.median(tt[1:] - tt[:-1])) if self.N > 1 else 0.0
+        self._pack = self._make_pack(*self._coeff_host)
 
         def rows_buf():
             # one spare row: the sweep prefetches row n+1 unconditionally
-            return torch.zeros((B * T + 1, ld), **f64)
+            return torch.zeros((B * T + 2, ld), **f64)
 
-        self.bufs = [dict(a=torch.zeros((B * T + 1,), **f64), U=rows_buf(), V=rows_buf(),
+        self.bufs = [dict(a=torch.zeros((B * T + 2,), **f64), U=rows_buf(), V=rows_buf(),
                           P=None if self.scaled else rows_buf(),
-                          de=torch.zeros((B * T + 1,), **f64))
-                     for _ in range(2 if T < self.N else 1)]
+                          de=torch.zeros((B * T + 2,), **f64))
+                     for _ in range(2 if (T < self.N and overlap_build) else 1)]
         self.d = torch.empty((B, T), **f64)
         self.z = torch.empty((B, T), **f64)
         nS = 64 * 64 if self.scaled else int(self.lib.gf_state_size(self.W))
@@ -365,7 +369,9 @@ class StreamingBatch:
         self.work = torch.empty((B * int(self.lib.gf_reduce_work(T)),), **f64)
         self.info = torch.zeros((B,), dtype=torch.int32, device=self.device)
         self.out = torch.empty((B,), **f64)
-        self.side = torch.cuda.Stream(device=self.device)
+        # build of tile k+1 on a side stream (overlapping the sweep of tile k) or in line
+        self.overlap_build = bool(overlap_build)
+        self.side = torch.cuda.Stream(device=self.device) if self.overlap_build else None
         self.time_factor = False
         self.factor_events = []
 
@@ -376,7 +382,13 @@ class StreamingBatch:
     def _make_pack(self, real, comp, diag_add, c):
         dev = self._dev
         cmax = np.max(c, axis=1)
-        return dev(real), dev(comp), dev(diag_add), dev(c), dev(cmax)
+        # rows between forced resets of the scaled coordinates: largest power of two with
+        # 1.5 * (block - 1) * cmax * cadence <= 28 (see k_build2)
+        x = 1.5 * float(np.max(cmax)) * max(getattr(self, "_dt_med", 0.0), 0.0)
+        block = 64
+        while block > 1 and (block - 1) * x > 28.0:
+            block //= 2
+        return dev(real), dev(comp), dev(diag_add), dev(c), dev(cmax), block
 
     def pack_coefficients(self, coeffs_list):
         Jr, Jc, real, comp, diag_add, c = _coeff_pack(coeffs_list)
@@ -390,13 +402,13 @@ class StreamingBatch:
     def _build_tile(self, k, buf, stream):
         n0 = k * self.tile_rows
         rows = min(self.tile_rows, self.N - n0)
-        real, comp, diag_add, _, cmax = self._pack
+        real, comp, diag_add, _, cmax, block = self._pack
         p = _lib.ptr
         if self.scaled:
             st = self.lib.gf_build_scaled(
                 self.B, rows, n0, self.Jr, self.Jc, self.ld,
                 p(real[0]), p(real[1]), p(comp[0]), p(comp[1]), p(comp[2]), p(comp[3]),
-                p(diag_add), p(cmax), p(self.t), self._bs(self.t),
+                p(diag_add), p(cmax), block, p(self.t), self._bs(self.t),
                 p(self.diag), 0 if self.diag is None else self._bs(self.diag),
                 p(buf["a"]), p(buf["U"]), p(buf["V"]), p(buf["de"]), stream.cuda_stream)
             _lib.check(st, "gf_build_scaled")
@@ -414,7 +426,7 @@ class StreamingBatch:
         torch = self.torch
         lib, p = self.lib, _lib.ptr
         main = torch.cuda.current_stream(self.device)
-        side = self.side
+        side = self.side if self.overlap_build else main
         T, N, B = self.tile_rows, self.N, self.B
         ntiles = (N + T - 1) // T
         self.S_state.zero_()
@@ -423,7 +435,8 @@ class StreamingBatch:
         nb = len(self.bufs)
         built = [None] * nb          # event: tile in buffer i is built
         freed = [None] * nb          # event: sweep that used buffer i is done
-        side.wait_stream(main)
+        if side is not main:
+            side.wait_stream(main)
         for k in range(min(nb, ntiles)):
             with torch.cuda.stream(side):
                 self._build_tile(k, self.bufs[k % nb], side)

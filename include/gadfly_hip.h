@@ -100,19 +100,21 @@ int gf_factor(int B, int64_t N, int64_t n_first, int W, int ld,
  * log-likelihood path (gp.py:202 + gp.py:350); U~, V~ are u o rho and v / rho with
  * rho = exp(-c (t_n - t_ref)); de[n] = t_ref(n) - t_ref(n-1) >= 0 at reset rows (where the
  * accumulated decay exp(-c de) is applied once) and -1 elsewhere.
- *   cmax [B] : max_j c_j of each problem (sets the reset rule); c [B][W] decay rate per column;
- *   n_first must be a multiple of 8.
+ *   cmax [B] : max_j c_j of each problem; block: rows between forced resets, a power of two in
+ *   1..64 chosen by the caller so that (block - 1) * cmax * cadence stays well below 28 (a row
+ *   whose cmax * dt exceeds 28/(block-1) resets on its own); c [B][W] decay rate per column;
+ *   n_first must be a multiple of block.
  *   outputs of gf_build_scaled: a, de [B][N]; Ut, Vt [B][N][ld]
  *   gf_factor_scaled: y (tile pointer), d, z, S_state [B][64*64], F_state [B][64], info as in
  *   gf_factor (state mandatory; zero it and info before the first tile).  Wm is not produced.
- *   The sweep prefetches row n+1 unconditionally: a, de, y, Ut, Vt must each be readable one
- *   row (element) past the last row of the last problem.
+ *   The sweep prefetches rows n+1, n+2 unconditionally: a, de, y, Ut, Vt must each be readable
+ *   two rows (elements) past the last row of the last problem.
  */
 int gf_scaled_supported(int W);
 int gf_build_scaled(int B, int64_t N, int64_t n_first, int Jr, int Jc, int ld,
                     const double *ar, const double *cr, const double *ac,
                     const double *bc, const double *cc, const double *dc,
-                    const double *diag_add, const double *cmax,
+                    const double *diag_add, const double *cmax, int block,
                     const double *t, int64_t t_bs,
                     const double *diag, int64_t diag_bs,
                     double *a, double *Ut, double *Vt, double *de, void *stream);
