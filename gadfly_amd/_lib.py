@@ -43,6 +43,8 @@ SIGNATURES = {
                         + [_vp, _i64, _vp, _i64] + [_vp] * 4 + [_vp]),
     "gf_factor_scaled": (_int, [_int, _i64, _i64, _int, _int] + [_vp] * 5 + [_vp, _i64]
                          + [_vp] * 5 + [_vp]),
+    "gf_loglike_fused": (_int, [_int, _i64, _i64, _int, _int, _int] + [_vp] * 8
+                         + [_vp, _i64, _vp, _i64, _vp, _i64] + [_vp] * 5 + [_vp]),
     "gf_reduce_work": (_i64, [_i64]),
     "gf_reduce_tile": (_int, [_int, _i64] + [_vp] * 4 + [_int, _vp]),
     "gf_loglike_finish": (_int, [_int, _i64] + [_vp] * 4 + [_vp]),
@@ -65,7 +67,7 @@ def hipcc_command(out=SO_PATH):
 
 def build(force=False, verbose=False):
     """Compile the HIP library for gfx950 in-tree (cross-compiles without a GPU)."""
-    newest = max(os.path.getmtime(p) for p in SOURCES + [HEADER])
+    newest = max(os.path.getmtime(p) for p in SOURCES + [HEADER, os.path.join(CSRC, "fastmath.h")])
     if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= newest:
         return SO_PATH
     cmd = hipcc_command()

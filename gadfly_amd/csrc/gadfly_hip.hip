@@ -23,6 +23,12 @@
 
 #include "../../include/gadfly_hip.h"
 
+// sincos / exp with <= 1 ulp error for the argument ranges of k_build2 (validated against
+// long-double libm by oracle/fastmath_check.c); ~4x fewer instructions than the general OCML
+// routines, which carry Payne-Hanek reduction for arbitrary arguments.
+#define FM_INLINE __device__ __forceinline__
+#include "fastmath.h"
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -432,7 +438,7 @@ __global__ void __launch_bounds__(256) k_build2(const Build2Args A) {
         const size_t row = ((size_t)b * A.N + n0 + r) * A.ld;
         if (q < A.Jr) {
             const double ar = A.ar[(size_t)b * A.Jr + q], cr = A.cr[(size_t)b * A.Jr + q];
-            const double rho = exp(-cr * ds);
+            const double rho = fm_exp(-cr * ds);
             A.Ut[row + q] = ar * rho;
             A.Vt[row + q] = 1.0 / rho;
         } else {
@@ -441,8 +447,9 @@ __global__ void __launch_bounds__(256) k_build2(const Build2Args A) {
             const double ac = A.ac[ck], bc = A.bc[ck], cc = A.cc[ck], dc = A.dc[ck];
             const double arg = dc * tn;              // ONE rounded multiply (parity hazard i)
             double si, co;
-            sincos(arg, &si, &co);
-            const double rho = exp(-cc * ds), irho = 1.0 / rho;
+            if (fabs(arg) < 1.6e6) fm_sincos(arg, &si, &co);   // Cody-Waite range
+            else sincos(arg, &si, &co);                        // e.g. JD-based time axes
+            const double rho = fm_exp(-cc * ds), irho = 1.0 / rho;
             const int j = A.Jr + 2 * k;
             double2 u2, v2;
             u2.x = (ac * co + bc * si) * rho;
@@ -622,9 +629,9 @@ k_factor2(const int64_t N, const int64_t n_first, const int ld, const int W,
             const double el = colok ? exp(-cj * e_n) : 1.0;
             s_e[lane] = el;
             wave_lds_fence();
-            double eb[SW_AHEAD + 1][SW_BR], fb[SW_AHEAD + 1][SW_BR];
-            sweep_preload<ROWS>(eb, fb, s_e, s_w);
-            (void)sweep_run<ROWS, true>(T, eb, fb, s_e, s_w, q, el);
+            sweep_preload<ROWS>(ab, wb, s_e, s_w);      // ring reused, re-fetched below
+            (void)sweep_run<ROWS, true>(T, ab, wb, s_e, s_w, q, el);
+            sweep_preload<ROWS>(ab, wb, s_u, s_w);
             Fv = el * fma(rprev, zq, Fv);
             q = 0.0;
             zq = 0.0;
@@ -670,6 +677,190 @@ k_factor2(const int64_t N, const int64_t n_first, const int ld, const int W,
         if (fl) Fg[i] = v; else Sg[i] = v;
     }
     if (!PADF) Fg[lane] = fma(rprev, zq, Fv);
+}
+
+// ------------------------------------------------------------------------------------
+// k_factor3: the fully fused log-likelihood sweep (W < 64).  Same recurrence as k_factor2, but
+// the generator rows are never materialised: every row's u~, v~ are produced in registers
+// from t_n (theta = d t_n as one rounded multiply, fm_sincos, running products for rho), so an
+// evaluation reads only t, y, diag (24 B/row) and writes d, z (16 B/row).  Each lane computes
+// sin AND cos of its own phase (lanes 2k, 2k+1 share theta_k), which removes any cross-lane
+// exchange:  u~ = (uA * own + uB * other) * rho,  v~ = own / rho  with
+//   even column: own = cos, uA = a, uB = +b ;  odd column: own = sin, uA = a, uB = -b ;
+//   real column: d = 0 (cos = 1), uA = a_r, uB = 0.
+// rho_n = rho_{n-1} * exp(-c dt_n): the exp is re-evaluated only when dt moves by more than
+// 1e-5/cmax from its cached value; the rounding-level jitter of a uniform cadence is absorbed
+// exactly by exp(-x) = 1 - x + x^2/2 (|x| < 1e-5 => truncation < 2e-16).
+// Valid while |d t| < 1.6e6 (fm_sincos's Cody-Waite range): the caller checks and otherwise
+// uses the k_build2 + k_factor2 pair.
+// ------------------------------------------------------------------------------------
+template <int ROWS>
+__global__ void __launch_bounds__(64, 2)
+k_factor3(const int64_t N, const int64_t n_first, const int Jr, const int Jc,
+          const int block, const double gap,
+          const double *__restrict__ ar_, const double *__restrict__ cr_,
+          const double *__restrict__ ac_, const double *__restrict__ bc_,
+          const double *__restrict__ cc_, const double *__restrict__ dc_,
+          const double *__restrict__ diag_add_, const double *__restrict__ cmax_,
+          const double *__restrict__ t_, const int64_t t_bs,
+          const double *__restrict__ diag_, const int64_t diag_bs,
+          const double *__restrict__ y_, const int64_t y_bs,
+          double *__restrict__ d_, double *__restrict__ z_,
+          double *__restrict__ S_state, double *__restrict__ F_state,
+          int32_t *__restrict__ info) {
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    if (info[b] != 0) return;
+    const int W = Jr + 2 * Jc;
+    const size_t pb = (size_t)b * N;
+    const double *__restrict__ tg = t_ + (size_t)b * t_bs + n_first;
+    const double *__restrict__ yg = y_ + (size_t)b * y_bs + n_first;
+    const double *__restrict__ gg = diag_ ? diag_ + (size_t)b * diag_bs + n_first : nullptr;
+    double *__restrict__ dg = d_ + pb;
+    double *__restrict__ zg = z_ + pb;
+    double *__restrict__ Sg = S_state + (size_t)b * (64 * 64) + (size_t)lane * 64;
+    double *__restrict__ Fg = F_state + (size_t)b * 64;
+    const double diag_add = diag_add_[b], cmax = cmax_[b];
+
+    // per-lane column constants
+    const bool colok = lane < W;
+    double cj = 0.0, dj = 0.0, uA = 0.0, uB = 0.0;
+    bool is_sin = false;
+    if (lane < Jr) {
+        cj = cr_[(size_t)b * Jr + lane];
+        uA = ar_[(size_t)b * Jr + lane];
+    } else if (colok) {
+        const int k = (lane - Jr) >> 1;
+        const size_t ck = (size_t)b * Jc + k;
+        is_sin = ((lane - Jr) & 1) != 0;
+        cj = cc_[ck];
+        dj = dc_[ck];
+        uA = ac_[ck];
+        uB = is_sin ? -bc_[ck] : bc_[ck];
+    }
+
+    __shared__ double s_w[64];      // r_{n-1}  (pending rank-1 update, row form)
+    __shared__ double s_u[64];      // u~_n
+    __shared__ double s_e[64];      // block decay E at reset rows
+    const bool fl = lane == 63;     // pad lane carrying the forward solve (W < 64)
+
+    double T[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) T[i] = fl ? Fg[i] : Sg[i];
+    double rprev = 0.0, q = 0.0, zq = 0.0;
+    int32_t fail = 0;
+
+    // running scale state
+    double rho = 1.0, irho = 1.0, p_ref = 1.0, ip_ref = 1.0, dt_ref = -1.0;
+    // reference time of the block that precedes the tile's first row (for its decay)
+    double tref = tg[0];
+    if (n_first > 0) {
+        int64_t g = -1;                             // tile-local index of global row n_first-1
+        while (!(((n_first + g) & (block - 1)) == 0 || cmax * (tg[g] - tg[g - 1]) > gap)) --g;
+        tref = tg[g];
+    }
+
+    // generate row m (tile-local): returns u~, v~ and whether it is a reset row (+ its decay span)
+    double t_m1 = (n_first > 0) ? tg[-1] : tg[0];   // t of the previous row
+    auto gen = [&](const double tn, const int64_t g, double &ut, double &vt, bool &rst, double &de) {
+        const double dt = tn - t_m1;
+        t_m1 = tn;
+        rst = ((g & (block - 1)) == 0) || (cmax * dt > gap);
+        if (rst) {                                  // wave-uniform
+            de = (g > 0) ? (tn - tref) : 0.0;
+            tref = tn;
+            rho = 1.0;
+            irho = 1.0;
+        } else {
+            double ddt = dt - dt_ref;
+            if (!(fabs(ddt) * cmax < 1e-5)) {       // wave-uniform: new cadence -> new exp
+                p_ref = fm_exp(-cj * dt);
+                ip_ref = 1.0 / p_ref;
+                dt_ref = dt;
+                ddt = 0.0;
+            }
+            const double x = cj * ddt;              // exp(-x), exp(+x) to second order
+            const double hx = 0.5 * x;
+            rho *= p_ref * fma(x, hx - 1.0, 1.0);
+            irho *= ip_ref * fma(x, hx + 1.0, 1.0);
+            de = -1.0;
+        }
+        double si, co;
+        fm_sincos(dj * tn, &si, &co);               // ONE rounded multiply for the phase
+        const double own = is_sin ? si : co, oth = is_sin ? co : si;
+        ut = fma(uA, own, uB * oth) * rho;          // pad lanes: uA = uB = 0
+        vt = colok ? own * irho : 0.0;
+    };
+
+    // rows are generated one row ahead of their sweep; t, y, diag are prefetched two further
+    // rows ahead (the caller pads t, y, diag by two elements)
+    double t_n1 = tg[1], t_n2 = tg[2];
+    double y_n = yg[0], y_n1 = yg[1], y_n2 = yg[2];
+    double g_n = gg ? gg[0] : 0.0, g_n1 = gg ? gg[1] : 0.0, g_n2 = gg ? gg[2] : 0.0;
+    double ut, vt, de;
+    bool rst;
+    gen(tg[0], n_first, ut, vt, rst, de);
+
+    double ab[SW_AHEAD + 1][SW_BR], wb[SW_AHEAD + 1][SW_BR];
+    s_w[lane] = 0.0;
+    s_u[lane] = ut;
+    wave_lds_fence();
+    sweep_preload<ROWS>(ab, wb, s_u, s_w);
+
+    for (int64_t n = 0; n < N; ++n) {
+        const double a_n = g_n + diag_add, yy = y_n;
+        const double ut_c = ut, vt_c = vt;
+        if (rst) {                          // wave-uniform: fold the pending update, then decay
+            const double el = fm_exp(-cj * de);     // pad lanes: cj = 0 -> 1
+            s_e[lane] = el;
+            wave_lds_fence();
+            // the operand ring is reused (its preloaded rows are simply fetched again below):
+            // keeping a second ring alive across this branch costs 48 VGPRs on every row
+            sweep_preload<ROWS>(ab, wb, s_e, s_w);
+            (void)sweep_run<ROWS, true>(T, ab, wb, s_e, s_w, q, el);
+            sweep_preload<ROWS>(ab, wb, s_u, s_w);
+            q = 0.0;
+            zq = 0.0;
+        }
+        const double tmp = sweep_run<ROWS, false>(T, ab, wb, s_u, s_w, q, 0.0);
+        const double r = fl ? 0.0 : (vt_c - tmp);
+        // next row's operands: generated here, where the operand ring is dead (register budget)
+        gen(t_n1, n_first + n + 1, ut, vt, rst, de);
+        t_n1 = t_n2; y_n = y_n1; y_n1 = y_n2; g_n = g_n1; g_n1 = g_n2;
+        t_n2 = tg[n + 3];
+        y_n2 = yg[n + 3];
+        g_n2 = gg ? gg[n + 3] : 0.0;
+        wave_lds_fence();
+        s_w[lane] = r;
+        s_u[lane] = ut;
+        wave_lds_fence();
+        sweep_preload<ROWS>(ab, wb, s_u, s_w);
+        const double s1 = wave_sum(ut_c * tmp);     // u~ = 0 in lane 63
+        const double s2 = read_lane(tmp, 63);       // u~ . F~
+        const double dn = a_n - s1;
+        const double zn = yy - s2;
+        if (!(dn > 0.0)) {
+            const int64_t gf = n_first + n + 1;
+            fail = (int32_t)(gf > 0x7fffffff ? 0x7fffffff : gf);
+            break;
+        }
+        const double inv = 1.0 / dn;
+        zq = zn * inv;
+        q = fl ? zq : r * inv;
+        rprev = r;
+        if (lane == 0) { dg[n] = dn; zg[n] = zn; }
+    }
+    (void)rprev;
+    if (fail) {
+        if (lane == 0) info[b] = fail;
+        return;
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        const double v = fma(s_w[i], q, T[i]);
+        if (fl) Fg[i] = v; else Sg[i] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1115,6 +1306,35 @@ int gf_factor_scaled(int B, int64_t N, int64_t n_first, int W, int ld, const dou
         default: return set_err("gf_factor_scaled: internal dispatch error%s", "");
     }
     return check_launch("gf_factor_scaled");
+}
+
+#define GF_F3_CASE(R) case R: hipLaunchKernelGGL((k_factor3<R>), dim3(B), dim3(64), 0, st, N, n_first, Jr, Jc, block, gap, ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, S_state, F_state, info); break;
+
+int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int block,
+                     const double *ar, const double *cr, const double *ac,
+                     const double *bc, const double *cc, const double *dc,
+                     const double *diag_add, const double *cmax,
+                     const double *t, int64_t t_bs, const double *diag, int64_t diag_bs,
+                     const double *y, int64_t y_bs,
+                     double *d, double *z, double *S_state, double *F_state,
+                     int32_t *info, void *stream) {
+    const int W = Jr + 2 * Jc;
+    if (B < 1 || N < 1) return set_err("gf_loglike_fused: empty problem (B=%s%lld, N=%lld)", "", B, N);
+    if (W < 1 || W > 63) return set_err("gf_loglike_fused: width %s%lld unsupported (1..63)", "", W);
+    if (block < 1 || block > 64 || (block & (block - 1))) return set_err("gf_loglike_fused: block=%s%lld must be a power of two in 1..64", "", block);
+    if (n_first < 0 || (n_first % block) != 0) return set_err("gf_loglike_fused: n_first=%s%lld must be a non-negative multiple of block=%lld", "", n_first, block);
+    if (!t || !y || !d || !z || !S_state || !F_state || !info || !diag_add || !cmax)
+        return set_err("gf_loglike_fused: null pointer%s", "");
+    const double gap = (block > 1) ? SC_SPAN / (double)(block - 1) : 0.0;
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = (W + 3) / 4 * 4;
+    switch (rows) {
+        GF_F3_CASE(4) GF_F3_CASE(8) GF_F3_CASE(12) GF_F3_CASE(16) GF_F3_CASE(20) GF_F3_CASE(24)
+        GF_F3_CASE(28) GF_F3_CASE(32) GF_F3_CASE(36) GF_F3_CASE(40) GF_F3_CASE(44) GF_F3_CASE(48)
+        GF_F3_CASE(52) GF_F3_CASE(56) GF_F3_CASE(60) GF_F3_CASE(64)
+        default: return set_err("gf_loglike_fused: internal dispatch error%s", "");
+    }
+    return check_launch("gf_loglike_fused");
 }
 
 int64_t gf_reduce_work(int64_t N) { return 2 * (int64_t)red_groups(N); }

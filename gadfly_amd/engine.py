@@ -294,7 +294,7 @@ class StreamingBatch:
     """
 
     def __init__(self, coeffs_list, t, y, diag=None, tile_rows=8192, device=None,
-                 force_v1=False, overlap_build=False):
+                 force_v1=False, overlap_build=False, allow_fused=True):
         torch = _lib.require_device()
         self.torch = torch
         self.lib = _lib.load()
@@ -323,25 +323,33 @@ class StreamingBatch:
                 raise ValueError("dimension mismatch")
             return x
 
-        self.t = rows(t, "t")
-        self.N = int(self.t.shape[1])
+        def padded(x):
+            # spare elements at the very end: the sweeps prefetch up to three rows ahead
+            # unconditionally (a clamped index would defeat scalar-load code generation)
+            buf = torch.zeros((x.shape[0] * x.shape[1] + 4,), **f64)
+            buf[:x.numel()] = x.reshape(-1)
+            return buf[:x.numel()].view(x.shape[0], x.shape[1]), buf
+
+        t = rows(t, "t")
+        self.N = int(t.shape[1])
+        self._tmax = float(t.abs().max())
+        self.t, self._tpad = padded(t)
         y = rows(y, "y")
         if y.shape[1] != self.N:
             raise ValueError("dimension mismatch")
-        # one spare element at the very end: the sweep prefetches row n+1 unconditionally
-        ypad = torch.zeros((y.shape[0] * self.N + 2,), **f64)
-        ypad[:y.shape[0] * self.N] = y.reshape(-1)
-        self.y = ypad[:y.shape[0] * self.N].view(y.shape[0], self.N)
-        self._ypad = ypad
+        self.y, self._ypad = padded(y)
         self.diag = None
         if diag is not None:
-            self.diag = rows(diag, "diag")
-            if self.diag.shape[1] != self.N:
+            diag = rows(diag, "diag")
+            if diag.shape[1] != self.N:
                 raise ValueError("dimension mismatch")
+            self.diag, self._dpad = padded(diag)
         self._coeff_host = (real, comp, diag_add, c)
         B, ld = self.B, self.ld
         # W <= 64: block-scaled one-wave-per-problem kernels (k_build2 / k_factor2)
         self.scaled = bool(self.lib.gf_scaled_supported(self.W)) and not force_v1
+        # W <= 63 and phases inside the fused kernel's sincos range: nothing is materialised
+        self.allow_fused = bool(allow_fused) and self.scaled and self.W <= 63
         T = int(min(max(int(tile_rows), 1), self.N))
         if T < self.N:
             T = max(64, T // 64 * 64)         # tiles start on a reset row (any block <= 64)
@@ -355,10 +363,9 @@ class StreamingBatch:
             # one spare row: the sweep prefetches row n+1 unconditionally
             return torch.zeros((B * T + 2, ld), **f64)
 
-        self.bufs = [dict(a=torch.zeros((B * T + 2,), **f64), U=rows_buf(), V=rows_buf(),
-                          P=None if self.scaled else rows_buf(),
-                          de=torch.zeros((B * T + 2,), **f64))
-                     for _ in range(2 if (T < self.N and overlap_build) else 1)]
+        self._rows_buf = rows_buf
+        self._nbuf = 2 if (T < self.N and overlap_build) else 1
+        self.bufs = None                      # allocated on first use (not needed when fused)
         self.d = torch.empty((B, T), **f64)
         self.z = torch.empty((B, T), **f64)
         nS = 64 * 64 if self.scaled else int(self.lib.gf_state_size(self.W))
@@ -379,16 +386,30 @@ class StreamingBatch:
     def _bs(x):
         return 0 if x.shape[0] == 1 else x.stride(0)
 
+    def _alloc_bufs(self):
+        torch = self.torch
+        f64 = dict(dtype=torch.float64, device=self.device)
+        n = self.B * self.tile_rows + 2
+        self.bufs = [dict(a=torch.zeros((n,), **f64), U=self._rows_buf(), V=self._rows_buf(),
+                          P=None if self.scaled else self._rows_buf(),
+                          de=torch.zeros((n,), **f64))
+                     for _ in range(self._nbuf)]
+
+    def _fused_ok(self):
+        """Phases d*t must stay inside fm_sincos's Cody-Waite range (|x| < 1.6e6)."""
+        return self.allow_fused and self._pack[6] * self._tmax < 1.6e6
+
     def _make_pack(self, real, comp, diag_add, c):
         dev = self._dev
         cmax = np.max(c, axis=1)
+        dmax = float(np.max(np.abs(comp[3]))) if comp.size else 0.0
         # rows between forced resets of the scaled coordinates: largest power of two with
         # 1.5 * (block - 1) * cmax * cadence <= 28 (see k_build2)
         x = 1.5 * float(np.max(cmax)) * max(getattr(self, "_dt_med", 0.0), 0.0)
         block = 64
         while block > 1 and (block - 1) * x > 28.0:
             block //= 2
-        return dev(real), dev(comp), dev(diag_add), dev(c), dev(cmax), block
+        return dev(real), dev(comp), dev(diag_add), dev(c), dev(cmax), block, dmax
 
     def pack_coefficients(self, coeffs_list):
         Jr, Jc, real, comp, diag_add, c = _coeff_pack(coeffs_list)
@@ -402,7 +423,7 @@ class StreamingBatch:
     def _build_tile(self, k, buf, stream):
         n0 = k * self.tile_rows
         rows = min(self.tile_rows, self.N - n0)
-        real, comp, diag_add, _, cmax, block = self._pack
+        real, comp, diag_add, _, cmax, block, _ = self._pack
         p = _lib.ptr
         if self.scaled:
             st = self.lib.gf_build_scaled(
@@ -432,6 +453,10 @@ class StreamingBatch:
         self.S_state.zero_()
         self.F_state.zero_()
         self.info.zero_()
+        if self._fused_ok():
+            return self._log_likelihood_fused(main)
+        if self.bufs is None:
+            self._alloc_bufs()
         nb = len(self.bufs)
         built = [None] * nb          # event: tile in buffer i is built
         freed = [None] * nb          # event: sweep that used buffer i is done
@@ -473,6 +498,39 @@ class StreamingBatch:
                 with torch.cuda.stream(side):
                     self._build_tile(k + nb, buf, side)
                     built[i] = side.record_event()
+            st = lib.gf_reduce_tile(B, rows, p(self.d), p(self.z), p(self.work), p(self.acc),
+                                    1 if k == 0 else 0, main.cuda_stream)
+            _lib.check(st, "gf_reduce_tile")
+        out = torch.empty((B,), dtype=torch.float64, device=self.device)
+        st = lib.gf_loglike_finish(B, N, p(self.acc), p(self.info), p(out), None,
+                                   main.cuda_stream)
+        _lib.check(st, "gf_loglike_finish")
+        return out
+
+    def _log_likelihood_fused(self, main):
+        """gf_loglike_fused per tile: generator rows never leave the registers."""
+        torch = self.torch
+        lib, p = self.lib, _lib.ptr
+        T, N, B = self.tile_rows, self.N, self.B
+        real, comp, diag_add, _, cmax, block, _ = self._pack
+        for k in range((N + T - 1) // T):
+            n0 = k * T
+            rows = min(T, N - n0)
+            if self.time_factor:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+            st = lib.gf_loglike_fused(
+                B, rows, n0, self.Jr, self.Jc, block,
+                p(real[0]), p(real[1]), p(comp[0]), p(comp[1]), p(comp[2]), p(comp[3]),
+                p(diag_add), p(cmax), p(self.t), self._bs(self.t),
+                p(self.diag), 0 if self.diag is None else self._bs(self.diag),
+                p(self.y), self._bs(self.y), p(self.d), p(self.z),
+                p(self.S_state), p(self.F_state), p(self.info), main.cuda_stream)
+            _lib.check(st, "gf_loglike_fused")
+            if self.time_factor:
+                e1.record(main)
+                self.factor_events.append((e0, e1, rows))
             st = lib.gf_reduce_tile(B, rows, p(self.d), p(self.z), p(self.work), p(self.acc),
                                     1 if k == 0 else 0, main.cuda_stream)
             _lib.check(st, "gf_reduce_tile")

@@ -125,6 +125,24 @@ int gf_factor_scaled(int B, int64_t N, int64_t n_first, int W, int ld, const dou
                      int32_t *info, void *stream);
 
 /*
+ * Fully fused log-likelihood sweep (W <= 63): matrix build + factor + forward solve of N
+ * consecutive rows in one kernel, generator rows produced in registers (nothing but t, y, diag
+ * is read: 24 B/row).  Replaces gf_build_scaled + gf_factor_scaled on the log-likelihood path
+ * (gp.py:202 + gp.py:350) whenever max|d_c| * max|t| < 1.6e6 (the range of the kernel's
+ * Cody-Waite sincos; the caller checks).  Arguments as in gf_build_scaled / gf_factor_scaled;
+ * t, diag (NULL = 0), y are the WHOLE series (global row index, batch strides t_bs, diag_bs,
+ * y_bs) and must be readable three elements past row n_first + N - 1.
+ */
+int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int block,
+                     const double *ar, const double *cr, const double *ac,
+                     const double *bc, const double *cc, const double *dc,
+                     const double *diag_add, const double *cmax,
+                     const double *t, int64_t t_bs, const double *diag, int64_t diag_bs,
+                     const double *y, int64_t y_bs,
+                     double *d, double *z, double *S_state, double *F_state,
+                     int32_t *info, void *stream);
+
+/*
  * Log-likelihood reductions (fixed-shape tree, deterministic):
  *   gf_reduce_tile   : acc[b] = {sum log d, sum z^2/d} over N rows; init != 0 overwrites acc,
  *                      init == 0 adds to it (tiles in order).  z == NULL: second sum is 0.

@@ -231,17 +231,21 @@ STREAM_CASES = [
 
 
 @pytest.mark.parametrize("case", STREAM_CASES, ids=lambda c: f"{c[0]}-{c[1]}-T{c[2]}")
-@pytest.mark.parametrize("force_v1", [False, True], ids=["scaled", "v1"])
-def test_streaming_loglike(hip, case, force_v1):
-    """Tile-streamed evaluation (both kernel families) against the oracle, including the
+@pytest.mark.parametrize("mode", ["fused", "scaled", "v1"])
+def test_streaming_loglike(hip, case, mode):
+    """Tile-streamed evaluation (all three kernel families) against the oracle, including the
     state hand-off between tiles and the block-scaled coordinates' reset rows."""
+    force_v1, allow_fused = mode == "v1", mode == "fused"
     from gadfly_amd.engine import StreamingBatch
     from oracle import cref
     kind, kw, tile = case
     prob = _make((kind, kw))
     k, t, y = prob["kernel"], prob["t"], prob["y"]
     co = k.get_device_coefficients()
-    eng = StreamingBatch([co], t, y, diag=prob["diag_user"], tile_rows=tile, force_v1=force_v1)
+    eng = StreamingBatch([co], t, y, diag=prob["diag_user"], tile_rows=tile, force_v1=force_v1,
+                         allow_fused=allow_fused)
+    if mode == "fused":
+        assert eng._fused_ok() == (eng.W <= 63)
     ll = float(eng.log_likelihood()[0])
     ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y)
     assert info == 0
@@ -262,10 +266,11 @@ def test_streaming_fast_term_resets_every_row(hip):
     t, y = prob["t"], prob["y"]
     ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y)
     assert info == 0
-    for force_v1 in (False, True):
-        eng = StreamingBatch([co], t, y, diag=prob["diag_user"], tile_rows=512, force_v1=force_v1)
+    for force_v1, allow_fused in ((False, True), (False, False), (True, False)):
+        eng = StreamingBatch([co], t, y, diag=prob["diag_user"], tile_rows=512,
+                             force_v1=force_v1, allow_fused=allow_fused)
         ll = float(eng.log_likelihood()[0])
-        assert abs(ll - ref) <= RTOL_LL * abs(ref), (force_v1, ll, ref)
+        assert abs(ll - ref) <= RTOL_LL * abs(ref), (force_v1, allow_fused, ll, ref)
 
 
 def test_streaming_not_positive_definite(hip):
@@ -274,10 +279,41 @@ def test_streaming_not_positive_definite(hip):
     co = prob["kernel"].get_device_coefficients()
     bad = prob["diag_user"].copy()
     bad[137:] = -5.0 * prob["kernel"].get_value(np.zeros(1))[0]
-    for force_v1 in (False, True):
+    for force_v1, allow_fused in ((False, True), (False, False), (True, False)):
         eng = StreamingBatch([co, co], np.stack([prob["t"]] * 2), np.stack([prob["y"]] * 2),
                              diag=np.stack([prob["diag_user"], bad]), tile_rows=64,
-                             force_v1=force_v1)
+                             force_v1=force_v1, allow_fused=allow_fused)
         ll = eng.log_likelihood().cpu().numpy()
         assert np.isfinite(ll[0]) and ll[1] == -np.inf
         assert int(eng.info[0]) == 0 and int(eng.info[1]) == 138
+
+
+def test_streaming_large_phases_fall_back(hip):
+    """JD-like time axes push d*t beyond the fused kernel's sincos range: the engine must
+    fall back to the materialised path (OCML sincos) and still match."""
+    from gadfly_amd.engine import StreamingBatch
+    from oracle import cref
+    prob = util.solar_problem(20, 1200)
+    t = prob["t"] + 2.1e5                      # ~ JD 2,450,000 d in units of 1e6 s
+    co = prob["kernel"].get_device_coefficients()
+    eng = StreamingBatch([co], t, prob["y"], diag=prob["diag_user"], tile_rows=256)
+    assert not eng._fused_ok()
+    ll = float(eng.log_likelihood()[0])
+    ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], prob["y"])
+    assert info == 0 and abs(ll - ref) <= RTOL_LL * abs(ref), (ll, ref)
+
+
+def test_streaming_irregular_cadence_fused(hip):
+    """Irregular sampling: the fused kernel re-evaluates its cached exp(-c dt) on every row."""
+    from gadfly_amd.engine import StreamingBatch
+    from oracle import cref
+    rng = np.random.default_rng(11)
+    prob = util.solar_problem(12, 1500)
+    t = np.cumsum(rng.uniform(20e-6, 200e-6, len(prob["t"])))
+    co = prob["kernel"].get_device_coefficients()
+    ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], prob["y"])
+    for allow_fused in (True, False):
+        eng = StreamingBatch([co], t, prob["y"], diag=prob["diag_user"], tile_rows=320,
+                             allow_fused=allow_fused)
+        ll = float(eng.log_likelihood()[0])
+        assert info == 0 and abs(ll - ref) <= RTOL_LL * abs(ref), (allow_fused, ll, ref)
