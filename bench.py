@@ -163,10 +163,21 @@ def main():
         alg_bytes = 8.0 * fac_avg_rows * (3 * W + 4) * E
         alg_flops = 5.0 * W * W * fac_avg_rows * E
         ach = alg_bytes / (fac_avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+        # profiles/r01_traffic.json), scaled to this launch shape; null if not applicable
+        traffic = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tr.get("W") == W and getattr(eng, "_fused_ok", lambda: False)():
+                traffic = tr["hbm_bytes_per_row_eval"] * fac_avg_rows * E
+        except (OSError, ValueError, KeyError):
+            pass
         result["roofline"] = {
-            "bound": "hbm", "kernel": "k_factor (factor + fused forward solve)",
+            "bound": "hbm",
+            "kernel": "k_factor3 (fused build + factor + forward solve)"
+                      if getattr(eng, "_fused_ok", lambda: False)() else "k_factor",
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
             "kernel_ms": fac_avg_ms, "launches_timed": len(fac_ms),
             "rows_per_launch": fac_avg_rows,
             "algorithmic_bytes_per_launch": alg_bytes,
