@@ -87,6 +87,16 @@ __device__ __forceinline__ void wave_sum2(double &a, double &b) {
     b = read_lane(b, 63);
 }
 
+// max over the 64 lanes (same DPP tree), broadcast
+__device__ __forceinline__ double wave_max(double v) {
+    v = fmax(v, dpp_get<0xB1, 0xf>(v));
+    v = fmax(v, dpp_get<0x4E, 0xf>(v));
+    v = fmax(v, dpp_get<0x141, 0xf>(v));
+    v = fmax(v, dpp_get<0x140, 0xf>(v));
+    double r1 = read_lane(v, 15), r2 = read_lane(v, 31), r3 = read_lane(v, 47), r4 = read_lane(v, 63);
+    return fmax(fmax(r1, r2), fmax(r3, r4));
+}
+
 // Order LDS traffic of ONE wave: lane-form writes before uniform (broadcast) reads.
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS operations of one wave execute in issue order, so wavefront scope (a pure
@@ -693,76 +703,57 @@ k_factor2(const int64_t N, const int64_t n_first, const int ld, const int W,
 // exactly by exp(-x) = 1 - x + x^2/2 (|x| < 1e-5 => truncation < 2e-16).
 // Valid while |d t| < 1.6e6 (fm_sincos's Cody-Waite range): the caller checks and otherwise
 // uses the k_build2 + k_factor2 pair.
+//
+// Chunk mode (time-parallel evaluation of one series, see k_phi / k_combine): the grid is
+// (problem, chunk); block b handles rows [c L, (c+1) L) of problem b / nch with its own state
+// slot b, so the same kernel serves the nominal pass (zero start state, r~ rows stored for
+// k_phi) and the final pass (true start states from k_combine).
 // ------------------------------------------------------------------------------------
-template <int ROWS>
-__global__ void __launch_bounds__(64, 2)
-k_factor3(const int64_t N, const int64_t n_first, const int Jr, const int Jc,
-          const int block, const double gap,
-          const double *__restrict__ ar_, const double *__restrict__ cr_,
-          const double *__restrict__ ac_, const double *__restrict__ bc_,
-          const double *__restrict__ cc_, const double *__restrict__ dc_,
-          const double *__restrict__ diag_add_, const double *__restrict__ cmax_,
-          const double *__restrict__ t_, const int64_t t_bs,
-          const double *__restrict__ diag_, const int64_t diag_bs,
-          const double *__restrict__ y_, const int64_t y_bs,
-          double *__restrict__ d_, double *__restrict__ z_,
-          double *__restrict__ S_state, double *__restrict__ F_state,
-          int32_t *__restrict__ info) {
-    const int lane = threadIdx.x;
-    const int b = blockIdx.x;
-    if (info[b] != 0) return;
-    const int W = Jr + 2 * Jc;
-    const size_t pb = (size_t)b * N;
-    const double *__restrict__ tg = t_ + (size_t)b * t_bs + n_first;
-    const double *__restrict__ yg = y_ + (size_t)b * y_bs + n_first;
-    const double *__restrict__ gg = diag_ ? diag_ + (size_t)b * diag_bs + n_first : nullptr;
-    double *__restrict__ dg = d_ + pb;
-    double *__restrict__ zg = z_ + pb;
-    double *__restrict__ Sg = S_state + (size_t)b * (64 * 64) + (size_t)lane * 64;
-    double *__restrict__ Fg = F_state + (size_t)b * 64;
-    const double diag_add = diag_add_[b], cmax = cmax_[b];
-
+struct RowGen {
     // per-lane column constants
-    const bool colok = lane < W;
-    double cj = 0.0, dj = 0.0, uA = 0.0, uB = 0.0;
-    bool is_sin = false;
-    if (lane < Jr) {
-        cj = cr_[(size_t)b * Jr + lane];
-        uA = ar_[(size_t)b * Jr + lane];
-    } else if (colok) {
-        const int k = (lane - Jr) >> 1;
-        const size_t ck = (size_t)b * Jc + k;
-        is_sin = ((lane - Jr) & 1) != 0;
-        cj = cc_[ck];
-        dj = dc_[ck];
-        uA = ac_[ck];
-        uB = is_sin ? -bc_[ck] : bc_[ck];
-    }
-
-    __shared__ double s_w[64];      // r_{n-1}  (pending rank-1 update, row form)
-    __shared__ double s_u[64];      // u~_n
-    __shared__ double s_e[64];      // block decay E at reset rows
-    const bool fl = lane == 63;     // pad lane carrying the forward solve (W < 64)
-
-    double T[ROWS];
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) T[i] = fl ? Fg[i] : Sg[i];
-    double rprev = 0.0, q = 0.0, zq = 0.0;
-    int32_t fail = 0;
-
+    double cj, dj, uA, uB, cmax, gap;
+    bool is_sin, colok;
+    int block;
     // running scale state
-    double rho = 1.0, irho = 1.0, p_ref = 1.0, ip_ref = 1.0, dt_ref = -1.0;
-    // reference time of the block that precedes the tile's first row (for its decay)
-    double tref = tg[0];
-    if (n_first > 0) {
-        int64_t g = -1;                             // tile-local index of global row n_first-1
-        while (!(((n_first + g) & (block - 1)) == 0 || cmax * (tg[g] - tg[g - 1]) > gap)) --g;
-        tref = tg[g];
+    double rho, irho, p_ref, ip_ref, dt_ref, tref, t_m1;
+
+    __device__ __forceinline__ void init(int lane, int b, int Jr, int Jc, int block_, double gap_,
+                                         const double *ar_, const double *cr_, const double *ac_,
+                                         const double *bc_, const double *cc_, const double *dc_,
+                                         const double *cmax_, const double *tg, int64_t n_first) {
+        const int W = Jr + 2 * Jc;
+        colok = lane < W;
+        cj = 0.0; dj = 0.0; uA = 0.0; uB = 0.0; is_sin = false;
+        if (lane < Jr) {
+            cj = cr_[(size_t)b * Jr + lane];
+            uA = ar_[(size_t)b * Jr + lane];
+        } else if (colok) {
+            const int k = (lane - Jr) >> 1;
+            const size_t ck = (size_t)b * Jc + k;
+            is_sin = ((lane - Jr) & 1) != 0;
+            cj = cc_[ck];
+            dj = dc_[ck];
+            uA = ac_[ck];
+            uB = is_sin ? -bc_[ck] : bc_[ck];
+        }
+        cmax = cmax_[b];
+        block = block_;
+        gap = gap_;
+        rho = 1.0; irho = 1.0; p_ref = 1.0; ip_ref = 1.0; dt_ref = -1.0;
+        // reference time of the block that precedes the first row (for its decay); tg points
+        // at the first row, earlier rows are at negative indices
+        tref = tg[0];
+        if (n_first > 0) {
+            int64_t g = -1;
+            while (!(((n_first + g) & (block - 1)) == 0 || cmax * (tg[g] - tg[g - 1]) > gap)) --g;
+            tref = tg[g];
+        }
+        t_m1 = (n_first > 0) ? tg[-1] : tg[0];
     }
 
-    // generate row m (tile-local): returns u~, v~ and whether it is a reset row (+ its decay span)
-    double t_m1 = (n_first > 0) ? tg[-1] : tg[0];   // t of the previous row
-    auto gen = [&](const double tn, const int64_t g, double &ut, double &vt, bool &rst, double &de) {
+    // generate global row g at time tn: u~, v~, reset flag and (for reset rows) the decay span
+    __device__ __forceinline__ void next(const double tn, const int64_t g, double &ut, double &vt,
+                                         bool &rst, double &de) {
         const double dt = tn - t_m1;
         t_m1 = tn;
         rst = ((g & (block - 1)) == 0) || (cmax * dt > gap);
@@ -790,16 +781,64 @@ k_factor3(const int64_t N, const int64_t n_first, const int Jr, const int Jc,
         const double own = is_sin ? si : co, oth = is_sin ? co : si;
         ut = fma(uA, own, uB * oth) * rho;          // pad lanes: uA = uB = 0
         vt = colok ? own * irho : 0.0;
-    };
+    }
+};
+
+template <int ROWS>
+__global__ void __launch_bounds__(64, 2)
+k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int nch,
+          const int Jr, const int Jc, const int block, const double gap,
+          const double *__restrict__ ar_, const double *__restrict__ cr_,
+          const double *__restrict__ ac_, const double *__restrict__ bc_,
+          const double *__restrict__ cc_, const double *__restrict__ dc_,
+          const double *__restrict__ diag_add_, const double *__restrict__ cmax_,
+          const double *__restrict__ t_, const int64_t t_bs,
+          const double *__restrict__ diag_, const int64_t diag_bs,
+          const double *__restrict__ y_, const int64_t y_bs,
+          double *__restrict__ d_, double *__restrict__ z_, double *__restrict__ r_out,
+          double *__restrict__ S_state, double *__restrict__ F_state,
+          int32_t *__restrict__ info) {
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;                       // state slot = problem * nch + chunk
+    if (info[b] != 0) return;
+    const int pr = b / nch, ch = b - pr * nch;
+    const int64_t c0 = (int64_t)ch * chunk_len;     // first row of the chunk within this call
+    const int64_t rows = (N - c0 < chunk_len) ? (N - c0) : chunk_len;
+    const int64_t g0 = n_first + c0;                // global index of the chunk's first row
+    const size_t pb = (size_t)pr * N + c0;
+    const double *__restrict__ tg = t_ + (size_t)pr * t_bs + g0;
+    const double *__restrict__ yg = y_ + (size_t)pr * y_bs + g0;
+    const double *__restrict__ gg = diag_ ? diag_ + (size_t)pr * diag_bs + g0 : nullptr;
+    double *__restrict__ dg = d_ + pb;
+    double *__restrict__ zg = z_ + pb;
+    double *__restrict__ rg = r_out ? r_out + pb * 64 + lane : nullptr;
+    double *__restrict__ Sg = S_state + (size_t)b * (64 * 64) + (size_t)lane * 64;
+    double *__restrict__ Fg = F_state + (size_t)b * 64;
+    const double diag_add = diag_add_[pr];
+
+    RowGen G;
+    G.init(lane, pr, Jr, Jc, block, gap, ar_, cr_, ac_, bc_, cc_, dc_, cmax_, tg, g0);
+    const double cj = G.cj;
+
+    __shared__ double s_w[64];      // r_{n-1}  (pending rank-1 update, row form)
+    __shared__ double s_u[64];      // u~_n
+    __shared__ double s_e[64];      // block decay E at reset rows
+    const bool fl = lane == 63;     // pad lane carrying the forward solve (W < 64)
+
+    double T[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) T[i] = fl ? Fg[i] : Sg[i];
+    double q = 0.0, zq = 0.0;
+    int32_t fail = 0;
 
     // rows are generated one row ahead of their sweep; t, y, diag are prefetched two further
-    // rows ahead (the caller pads t, y, diag by two elements)
+    // rows ahead (the caller pads t, y, diag by three elements)
     double t_n1 = tg[1], t_n2 = tg[2];
     double y_n = yg[0], y_n1 = yg[1], y_n2 = yg[2];
     double g_n = gg ? gg[0] : 0.0, g_n1 = gg ? gg[1] : 0.0, g_n2 = gg ? gg[2] : 0.0;
     double ut, vt, de;
     bool rst;
-    gen(tg[0], n_first, ut, vt, rst, de);
+    G.next(tg[0], g0, ut, vt, rst, de);
 
     double ab[SW_AHEAD + 1][SW_BR], wb[SW_AHEAD + 1][SW_BR];
     s_w[lane] = 0.0;
@@ -807,7 +846,7 @@ k_factor3(const int64_t N, const int64_t n_first, const int Jr, const int Jc,
     wave_lds_fence();
     sweep_preload<ROWS>(ab, wb, s_u, s_w);
 
-    for (int64_t n = 0; n < N; ++n) {
+    for (int64_t n = 0; n < rows; ++n) {
         const double a_n = g_n + diag_add, yy = y_n;
         const double ut_c = ut, vt_c = vt;
         if (rst) {                          // wave-uniform: fold the pending update, then decay
@@ -825,7 +864,7 @@ k_factor3(const int64_t N, const int64_t n_first, const int Jr, const int Jc,
         const double tmp = sweep_run<ROWS, false>(T, ab, wb, s_u, s_w, q, 0.0);
         const double r = fl ? 0.0 : (vt_c - tmp);
         // next row's operands: generated here, where the operand ring is dead (register budget)
-        gen(t_n1, n_first + n + 1, ut, vt, rst, de);
+        G.next(t_n1, g0 + n + 1, ut, vt, rst, de);
         t_n1 = t_n2; y_n = y_n1; y_n1 = y_n2; g_n = g_n1; g_n1 = g_n2;
         t_n2 = tg[n + 3];
         y_n2 = yg[n + 3];
@@ -840,17 +879,16 @@ k_factor3(const int64_t N, const int64_t n_first, const int Jr, const int Jc,
         const double dn = a_n - s1;
         const double zn = yy - s2;
         if (!(dn > 0.0)) {
-            const int64_t gf = n_first + n + 1;
+            const int64_t gf = g0 + n + 1;
             fail = (int32_t)(gf > 0x7fffffff ? 0x7fffffff : gf);
             break;
         }
         const double inv = 1.0 / dn;
         zq = zn * inv;
         q = fl ? zq : r * inv;
-        rprev = r;
+        if (rg) rg[(size_t)n * 64] = r;             // r~ rows for k_phi (chunk mode)
         if (lane == 0) { dg[n] = dn; zg[n] = zn; }
     }
-    (void)rprev;
     if (fail) {
         if (lane == 0) info[b] = fail;
         return;
@@ -860,6 +898,403 @@ k_factor3(const int64_t N, const int64_t n_first, const int Jr, const int Jc,
     for (int i = 0; i < ROWS; ++i) {
         const double v = fma(s_w[i], q, T[i]);
         if (fl) Fg[i] = v; else Sg[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Exact time-parallel evaluation of ONE series (Lainiotis-type partitioning; the numpy
+// derivation and its verification against the sequential recurrence are in DESIGN.md 4.3).
+// The series is cut into nch chunks.  With X = S (+ pending update) handed from chunk to chunk:
+//   nominal pass  (k_factor3, zero start)      : Xbar_end, Ybar_end, dbar, zbar, rbar per chunk
+//   k_phi         : closed-loop transition      Phi <- (I - w~ u~^T) Phi,  h_n = Phi^T u~_n
+//   k_gram        : G = sum h h^T / dbar ,  m = sum h zbar / dbar
+//   k_combine     : X+ = Xbar_end + Phi K Phi^T ,  K = (I - X G)^-1 X          (sequential in c)
+//                   Y+ = Ybar_end + Phi (I - X G)^-1 (Y - X m)
+//   final pass    (k_factor3 from the true X, Y): d, z  -- identical to the sequential run
+// k_phi is the same register-resident sweep as the factor: Phi_i += (r~_{n-1,i}) * (-h_{n-1}/d),
+// h_n = sum_i u~_{n,i} Phi_i, with no reduction and no division on its chain.
+// ------------------------------------------------------------------------------------
+template <int ROWS>
+__global__ void __launch_bounds__(64, 2)
+k_phi(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int nch,
+      const int Jr, const int Jc, const int block, const double gap,
+      const double *__restrict__ ar_, const double *__restrict__ cr_,
+      const double *__restrict__ ac_, const double *__restrict__ bc_,
+      const double *__restrict__ cc_, const double *__restrict__ dc_,
+      const double *__restrict__ cmax_,
+      const double *__restrict__ t_, const int64_t t_bs,
+      const double *__restrict__ dbar_, const double *__restrict__ rbar_,
+      double *__restrict__ h_out, double *__restrict__ Phi_out) {
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    const int pr = b / nch, ch = b - pr * nch;
+    const int64_t c0 = (int64_t)ch * chunk_len;
+    const int64_t rows = (N - c0 < chunk_len) ? (N - c0) : chunk_len;
+    const int64_t g0 = n_first + c0;
+    const size_t pb = (size_t)pr * N + c0;
+    const double *__restrict__ tg = t_ + (size_t)pr * t_bs + g0;
+    const double *__restrict__ dg = dbar_ + pb;
+    const double *__restrict__ rg = rbar_ + pb * 64 + lane;
+    double *__restrict__ hg = h_out + pb * 64 + lane;
+    double *__restrict__ Pg = Phi_out + (size_t)b * (64 * 64) + (size_t)lane * 64;
+
+    RowGen G;
+    G.init(lane, pr, Jr, Jc, block, gap, ar_, cr_, ac_, bc_, cc_, dc_, cmax_, tg, g0);
+    const double cj = G.cj;
+
+    __shared__ double s_w[64], s_u[64], s_e[64];
+    double T[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) T[i] = (i == lane) ? 1.0 : 0.0;      // Phi = I
+    double q = 0.0;
+
+    double t_n1 = tg[1], t_n2 = tg[2];
+    double d_n = dg[0], d_n1 = dg[1];               // dbar, rbar are padded by the caller
+    double r_n = rg[0], r_n1 = rg[64];
+    double ut, vt, de;
+    bool rst;
+    G.next(tg[0], g0, ut, vt, rst, de);
+
+    double ab[SW_AHEAD + 1][SW_BR], wb[SW_AHEAD + 1][SW_BR];
+    s_w[lane] = 0.0;
+    s_u[lane] = ut;
+    wave_lds_fence();
+    sweep_preload<ROWS>(ab, wb, s_u, s_w);
+
+    for (int64_t n = 0; n < rows; ++n) {
+        const double dcur = d_n, rcur = r_n;
+        if (rst) {                          // Phi <- E (Phi + pending): row scaling only
+            const double el = fm_exp(-cj * de);
+            s_e[lane] = el;
+            wave_lds_fence();
+            sweep_preload<ROWS>(ab, wb, s_e, s_w);
+            (void)sweep_run<ROWS, true>(T, ab, wb, s_e, s_w, q, 1.0);
+            sweep_preload<ROWS>(ab, wb, s_u, s_w);
+            q = 0.0;
+        }
+        const double h = sweep_run<ROWS, false>(T, ab, wb, s_u, s_w, q, 0.0);
+        hg[(size_t)n * 64] = h;
+        G.next(t_n1, g0 + n + 1, ut, vt, rst, de);
+        t_n1 = t_n2;
+        t_n2 = tg[n + 3];
+        d_n = d_n1; r_n = r_n1;
+        d_n1 = dg[n + 2];
+        r_n1 = rg[(size_t)(n + 2) * 64];
+        wave_lds_fence();
+        s_w[lane] = rcur;                   // pending: Phi_i -= (r_i / d) h_j
+        s_u[lane] = ut;
+        wave_lds_fence();
+        sweep_preload<ROWS>(ab, wb, s_u, s_w);
+        q = -h / dcur;
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) Pg[i] = fma(s_w[i], q, T[i]);
+#pragma unroll
+    for (int i = ROWS; i < 64; ++i) Pg[i] = 0.0;
+}
+
+// G[i][j] = sum_n h_n[i] h_n[j] / dbar_n ;  m[i] = sum_n h_n[i] zbar_n / dbar_n   per chunk.
+// One workgroup of 256 threads per (problem, chunk); thread (ty, tx) owns a 4x4 block of G.
+// Output layout [j][i] (column-major, = the lane-major layout of the sweep states).
+__global__ void __launch_bounds__(256)
+k_gram(const int64_t N, const int64_t chunk_len, const int nch,
+       const double *__restrict__ h_, const double *__restrict__ dbar_,
+       const double *__restrict__ zbar_, double *__restrict__ G_out, double *__restrict__ m_out) {
+    constexpr int TR = 32;
+    const int b = blockIdx.x;
+    const int pr = b / nch, ch = b - pr * nch;
+    const int64_t c0 = (int64_t)ch * chunk_len;
+    const int64_t rows = (N - c0 < chunk_len) ? (N - c0) : chunk_len;
+    const size_t pb = (size_t)pr * N + c0;
+    const double *__restrict__ hg = h_ + pb * 64;
+    const double *__restrict__ dg = dbar_ + pb;
+    const double *__restrict__ zg = zbar_ + pb;
+    __shared__ double sh[TR][64], shd[TR][64], sz[TR];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    double acc[4][4] = {};
+    double macc[4] = {};
+    for (int64_t r0 = 0; r0 < rows; r0 += TR) {
+        const int nr = (int)((rows - r0 < TR) ? (rows - r0) : TR);
+        for (int e = tid; e < TR * 64; e += 256) {
+            const int r = e >> 6, j = e & 63;
+            double hv = 0.0, dinv = 0.0;
+            if (r < nr) { hv = hg[(size_t)(r0 + r) * 64 + j]; dinv = 1.0 / dg[r0 + r]; }
+            sh[r][j] = hv;
+            shd[r][j] = hv * dinv;
+            if (j == 0) sz[r] = (r < nr) ? zg[r0 + r] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int r = 0; r < TR; ++r) {
+            double hi[4], hj[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { hi[a] = sh[r][4 * ty + a]; hj[a] = shd[r][4 * tx + a]; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[a][c] = fma(hi[a], hj[c], acc[a][c]);
+            if (tx == 0) {
+                const double zr = sz[r];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) macc[a] = fma(shd[r][4 * ty + a], zr, macc[a]);
+            }
+        }
+        __syncthreads();
+    }
+    double *Gg = G_out + (size_t)b * (64 * 64);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Gg[(size_t)(4 * tx + c) * 64 + 4 * ty + a] = acc[a][c];
+    if (tx == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) m_out[(size_t)b * 64 + 4 * ty + a] = macc[a];
+    }
+}
+
+// Sequential LFT combine over the chunks of each problem (one workgroup per problem).
+// All 64x64 matrices are stored [j][i] (column-major); pad rows/columns are zero.
+//   A = I - X G ;  [K | v] = A^-1 [X | Y - X m]  (Gauss-Jordan, partial pivoting, in LDS)
+//   X+ = Xbar_c + Phi_c K Phi_c^T ;  Y+ = Ybar_c + Phi_c v
+// S_state/F_state slot c holds (Xbar_end, Ybar_end) of chunk c on entry and the TRUE start
+// state of chunk c on exit (slot 0 <- 0).
+__global__ void __launch_bounds__(256)
+k_combine(const int nch, const double *__restrict__ Phi_, const double *__restrict__ G_,
+          const double *__restrict__ m_, double *__restrict__ S_state,
+          double *__restrict__ F_state) {
+    constexpr int LD = 65, LA = 130;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *Xs = lds;                       // [64][LD]   X  (row i, col j) at Xs[i*LD + j]
+    double *Au = Xs + 64 * LD;              // [64][LA]   [A | X | rhs]
+    double *Bs = Au + 64 * LA;              // [64][LD]   temp
+    double *Ys = Bs + 64 * LD;              // [64]
+    double *vs = Ys + 64;                   // [64]
+    __shared__ int s_piv;
+    const int pr = blockIdx.x;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    for (int e = tid; e < 64 * LD; e += 256) Xs[e] = 0.0;
+    if (tid < 64) Ys[tid] = 0.0;
+    __syncthreads();
+
+    for (int c = 0; c < nch; ++c) {
+        const size_t slot = (size_t)pr * nch + c;
+        double *Sg = S_state + slot * 4096;
+        double *Fg = F_state + slot * 64;
+        const double *Pg = Phi_ + slot * 4096;
+        const double *Gg = G_ + slot * 4096;
+        const double *mg = m_ + slot * 64;
+        // this chunk's nominal end state (needed after the solve) -> registers, through LDS so
+        // that the global reads stay coalesced
+        double xbar[4][4], ybar = 0.0;
+        _Pragma("unroll 16")
+        for (int e = tid; e < 4096; e += 256) { const int j = e >> 6, i = e & 63; Bs[i * LD + j] = Sg[e]; }
+        if (tid < 64) { ybar = Fg[tid]; vs[tid] = mg[tid]; }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) xbar[a][cc] = Bs[(4 * ty + a) * LD + 4 * tx + cc];
+        __syncthreads();
+        // publish the TRUE start state of chunk c
+        _Pragma("unroll 16")
+        for (int e = tid; e < 4096; e += 256) { const int j = e >> 6, i = e & 63; Sg[e] = Xs[i * LD + j]; }
+        if (tid < 64) Fg[tid] = Ys[tid];
+        if (c == nch - 1) break;
+        // Bs <- G ;  A = I - X G  (4x4 block per thread) ; rhs columns
+        _Pragma("unroll 16")
+        for (int e = tid; e < 4096; e += 256) { const int j = e >> 6, i = e & 63; Bs[i * LD + j] = Gg[e]; }
+        __syncthreads();
+        {
+            double acc[4][4] = {};
+            for (int k = 0; k < 64; ++k) {
+                double xa[4], gb[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { xa[a] = Xs[(4 * ty + a) * LD + k]; gb[a] = Bs[k * LD + 4 * tx + a]; }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) acc[a][cc] = fma(xa[a], gb[cc], acc[a][cc]);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int i = 4 * ty + a, j = 4 * tx + cc;
+                    Au[i * LA + j] = ((i == j) ? 1.0 : 0.0) - acc[a][cc];
+                    Au[i * LA + 64 + j] = Xs[i * LD + j];
+                }
+        }
+        if (tid < 64) {                     // rhs = Y - X m
+            double sacc = Ys[tid];
+            for (int k = 0; k < 64; ++k) sacc = fma(-Xs[tid * LD + k], vs[k], sacc);
+            Au[tid * LA + 128] = sacc;
+        }
+        __syncthreads();
+        // Gauss-Jordan with IMPLICIT partial pivoting on the 64 x 129 augmented system, held in
+        // registers: thread (rgp, jj) owns rows rgp*8..+7 x columns {jj, jj+32, jj+64, jj+96}
+        // (+ column 128 for jj == 0).  Per step only the pivot column (for the search) and the
+        // pivot row travel through LDS; rows are never swapped or normalised, eliminated
+        // columns are never revisited.  Every wave repeats the 64-candidate DPP arg-max, so a
+        // step needs two barriers.
+        {
+            const int jj = tid & 31, rgp = tid >> 5, lane = tid & 63;
+            double *pcol = Bs;                  // [64]  candidate column
+            double *prow = Bs + 64;             // [129] pivot row
+            double *pinvr = Bs + 64 + 136;      // [64]  1 / pivot of the row
+            int *rowvar = reinterpret_cast<int *>(Bs + 64 + 136 + 64);     // [64] variable solved by row
+            double R[8][5];
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int cc = 0; cc < 5; ++cc) {
+                    const int j = (cc < 4) ? (jj + 32 * cc) : 128;
+                    R[a][cc] = (cc < 4 || jj == 0) ? Au[(rgp * 8 + a) * LA + j] : 0.0;
+                }
+            bool used = false;                  // lane-form: row `lane` already served as a pivot
+            __syncthreads();
+            if (jj == 0) {                      // column 0 -> pcol
+#pragma unroll
+                for (int a = 0; a < 8; ++a) pcol[rgp * 8 + a] = R[a][0];
+            }
+            __syncthreads();
+            for (int k = 0; k < 64; ++k) {
+                // arg-max over unused rows (every wave, identical result)
+                const double cand = used ? -1.0 : fabs(pcol[lane]);
+                const double vm = wave_max(cand);
+                const unsigned long long hit = __ballot(cand == vm);
+                const int pv = (int)__ffsll((long long)hit) - 1;
+                if (lane == pv) used = true;
+                // owners of row pv publish it
+                if ((pv >> 3) == rgp) {
+                    const int a = pv & 7;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int a2 = 0; a2 < 8; ++a2) v = (a2 == a) ? R[a2][cc] : v;
+                        prow[jj + 32 * cc] = v;
+                    }
+                    if (jj == 0) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int a2 = 0; a2 < 8; ++a2) v = (a2 == a) ? R[a2][4] : v;
+                        prow[128] = v;
+                    }
+                }
+                if (tid == 0) rowvar[pv] = k;
+                __syncthreads();
+                const double pinv = 1.0 / prow[k];
+                if (tid == 0) pinvr[pv] = pinv;
+                double fr[8];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    const int i = rgp * 8 + a;
+                    fr[a] = (i == pv) ? 0.0 : pcol[i] * pinv;
+                }
+                const int kn = k + 1;           // next pivot column lives in column slot kn>>5
+#pragma unroll
+                for (int cc = 0; cc < 5; ++cc) {
+                    const int j = (cc < 4) ? (jj + 32 * cc) : 128;
+                    if (j > k && (cc < 4 || jj == 0)) {
+                        const double pk = prow[j];
+#pragma unroll
+                        for (int a = 0; a < 8; ++a) R[a][cc] = fma(-fr[a], pk, R[a][cc]);
+                    }
+                }
+                __syncthreads();                // everyone is done with pcol / prow
+                if (kn < 64 && jj == (kn & 31)) {
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int cc = 0; cc < 2; ++cc) v = (cc == (kn >> 5)) ? R[a][cc] : v;
+                        pcol[rgp * 8 + a] = v;
+                    }
+                }
+                __syncthreads();
+            }
+            // solution rows: variable rowvar[i] = (right part of row i) / pivot(i)
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const int i = rgp * 8 + a;
+                const int kv = rowvar[i];
+                const double sc = pinvr[i];
+                Au[kv * LA + 64 + jj] = R[a][2] * sc;
+                Au[kv * LA + 96 + jj] = R[a][3] * sc;
+                if (jj == 0) Au[kv * LA + 128] = R[a][4] * sc;
+            }
+            __syncthreads();
+        }
+        // K = Au[:, 64:128] (symmetrised), v = Au[:, 128];  Bs <- Phi ; Xs <- Z = Phi K
+        _Pragma("unroll 16")
+        for (int e = tid; e < 4096; e += 256) { const int j = e >> 6, i = e & 63; Bs[i * LD + j] = Pg[e]; }
+        if (tid < 64) vs[tid] = Au[tid * LA + 128];
+        __syncthreads();
+        {
+            double acc[4][4] = {};
+            for (int k = 0; k < 64; ++k) {
+                double pa[4], kb[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    pa[a] = Bs[(4 * ty + a) * LD + k];
+                    kb[a] = 0.5 * (Au[k * LA + 64 + 4 * tx + a] + Au[(4 * tx + a) * LA + 64 + k]);
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) acc[a][cc] = fma(pa[a], kb[cc], acc[a][cc]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) Xs[(4 * ty + a) * LD + 4 * tx + cc] = acc[a][cc];
+        }
+        double ynew = 0.0;
+        if (tid < 64) {                     // Y+ = Ybar + Phi v
+            ynew = ybar;
+            for (int k = 0; k < 64; ++k) ynew = fma(Bs[tid * LD + k], vs[k], ynew);
+        }
+        __syncthreads();
+        {                                   // X+ = Xbar + Z Phi^T
+            double acc[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) acc[a][cc] = xbar[a][cc];
+            for (int k = 0; k < 64; ++k) {
+                double za[4], pb2[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { za[a] = Xs[(4 * ty + a) * LD + k]; pb2[a] = Bs[(4 * tx + a) * LD + k]; }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) acc[a][cc] = fma(za[a], pb2[cc], acc[a][cc]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) Xs[(4 * ty + a) * LD + 4 * tx + cc] = acc[a][cc];
+        }
+        if (tid < 64) Ys[tid] = ynew;
+        __syncthreads();
+        // symmetrise X (kills rounding asymmetry of the two-sided product)
+        {
+            double sym[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+                    sym[a][cc] = 0.5 * (Xs[(4 * ty + a) * LD + 4 * tx + cc] + Xs[(4 * tx + cc) * LD + 4 * ty + a]);
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) Xs[(4 * ty + a) * LD + 4 * tx + cc] = sym[a][cc];
+        }
+        __syncthreads();
     }
 }
 
@@ -1308,7 +1743,38 @@ int gf_factor_scaled(int B, int64_t N, int64_t n_first, int W, int ld, const dou
     return check_launch("gf_factor_scaled");
 }
 
-#define GF_F3_CASE(R) case R: hipLaunchKernelGGL((k_factor3<R>), dim3(B), dim3(64), 0, st, N, n_first, Jr, Jc, block, gap, ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, S_state, F_state, info); break;
+#define GF_F3_CASE(R) case R: hipLaunchKernelGGL((k_factor3<R>), dim3(B * nch), dim3(64), 0, st, N, n_first, chunk_len, nch, Jr, Jc, block, gap, ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out, S_state, F_state, info); break;
+
+static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int64_t chunk_len, int nch,
+                        int Jr, int Jc, int block,
+                        const double *ar, const double *cr, const double *ac,
+                        const double *bc, const double *cc, const double *dc,
+                        const double *diag_add, const double *cmax,
+                        const double *t, int64_t t_bs, const double *diag, int64_t diag_bs,
+                        const double *y, int64_t y_bs,
+                        double *d, double *z, double *r_out, double *S_state, double *F_state,
+                        int32_t *info, void *stream) {
+    const int W = Jr + 2 * Jc;
+    if (B < 1 || N < 1) return set_err("%s: empty problem (N=%lld)", who, N);
+    if (W < 1 || W > 63) return set_err("%s: width %lld unsupported (1..63)", who, W);
+    if (block < 1 || block > 64 || (block & (block - 1))) return set_err("%s: block=%lld must be a power of two in 1..64", who, block);
+    if (n_first < 0 || (n_first % block) != 0) return set_err("%s: n_first=%lld must be a non-negative multiple of block=%lld", who, n_first, block);
+    if (nch < 1 || chunk_len < 1 || (nch > 1 && (chunk_len % block) != 0) || (int64_t)nch * chunk_len < N
+        || (int64_t)(nch - 1) * chunk_len >= N)
+        return set_err("%s: bad chunking (chunk_len=%lld, nch=%lld)", who, chunk_len, nch);
+    if (!t || !y || !d || !z || !S_state || !F_state || !info || !diag_add || !cmax)
+        return set_err("%s: null pointer%s", who);
+    const double gap = (block > 1) ? SC_SPAN / (double)(block - 1) : 0.0;
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = (W + 3) / 4 * 4;
+    switch (rows) {
+        GF_F3_CASE(4) GF_F3_CASE(8) GF_F3_CASE(12) GF_F3_CASE(16) GF_F3_CASE(20) GF_F3_CASE(24)
+        GF_F3_CASE(28) GF_F3_CASE(32) GF_F3_CASE(36) GF_F3_CASE(40) GF_F3_CASE(44) GF_F3_CASE(48)
+        GF_F3_CASE(52) GF_F3_CASE(56) GF_F3_CASE(60) GF_F3_CASE(64)
+        default: return set_err("%s: internal dispatch error", who);
+    }
+    return check_launch(who);
+}
 
 int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int block,
                      const double *ar, const double *cr, const double *ac,
@@ -1318,23 +1784,67 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
                      const double *y, int64_t y_bs,
                      double *d, double *z, double *S_state, double *F_state,
                      int32_t *info, void *stream) {
+    return fused_launch("gf_loglike_fused", B, N, n_first, N, 1, Jr, Jc, block, ar, cr, ac, bc, cc, dc,
+                        diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, nullptr,
+                        S_state, F_state, info, stream);
+}
+
+int gf_chunk_sweep(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc, int block,
+                   const double *ar, const double *cr, const double *ac,
+                   const double *bc, const double *cc, const double *dc,
+                   const double *diag_add, const double *cmax,
+                   const double *t, int64_t t_bs, const double *diag, int64_t diag_bs,
+                   const double *y, int64_t y_bs,
+                   double *d, double *z, double *r_out, double *S_state, double *F_state,
+                   int32_t *info, void *stream) {
+    return fused_launch("gf_chunk_sweep", B, N, 0, chunk_len, nch, Jr, Jc, block, ar, cr, ac, bc, cc, dc,
+                        diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out,
+                        S_state, F_state, info, stream);
+}
+
+#define GF_PHI_CASE(R) case R: hipLaunchKernelGGL((k_phi<R>), dim3(B * nch), dim3(64), 0, st, N, (int64_t)0, chunk_len, nch, Jr, Jc, block, gap, ar, cr, ac, bc, cc, dc, cmax, t, t_bs, dbar, rbar, h_out, Phi_out); break;
+
+int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc, int block,
+                        const double *ar, const double *cr, const double *ac,
+                        const double *bc, const double *cc, const double *dc,
+                        const double *cmax, const double *t, int64_t t_bs,
+                        const double *dbar, const double *zbar, const double *rbar,
+                        double *h_out, double *Phi_out, double *G_out, double *m_out,
+                        void *stream) {
     const int W = Jr + 2 * Jc;
-    if (B < 1 || N < 1) return set_err("gf_loglike_fused: empty problem (B=%s%lld, N=%lld)", "", B, N);
-    if (W < 1 || W > 63) return set_err("gf_loglike_fused: width %s%lld unsupported (1..63)", "", W);
-    if (block < 1 || block > 64 || (block & (block - 1))) return set_err("gf_loglike_fused: block=%s%lld must be a power of two in 1..64", "", block);
-    if (n_first < 0 || (n_first % block) != 0) return set_err("gf_loglike_fused: n_first=%s%lld must be a non-negative multiple of block=%lld", "", n_first, block);
-    if (!t || !y || !d || !z || !S_state || !F_state || !info || !diag_add || !cmax)
-        return set_err("gf_loglike_fused: null pointer%s", "");
+    if (B < 1 || N < 1) return set_err("gf_chunk_transition: empty problem (N=%s%lld)", "", N);
+    if (W < 1 || W > 63) return set_err("gf_chunk_transition: width %s%lld unsupported (1..63)", "", W);
+    if (block < 1 || block > 64 || (block & (block - 1))) return set_err("gf_chunk_transition: bad block %s%lld", "", block);
+    if (nch < 1 || chunk_len < 1 || (nch > 1 && (chunk_len % block) != 0) || (int64_t)nch * chunk_len < N
+        || (int64_t)(nch - 1) * chunk_len >= N)
+        return set_err("gf_chunk_transition: bad chunking (chunk_len=%s%lld, nch=%lld)", "", chunk_len, nch);
+    if (!t || !dbar || !zbar || !rbar || !h_out || !Phi_out || !G_out || !m_out || !cmax)
+        return set_err("gf_chunk_transition: null pointer%s", "");
     const double gap = (block > 1) ? SC_SPAN / (double)(block - 1) : 0.0;
     hipStream_t st = (hipStream_t)stream;
     const int rows = (W + 3) / 4 * 4;
     switch (rows) {
-        GF_F3_CASE(4) GF_F3_CASE(8) GF_F3_CASE(12) GF_F3_CASE(16) GF_F3_CASE(20) GF_F3_CASE(24)
-        GF_F3_CASE(28) GF_F3_CASE(32) GF_F3_CASE(36) GF_F3_CASE(40) GF_F3_CASE(44) GF_F3_CASE(48)
-        GF_F3_CASE(52) GF_F3_CASE(56) GF_F3_CASE(60) GF_F3_CASE(64)
-        default: return set_err("gf_loglike_fused: internal dispatch error%s", "");
+        GF_PHI_CASE(4) GF_PHI_CASE(8) GF_PHI_CASE(12) GF_PHI_CASE(16) GF_PHI_CASE(20) GF_PHI_CASE(24)
+        GF_PHI_CASE(28) GF_PHI_CASE(32) GF_PHI_CASE(36) GF_PHI_CASE(40) GF_PHI_CASE(44) GF_PHI_CASE(48)
+        GF_PHI_CASE(52) GF_PHI_CASE(56) GF_PHI_CASE(60) GF_PHI_CASE(64)
+        default: return set_err("gf_chunk_transition: internal dispatch error%s", "");
     }
-    return check_launch("gf_loglike_fused");
+    hipLaunchKernelGGL(k_gram, dim3(B * nch), dim3(256), 0, st, N, chunk_len, nch, h_out, dbar, zbar, G_out, m_out);
+    return check_launch("gf_chunk_transition");
+}
+
+int gf_chunk_combine(int B, int nch, const double *Phi, const double *G, const double *m,
+                     double *S_state, double *F_state, void *stream) {
+    if (B < 1 || nch < 1) return set_err("gf_chunk_combine: empty problem%s", "");
+    if (!Phi || !G || !m || !S_state || !F_state) return set_err("gf_chunk_combine: null pointer%s", "");
+    const size_t lds = sizeof(double) * (64 * 65 + 64 * 130 + 64 * 65 + 128);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_combine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_combine, dim3(B), dim3(256), lds, (hipStream_t)stream, nch, Phi, G, m, S_state, F_state);
+    return check_launch("gf_chunk_combine");
 }
 
 int64_t gf_reduce_work(int64_t N) { return 2 * (int64_t)red_groups(N); }

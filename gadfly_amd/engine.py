@@ -540,6 +540,97 @@ class StreamingBatch:
         _lib.check(st, "gf_loglike_finish")
         return out
 
+    # -- exact time-parallel evaluation (few problems, long series) ------------------------
+    def log_likelihood_time_parallel(self, chunk_len=None):
+        """
+        One evaluation per problem with the time axis swept in parallel chunks and stitched by
+        the exact LFT combine (gf_chunk_sweep / gf_chunk_transition / gf_chunk_combine).
+        Same result as :meth:`log_likelihood` to rounding; ~3.5x the flops but O(N / nch)
+        sequential depth -- the latency path for B = 1.  Needs the fused kernel's conditions.
+        """
+        if not self._fused_ok():
+            raise ValueError("time-parallel evaluation needs W <= 63 and |d t| < 1.6e6")
+        torch = self.torch
+        lib, p = self.lib, _lib.ptr
+        N, B = self.N, self.B
+        real, comp, diag_add, _, cmax, block, _ = self._pack
+        if chunk_len is None:
+            # ~128 chunks per problem: beyond that the (sequential, ~0.12 ms/chunk) combine
+            # outweighs the shorter sweeps (measured at N = 1e6, W = 60: DESIGN.md 4.3)
+            chunk_len = max(1024, -(-N // max(1, 128 // B)))
+        chunk_len = max(block, (int(chunk_len) + 63) // 64 * 64)
+        nch = -(-N // chunk_len)
+        self._tp_used = nch > 1
+        if nch == 1:
+            return self.log_likelihood()
+        f64 = dict(dtype=torch.float64, device=self.device)
+        key = (chunk_len, nch)
+        if getattr(self, "_tp_key", None) != key:
+            self._tp = dict(
+                S=torch.empty((B * nch, 4096), **f64), F=torch.empty((B * nch, 64), **f64),
+                Phi=torch.empty((B * nch, 4096), **f64), G=torch.empty((B * nch, 4096), **f64),
+                m=torch.empty((B * nch, 64), **f64),
+                d=torch.zeros((B * N + 2,), **f64), z=torch.zeros((B * N + 2,), **f64),
+                r=torch.zeros((B * N + 2, 64), **f64), h=torch.empty((B * N, 64), **f64),
+                info=torch.zeros((B * nch,), dtype=torch.int32, device=self.device),
+                work=torch.empty((B * int(lib.gf_reduce_work(N)),), **f64),
+                acc=torch.empty((B, 2), **f64))
+            self._tp_key = key
+        w = self._tp
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        w["S"].zero_(); w["F"].zero_(); w["info"].zero_()
+        coeffs = (p(real[0]), p(real[1]), p(comp[0]), p(comp[1]), p(comp[2]), p(comp[3]))
+        tyd = (p(self.t), self._bs(self.t), p(self.diag),
+               0 if self.diag is None else self._bs(self.diag), p(self.y), self._bs(self.y))
+        rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, self.Jr, self.Jc, block, *coeffs,
+                                p(diag_add), p(cmax), *tyd, p(w["d"]), p(w["z"]), p(w["r"]),
+                                p(w["S"]), p(w["F"]), p(w["info"]), st)
+        _lib.check(rc, "gf_chunk_sweep")
+        rc = lib.gf_chunk_transition(B, N, chunk_len, nch, self.Jr, self.Jc, block, *coeffs,
+                                     p(cmax), p(self.t), self._bs(self.t), p(w["d"]), p(w["z"]),
+                                     p(w["r"]), p(w["h"]), p(w["Phi"]), p(w["G"]), p(w["m"]), st)
+        _lib.check(rc, "gf_chunk_transition")
+        rc = lib.gf_chunk_combine(B, nch, p(w["Phi"]), p(w["G"]), p(w["m"]), p(w["S"]),
+                                  p(w["F"]), st)
+        _lib.check(rc, "gf_chunk_combine")
+        rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, self.Jr, self.Jc, block, *coeffs,
+                                p(diag_add), p(cmax), *tyd, p(w["d"]), p(w["z"]), None,
+                                p(w["S"]), p(w["F"]), p(w["info"]), st)
+        _lib.check(rc, "gf_chunk_sweep")
+        rc = lib.gf_reduce_tile(B, N, p(w["d"]), p(w["z"]), p(w["work"]), p(w["acc"]), 1, st)
+        _lib.check(rc, "gf_reduce_tile")
+        # a chunk that failed marks its problem
+        self.info.copy_(w["info"].view(B, nch).max(dim=1).values)
+        out = torch.empty((B,), **f64)
+        rc = lib.gf_loglike_finish(B, N, p(w["acc"]), p(self.info), p(out), None, st)
+        _lib.check(rc, "gf_loglike_finish")
+        return out
+
+    def set_y(self, resid):
+        """Replace the right-hand side(s) (same shape as at construction)."""
+        r = self._dev(resid)
+        if r.ndim == 1:
+            r = r[None, :]
+        if r.shape != self.y.shape:
+            raise ValueError("dimension mismatch")
+        self.y.copy_(r)
+
+    def evaluate(self, time_parallel=None):
+        """(loglike (B,), logdet (B,)) device tensors; picks the time-parallel evaluation for
+        few long series (B * N large per problem, B small) unless told otherwise."""
+        if time_parallel is None:
+            time_parallel = self._fused_ok() and self.B <= 16 and self.N >= 16384
+        if time_parallel and self._fused_ok():
+            out = self.log_likelihood_time_parallel()
+            acc = self._tp["acc"] if getattr(self, "_tp_key", None) and self._tp_used else self.acc
+        else:
+            self._tp_used = False
+            out = self.log_likelihood()
+            acc = self.acc
+        torch = self.torch
+        logdet = torch.where(self.info != 0, torch.full_like(acc[:, 0], float("-inf")), acc[:, 0])
+        return out, logdet
+
     @property
     def nbytes_algorithmic_loglike(self):
         return 8 * self.N * (3 * self.W + 4) * self.B

@@ -17,7 +17,7 @@ log-determinant is ``-inf`` and the log-likelihood ``-inf`` (gp.py:188-192).
 import numpy as np
 
 from . import units as _units
-from .engine import DeviceBatch, LOG_2PI
+from .engine import DeviceBatch, StreamingBatch, LOG_2PI
 
 __all__ = ["GaussianProcess", "ConditionalDistribution", "LinAlgError"]
 
@@ -128,7 +128,8 @@ class GaussianProcess:
         self.kernel = kernel
         self.mean = mean
         self._device = device
-        self._engine = None
+        self._factor = None
+        self._fast = None
         self._t = None
         self._mean_value = None
         self._diag = None
@@ -207,9 +208,9 @@ class GaussianProcess:
 
     # ---- helpers ------------------------------------------------------------
     def _to_device(self, x):
-        eng = self._engine
-        return eng.torch.as_tensor(
-            np.ascontiguousarray(x, dtype=np.float64)).to(eng.device)
+        import torch
+        return torch.as_tensor(
+            np.ascontiguousarray(x, dtype=np.float64)).to(self._device_of())
 
     def _process_input(self, y, *, require_vector=False):
         if self._t is None:
@@ -251,8 +252,8 @@ class GaussianProcess:
         elif diag is not None:
             self._diag += np.broadcast_to(np.asarray(diag, dtype=np.float64), (N,))
 
-        self._engine = DeviceBatch([self.kernel.get_device_coefficients()], t,
-                                   diag=self._diag, device=self._device)
+        self._factor = None            # stored-factor engine, built on first need
+        self._fast = None              # fused / time-parallel log-likelihood engine
         self._do_compute(quiet)
 
     def recompute(self, *, quiet=False):
@@ -260,11 +261,42 @@ class GaussianProcess:
             raise RuntimeError("The process must be initialized with compute")
         self._do_compute(quiet)
 
+    # The stored factor (U, V, P, W rows in HBM: what solves, predictions and draws need) is
+    # built lazily; `compute` + `log_likelihood` -- the MCMC hot path -- run on the fused
+    # engine (time-parallel for long series), which never materialises it.
+    @property
+    def _engine(self):
+        if self._factor is None:
+            if self._t is None:
+                raise RuntimeError("The process must be initialized with compute")
+            self._factor = DeviceBatch([self.kernel.get_device_coefficients()], self._t,
+                                       diag=self._diag, device=self._device)
+            info = self._factor.factor(keep_W=True)
+            if int(info[0].item()) and np.isfinite(self._log_det):
+                raise LinAlgError("failed to factorize or solve matrix")
+        return self._factor
+
     def _do_compute(self, quiet):
-        eng = self._engine
-        info = eng.factor(keep_W=True)
-        _, logdet = eng.reduce(with_quad=False)
+        co = self.kernel.get_device_coefficients()
+        W = len(co[0]) + 2 * len(co[2])
+        fast = None
+        if W <= 63:
+            fast = StreamingBatch([co], self._t, np.zeros(self._size), diag=self._diag,
+                                  device=self._device)
+            if not fast._fused_ok():
+                fast = None
+        self._fast = fast
+        if fast is not None:
+            _, logdet = fast.evaluate()
+            info = fast.info
+        else:
+            self._factor = None
+            eng = DeviceBatch([co], self._t, diag=self._diag, device=self._device)
+            self._factor = eng
+            info = eng.factor(keep_W=True)
+            _, logdet = eng.reduce(with_quad=False)
         failed = int(info[0].item())
+        self._failed_row = failed
         if failed:
             if not quiet:
                 raise LinAlgError(
@@ -293,6 +325,10 @@ class GaussianProcess:
         z = eng.solve_lower(Y).reshape(-1)
         return float((z * z / eng.d[0]).sum().item())
 
+    def _device_of(self):
+        import torch
+        return torch.device(self._device if self._device is not None else "cuda:0")
+
     # ---- public numerical API (reference gp.py:308-395) ------------------------
     def dot_tril(self, y, *, inplace=False):
         """``L D^{1/2} y`` with K = L D L^T (the mean is not applied)."""
@@ -313,6 +349,11 @@ class GaussianProcess:
         y = self._process_input(y, require_vector=True)
         if not np.isfinite(self._log_det):
             return -np.inf
+        if self._fast is not None:
+            # fused build + factor + solve + reductions (time-parallel for long series)
+            self._fast.set_y(y - self._mean_value)
+            out, _ = self._fast.evaluate()
+            return float(out[0].item())
         return -0.5 * self._do_norm(y - self._mean_value) - self._norm
 
     def apply_inverse(self, y, *, inplace=False):

@@ -143,6 +143,40 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
                      int32_t *info, void *stream);
 
 /*
+ * Exact time-parallel evaluation of ONE long series (or a few): the N rows are cut into nch
+ * chunks of chunk_len rows (a multiple of `block`; the last chunk may be shorter) that are swept
+ * concurrently, then stitched with an exact linear-fractional combine:
+ *   1. gf_chunk_sweep      nominal pass: S_state/F_state [B*nch] zeroed by the caller; every chunk
+ *                          starts from the zero state; outputs dbar, zbar [B][N], rbar [B][N][64]
+ *                          (pass r_out) and the nominal end states in S_state/F_state.
+ *   2. gf_chunk_transition closed-loop transition Phi [B*nch][64*64], the rows h [B][N][64], and
+ *                          G [B*nch][64*64], m [B*nch][64] of every chunk.
+ *   3. gf_chunk_combine    sequential LFT combine over the chunks (64x64 pivoted solves in LDS):
+ *                          S_state/F_state slot c <- TRUE start state of chunk c.
+ *   4. gf_chunk_sweep      final pass from those states (r_out = NULL): d, z equal the
+ *                          sequential result to rounding; reduce with gf_reduce_tile.
+ * Same argument conventions and padding rules as gf_loglike_fused; dbar and rbar must be
+ * readable two rows past the end.  Width 1..63, phases |d t| < 1.6e6.
+ */
+int gf_chunk_sweep(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc, int block,
+                   const double *ar, const double *cr, const double *ac,
+                   const double *bc, const double *cc, const double *dc,
+                   const double *diag_add, const double *cmax,
+                   const double *t, int64_t t_bs, const double *diag, int64_t diag_bs,
+                   const double *y, int64_t y_bs,
+                   double *d, double *z, double *r_out, double *S_state, double *F_state,
+                   int32_t *info, void *stream);
+int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc, int block,
+                        const double *ar, const double *cr, const double *ac,
+                        const double *bc, const double *cc, const double *dc,
+                        const double *cmax, const double *t, int64_t t_bs,
+                        const double *dbar, const double *zbar, const double *rbar,
+                        double *h_out, double *Phi_out, double *G_out, double *m_out,
+                        void *stream);
+int gf_chunk_combine(int B, int nch, const double *Phi, const double *G, const double *m,
+                     double *S_state, double *F_state, void *stream);
+
+/*
  * Log-likelihood reductions (fixed-shape tree, deterministic):
  *   gf_reduce_tile   : acc[b] = {sum log d, sum z^2/d} over N rows; init != 0 overwrites acc,
  *                      init == 0 adds to it (tiles in order).  z == NULL: second sum is 0.
