@@ -46,7 +46,11 @@ SIGNATURES = {
     "gf_loglike_fused": (_int, [_int, _i64, _i64, _int, _int, _int] + [_vp] * 8
                          + [_vp, _i64, _vp, _i64, _vp, _i64] + [_vp] * 5 + [_vp]),
     "gf_chunk_sweep": (_int, [_int, _i64, _i64, _int, _int, _int, _int] + [_vp] * 8
-                       + [_vp, _i64, _vp, _i64, _vp, _i64] + [_vp] * 6 + [_vp]),
+                       + [_vp, _i64, _vp, _i64, _vp, _i64] + [_vp] * 9 + [_vp]),
+    "gf_chunk_linear": (_int, [_int, _int, _i64, _i64, _int, _int, _int, _int, _int]
+                        + [_vp] * 8 + [_vp]),
+    "gf_chunk_linear_combine": (_int, [_int, _int, _i64, _i64, _int, _int, _int] + [_vp] * 5
+                                + [_vp]),
     "gf_chunk_transition": (_int, [_int, _i64, _i64, _int, _int, _int, _int] + [_vp] * 7
                             + [_vp, _i64] + [_vp] * 7 + [_vp]),
     "gf_chunk_combine": (_int, [_int, _int] + [_vp] * 5 + [_vp]),

@@ -796,6 +796,7 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
           const double *__restrict__ diag_, const int64_t diag_bs,
           const double *__restrict__ y_, const int64_t y_bs,
           double *__restrict__ d_, double *__restrict__ z_, double *__restrict__ r_out,
+          double *__restrict__ Ut_out, double *__restrict__ Wt_out, double *__restrict__ de_out,
           double *__restrict__ S_state, double *__restrict__ F_state,
           int32_t *__restrict__ info) {
     const int lane = threadIdx.x;
@@ -812,6 +813,9 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     double *__restrict__ dg = d_ + pb;
     double *__restrict__ zg = z_ + pb;
     double *__restrict__ rg = r_out ? r_out + pb * 64 + lane : nullptr;
+    double *__restrict__ ug = Ut_out ? Ut_out + pb * 64 + lane : nullptr;   // stored factor:
+    double *__restrict__ wg = Wt_out ? Wt_out + pb * 64 + lane : nullptr;   // u~, w~ = r/d rows
+    double *__restrict__ eg = de_out ? de_out + pb : nullptr;               // reset spans (-1: none)
     double *__restrict__ Sg = S_state + (size_t)b * (64 * 64) + (size_t)lane * 64;
     double *__restrict__ Fg = F_state + (size_t)b * 64;
     const double diag_add = diag_add_[pr];
@@ -849,6 +853,7 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     for (int64_t n = 0; n < rows; ++n) {
         const double a_n = g_n + diag_add, yy = y_n;
         const double ut_c = ut, vt_c = vt;
+        if (eg && lane == 0) eg[n] = rst ? de : -1.0;
         if (rst) {                          // wave-uniform: fold the pending update, then decay
             const double el = fm_exp(-cj * de);     // pad lanes: cj = 0 -> 1
             s_e[lane] = el;
@@ -887,6 +892,7 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
         zq = zn * inv;
         q = fl ? zq : r * inv;
         if (rg) rg[(size_t)n * 64] = r;             // r~ rows for k_phi (chunk mode)
+        if (ug) { ug[(size_t)n * 64] = ut_c; wg[(size_t)n * 64] = fl ? 0.0 : q; }
         if (lane == 0) { dg[n] = dn; zg[n] = zn; }
     }
     if (fail) {
@@ -1296,6 +1302,223 @@ k_combine(const int nch, const double *__restrict__ Phi_, const double *__restri
         }
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------
+// Triangular sweeps on the STORED scaled factor (u~, w~ = r/d rows, d, reset spans de), chunked:
+// every (problem, chunk) starts from the state in F_state and leaves its end state there.
+// In scaled coordinates the recurrences have no per-row decay (A.6/A.7 with P folded into the
+// block scaling); at a reset row the state is multiplied by E = exp(-c de) once:
+//   lower  : F <- [E](F + w~_{n-1} z_{n-1}) ;  z_n = y_n - u~_n . F           (ascending)
+//   upper  : G <- [E_{n+1}](G + u~_{n+1} z_{n+1}) ;  z_n = y_n - w~_n . G     (descending; the
+//            decay of reset row n+1 is crossed when stepping from n+1 down to n)
+//   matmul : F <- [E](F + w~_{n-1} y_{n-1}) ;  z_n = y_n + u~_n . F           (ascending)
+// with optional input scaling y <- y / d (upper: apply_inverse) or y <- y sqrt(d) (matmul:
+// dot_tril).  R = 1: the state is lane-resident, one DPP tree per row.
+// ------------------------------------------------------------------------------------
+struct LinArgs {
+    int64_t N, chunk_len;
+    int nch, W, mode, scale, store;     // store: write z (final pass) or only the end state
+    const double *c;                    // [B][W]
+    const double *Ut, *Wt, *d, *de, *Y; // rows [B][N][64] / [B][N]; Y [B][N][R]
+    double *Z;
+    double *F_state;                    // [B*nch][64 * R]  (R = 1: [64])
+    int R;
+};
+
+__global__ void __launch_bounds__(64) k_lin1(const LinArgs A) {
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const int pr = b / A.nch, ch = b - pr * A.nch;
+    const int64_t c0 = (int64_t)ch * A.chunk_len;
+    const int64_t rows = (A.N - c0 < A.chunk_len) ? (A.N - c0) : A.chunk_len;
+    const size_t pb = (size_t)pr * A.N + c0;
+    const double *__restrict__ Ug = A.Ut + pb * 64 + lane;
+    const double *__restrict__ Wg = A.Wt + pb * 64 + lane;
+    const double *__restrict__ dg = A.d + pb;
+    const double *__restrict__ eg = A.de + pb;
+    const double *__restrict__ Yg = A.Y + pb;
+    double *__restrict__ Zg = A.Z + pb;
+    double *__restrict__ Fg = A.F_state + (size_t)b * 64;
+    const double cj = (lane < A.W) ? A.c[(size_t)pr * A.W + lane] : 0.0;
+    const bool up = A.mode == GF_SOLVE_UPPER, mm = A.mode == GF_MATMUL_LOWER;
+    double F = Fg[lane];
+    if (!up) {
+        double carry = 0.0, wprev = 0.0;            // pending F += w~_{n-1} * carry
+        for (int64_t n = 0; n < rows; ++n) {
+            double yn = Yg[n];
+            if (A.scale) yn = mm ? yn * sqrt(dg[n]) : yn / dg[n];
+            const double de = eg[n];
+            F = fma(wprev, carry, F);
+            if (de >= 0.0) F *= fm_exp(-cj * de);
+            const double dot = wave_sum(Ug[(size_t)n * 64] * F);
+            const double zn = mm ? (yn + dot) : (yn - dot);
+            if (A.store && lane == 0) Zg[n] = zn;
+            carry = mm ? yn : zn;
+            wprev = Wg[(size_t)n * 64];
+        }
+        Fg[lane] = fma(wprev, carry, F);            // pending folded, decay left to the next chunk
+    } else {
+        // the state handed DOWN to this chunk already carries the decay of the boundary it crossed
+        double carry = 0.0, uprev = 0.0, de_up = -1.0;      // row n+1's quantities
+        for (int64_t n = rows - 1; n >= 0; --n) {
+            double yn = Yg[n];
+            if (A.scale) yn = yn / dg[n];
+            F = fma(uprev, carry, F);
+            if (de_up >= 0.0) F *= fm_exp(-cj * de_up);
+            const double dot = wave_sum(Wg[(size_t)n * 64] * F);
+            const double zn = yn - dot;
+            if (A.store && lane == 0) Zg[n] = zn;
+            carry = zn;
+            uprev = Ug[(size_t)n * 64];
+            de_up = eg[n];
+        }
+        F = fma(uprev, carry, F);
+        if (de_up >= 0.0) F *= fm_exp(-cj * de_up);     // cross the chunk's first-row boundary
+        Fg[lane] = F;
+    }
+}
+
+// R right-hand sides: lane r owns column r of Y/Z and F[:, r] (ROWS doubles in VGPRs); the
+// generator rows are staged per row in LDS and read back as wave-uniform operands.
+template <int ROWS>
+__global__ void __launch_bounds__(64) k_linR(const LinArgs A) {
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;                       // (problem, chunk)
+    const int rt = blockIdx.y;                      // RHS tile of 64 columns
+    const int pr = b / A.nch, ch = b - pr * A.nch;
+    const int R = A.R;
+    const int r = rt * 64 + lane;
+    const bool rok = r < R;
+    const int64_t c0 = (int64_t)ch * A.chunk_len;
+    const int64_t rows = (A.N - c0 < A.chunk_len) ? (A.N - c0) : A.chunk_len;
+    const size_t pb = (size_t)pr * A.N + c0;
+    const double *__restrict__ Ug = A.Ut + pb * 64 + lane;
+    const double *__restrict__ Wg = A.Wt + pb * 64 + lane;
+    const double *__restrict__ dg = A.d + pb;
+    const double *__restrict__ eg = A.de + pb;
+    const double *__restrict__ Yg = A.Y + pb * R;
+    double *__restrict__ Zg = A.Z + pb * R;
+    double *__restrict__ Fg = A.F_state + (size_t)b * 64 * R;      // [i][R]
+    const double cj = (lane < A.W) ? A.c[(size_t)pr * A.W + lane] : 0.0;
+    const bool up = A.mode == GF_SOLVE_UPPER, mm = A.mode == GF_MATMUL_LOWER;
+    __shared__ double s_a[64], s_b[64], s_e[64];
+    double F[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) F[i] = rok ? Fg[(size_t)i * R + r] : 0.0;
+    double carry = 0.0;
+    s_a[lane] = 0.0;                                // pending push row (w~_{n-1} or u~_{n+1})
+    double de_cross = -1.0;
+    for (int64_t s = 0; s < rows; ++s) {
+        const int64_t n = up ? (rows - 1 - s) : s;
+        double yn = rok ? Yg[(size_t)n * R + r] : 0.0;
+        if (A.scale) { const double dn = dg[n]; yn = mm ? yn * sqrt(dn) : yn / dn; }
+        const double de = up ? de_cross : eg[n];    // decay to apply before this row's dot
+        const double pullv = up ? Wg[(size_t)n * 64] : Ug[(size_t)n * 64];
+        wave_lds_fence();
+        s_b[lane] = pullv;
+        const bool dec = de >= 0.0;
+        if (dec) s_e[lane] = fm_exp(-cj * de);
+        wave_lds_fence();
+        double dot = 0.0, dot2 = 0.0;
+        if (dec) {
+#pragma unroll
+            for (int i = 0; i < ROWS; i += 2) {
+                F[i] = fma(s_a[i], carry, F[i]) * s_e[i];
+                dot = fma(s_b[i], F[i], dot);
+                F[i + 1] = fma(s_a[i + 1], carry, F[i + 1]) * s_e[i + 1];
+                dot2 = fma(s_b[i + 1], F[i + 1], dot2);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < ROWS; i += 2) {
+                F[i] = fma(s_a[i], carry, F[i]);
+                dot = fma(s_b[i], F[i], dot);
+                F[i + 1] = fma(s_a[i + 1], carry, F[i + 1]);
+                dot2 = fma(s_b[i + 1], F[i + 1], dot2);
+            }
+        }
+        dot += dot2;
+        const double zn = mm ? (yn + dot) : (yn - dot);
+        if (A.store && rok) Zg[(size_t)n * R + r] = zn;
+        carry = mm ? yn : zn;
+        const double pushv = up ? Ug[(size_t)n * 64] : Wg[(size_t)n * 64];
+        wave_lds_fence();
+        s_a[lane] = pushv;
+        if (up) de_cross = eg[n];
+    }
+    wave_lds_fence();
+    const bool dec = up && de_cross >= 0.0;
+    if (dec) s_e[lane] = fm_exp(-cj * de_cross);
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        double v = fma(s_a[i], carry, F[i]);
+        if (dec) v *= s_e[i];
+        if (rok) Fg[(size_t)i * R + r] = v;
+    }
+}
+
+// Linear combine of the chunk states of a sweep: on entry F_state slot c holds chunk c's end
+// state from a zero start (local pass); on exit it holds the TRUE start state of chunk c.
+//   lower  : F_{c+1} = Fbar_c + Phi_c F_c            (ascending; Phi = true closed-loop transition)
+//   upper  : G_{c-1} = Gbar_c + Phi_c^T G_c          (descending)
+//   matmul : F_{c+1} = Fbar_c + D_c o F_c            (D = product of the chunk's reset decays)
+// One workgroup of 64 x RT threads per (problem, RHS tile); Phi is stored [j][i].
+__global__ void __launch_bounds__(256)
+k_lincombine(const int nch, const int W, const int mode, const int R,
+             const double *__restrict__ Phi_, const double *__restrict__ Dch_,
+             double *__restrict__ F_state) {
+    const int pr = blockIdx.x;
+    const int i = threadIdx.x & 63;                 // state row
+    const int rsub = threadIdx.x >> 6;              // 4 RHS columns in flight per pass
+    const bool up = mode == GF_SOLVE_UPPER, mm = mode == GF_MATMUL_LOWER;
+    extern __shared__ __attribute__((aligned(16))) double lds[];    // cur[64][R]
+    double *cur = lds;
+    for (int e = threadIdx.x; e < 64 * R; e += 256) cur[e] = 0.0;
+    __syncthreads();
+    for (int s = 0; s < nch; ++s) {
+        const int c = up ? (nch - 1 - s) : s;
+        const size_t slot = (size_t)pr * nch + c;
+        double *Fg = F_state + slot * 64 * R;
+        const double *Pg = Phi_ ? Phi_ + slot * 4096 : nullptr;
+        for (int r0 = 0; r0 < R; r0 += 4) {
+            const int r = r0 + rsub;
+            double nxt = 0.0;
+            if (r < R) {
+                nxt = Fg[(size_t)i * R + r];                        // local end state of chunk c
+                if (mm) {
+                    nxt = fma(Dch_[slot * 64 + i], cur[i * R + r], nxt);
+                } else if (!up) {
+#pragma unroll 8
+                    for (int j = 0; j < 64; ++j) nxt = fma(Pg[(size_t)j * 64 + i], cur[j * R + r], nxt);
+                } else {
+#pragma unroll 8
+                    for (int j = 0; j < 64; ++j) nxt = fma(Pg[(size_t)i * 64 + j], cur[j * R + r], nxt);
+                }
+                Fg[(size_t)i * R + r] = cur[i * R + r];             // publish the true start state
+            }
+            __syncthreads();
+            if (r < R) cur[i * R + r] = nxt;
+            __syncthreads();
+        }
+    }
+}
+
+// D_c[j] = exp(-c_j * (sum of the reset spans inside chunk c))   (diagonal chunk transition of
+// matmul_lower; the first row of every chunk is a reset row)
+__global__ void __launch_bounds__(64)
+k_chunk_decay(const int64_t N, const int64_t chunk_len, const int nch, const int W,
+              const double *__restrict__ c_, const double *__restrict__ de_, double *__restrict__ D_out) {
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const int pr = b / nch, ch = b - pr * nch;
+    const int64_t c0 = (int64_t)ch * chunk_len;
+    const int64_t rows = (N - c0 < chunk_len) ? (N - c0) : chunk_len;
+    const double *eg = de_ + (size_t)pr * N + c0;
+    double acc = 0.0;
+    for (int64_t n = lane; n < rows; n += 64) { const double v = eg[n]; if (v > 0.0) acc += v; }
+    acc = wave_sum(acc);
+    const double cj = (lane < W) ? c_[(size_t)pr * W + lane] : 0.0;
+    D_out[(size_t)b * 64 + lane] = fm_exp(-cj * acc);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1743,7 +1966,7 @@ int gf_factor_scaled(int B, int64_t N, int64_t n_first, int W, int ld, const dou
     return check_launch("gf_factor_scaled");
 }
 
-#define GF_F3_CASE(R) case R: hipLaunchKernelGGL((k_factor3<R>), dim3(B * nch), dim3(64), 0, st, N, n_first, chunk_len, nch, Jr, Jc, block, gap, ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out, S_state, F_state, info); break;
+#define GF_F3_CASE(R) case R: hipLaunchKernelGGL((k_factor3<R>), dim3(B * nch), dim3(64), 0, st, N, n_first, chunk_len, nch, Jr, Jc, block, gap, ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out, Ut_out, Wt_out, de_out, S_state, F_state, info); break;
 
 static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int64_t chunk_len, int nch,
                         int Jr, int Jc, int block,
@@ -1752,10 +1975,13 @@ static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int6
                         const double *diag_add, const double *cmax,
                         const double *t, int64_t t_bs, const double *diag, int64_t diag_bs,
                         const double *y, int64_t y_bs,
-                        double *d, double *z, double *r_out, double *S_state, double *F_state,
+                        double *d, double *z, double *r_out, double *Ut_out, double *Wt_out,
+                        double *de_out, double *S_state, double *F_state,
                         int32_t *info, void *stream) {
     const int W = Jr + 2 * Jc;
     if (B < 1 || N < 1) return set_err("%s: empty problem (N=%lld)", who, N);
+    if ((Ut_out != nullptr) != (Wt_out != nullptr) || (Ut_out != nullptr) != (de_out != nullptr))
+        return set_err("%s: Ut_out, Wt_out, de_out go together%s", who);
     if (W < 1 || W > 63) return set_err("%s: width %lld unsupported (1..63)", who, W);
     if (block < 1 || block > 64 || (block & (block - 1))) return set_err("%s: block=%lld must be a power of two in 1..64", who, block);
     if (n_first < 0 || (n_first % block) != 0) return set_err("%s: n_first=%lld must be a non-negative multiple of block=%lld", who, n_first, block);
@@ -1786,7 +2012,7 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
                      int32_t *info, void *stream) {
     return fused_launch("gf_loglike_fused", B, N, n_first, N, 1, Jr, Jc, block, ar, cr, ac, bc, cc, dc,
                         diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, nullptr,
-                        S_state, F_state, info, stream);
+                        nullptr, nullptr, nullptr, S_state, F_state, info, stream);
 }
 
 int gf_chunk_sweep(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc, int block,
@@ -1795,11 +2021,12 @@ int gf_chunk_sweep(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc,
                    const double *diag_add, const double *cmax,
                    const double *t, int64_t t_bs, const double *diag, int64_t diag_bs,
                    const double *y, int64_t y_bs,
-                   double *d, double *z, double *r_out, double *S_state, double *F_state,
+                   double *d, double *z, double *r_out, double *Ut_out, double *Wt_out,
+                   double *de_out, double *S_state, double *F_state,
                    int32_t *info, void *stream) {
     return fused_launch("gf_chunk_sweep", B, N, 0, chunk_len, nch, Jr, Jc, block, ar, cr, ac, bc, cc, dc,
                         diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out,
-                        S_state, F_state, info, stream);
+                        Ut_out, Wt_out, de_out, S_state, F_state, info, stream);
 }
 
 #define GF_PHI_CASE(R) case R: hipLaunchKernelGGL((k_phi<R>), dim3(B * nch), dim3(64), 0, st, N, (int64_t)0, chunk_len, nch, Jr, Jc, block, gap, ar, cr, ac, bc, cc, dc, cmax, t, t_bs, dbar, rbar, h_out, Phi_out); break;
@@ -1845,6 +2072,52 @@ int gf_chunk_combine(int B, int nch, const double *Phi, const double *G, const d
     }
     hipLaunchKernelGGL(k_combine, dim3(B), dim3(256), lds, (hipStream_t)stream, nch, Phi, G, m, S_state, F_state);
     return check_launch("gf_chunk_combine");
+}
+
+#define GF_LINR_CASE(Rw) case Rw: hipLaunchKernelGGL((k_linR<Rw>), dim3(B * nch, (R + 63) / 64), dim3(64), 0, st, A); break;
+
+int gf_chunk_linear(int mode, int B, int64_t N, int64_t chunk_len, int nch, int W, int R,
+                    int scale, int store, const double *c,
+                    const double *Ut, const double *Wt, const double *d, const double *de,
+                    const double *Y, double *Z, double *F_state, void *stream) {
+    if (mode < 0 || mode > 2) return set_err("gf_chunk_linear: bad mode %s%lld", "", mode);
+    if (B < 1 || N < 1 || R < 1) return set_err("gf_chunk_linear: empty problem (N=%s%lld, R=%lld)", "", N, R);
+    if (W < 1 || W > 63) return set_err("gf_chunk_linear: width %s%lld unsupported (1..63)", "", W);
+    if (nch < 1 || chunk_len < 1 || (int64_t)nch * chunk_len < N || (int64_t)(nch - 1) * chunk_len >= N)
+        return set_err("gf_chunk_linear: bad chunking (chunk_len=%s%lld, nch=%lld)", "", chunk_len, nch);
+    if (!c || !Ut || !Wt || !d || !de || !Y || !Z || !F_state) return set_err("gf_chunk_linear: null pointer%s", "");
+    LinArgs A;
+    A.N = N; A.chunk_len = chunk_len; A.nch = nch; A.W = W; A.mode = mode; A.scale = scale; A.store = store;
+    A.c = c; A.Ut = Ut; A.Wt = Wt; A.d = d; A.de = de; A.Y = Y; A.Z = Z; A.F_state = F_state; A.R = R;
+    hipStream_t st = (hipStream_t)stream;
+    if (R == 1) {
+        hipLaunchKernelGGL(k_lin1, dim3(B * nch), dim3(64), 0, st, A);
+    } else {
+        const int rows = (W + 3) / 4 * 4;
+        switch (rows) {
+            GF_LINR_CASE(4) GF_LINR_CASE(8) GF_LINR_CASE(12) GF_LINR_CASE(16) GF_LINR_CASE(20) GF_LINR_CASE(24)
+            GF_LINR_CASE(28) GF_LINR_CASE(32) GF_LINR_CASE(36) GF_LINR_CASE(40) GF_LINR_CASE(44) GF_LINR_CASE(48)
+            GF_LINR_CASE(52) GF_LINR_CASE(56) GF_LINR_CASE(60) GF_LINR_CASE(64)
+            default: return set_err("gf_chunk_linear: internal dispatch error%s", "");
+        }
+    }
+    return check_launch("gf_chunk_linear");
+}
+
+int gf_chunk_linear_combine(int mode, int B, int64_t N, int64_t chunk_len, int nch, int W, int R,
+                            const double *c, const double *de, const double *Phi,
+                            double *D_work, double *F_state, void *stream) {
+    if (mode < 0 || mode > 2) return set_err("gf_chunk_linear_combine: bad mode %s%lld", "", mode);
+    if (B < 1 || nch < 1 || R < 1) return set_err("gf_chunk_linear_combine: empty problem%s", "");
+    if (!F_state || (mode == GF_MATMUL_LOWER ? (!D_work || !c || !de) : !Phi))
+        return set_err("gf_chunk_linear_combine: null pointer%s", "");
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == GF_MATMUL_LOWER)
+        hipLaunchKernelGGL(k_chunk_decay, dim3(B * nch), dim3(64), 0, st, N, chunk_len, nch, W, c, de, D_work);
+    const size_t lds = sizeof(double) * 64 * (size_t)R;
+    if (lds > 64 * 1024) return set_err("gf_chunk_linear_combine: R=%s%lld too large (max 128)", "", R);
+    hipLaunchKernelGGL(k_lincombine, dim3(B), dim3(256), lds, st, nch, W, mode, R, Phi, D_work, F_state);
+    return check_launch("gf_chunk_linear_combine");
 }
 
 int64_t gf_reduce_work(int64_t N) { return 2 * (int64_t)red_groups(N); }

@@ -280,6 +280,90 @@ class DeviceBatch:
 LOG_2PI = math.log(2.0 * math.pi)
 
 
+class ScaledFactor:
+    """
+    The LDL^T factor of B problems stored in block-scaled form (rows u~, w~ = r/d, pivots d,
+    reset spans de, per-chunk closed-loop transitions Phi) -- what `apply_inverse`, `dot_tril`,
+    `predict` and `sample` need (/root/reference/gadfly/gp.py:370, :327, :232, :391).  All sweeps are
+    chunk-parallel in time: local pass, linear combine of the chunk states, final pass
+    (gf_chunk_linear / gf_chunk_linear_combine).  Same method surface as :class:`DeviceBatch`.
+    """
+
+    RMAX = 64                           # right-hand sides per sweep (one wave of lanes)
+
+    def __init__(self, owner, chunk_len, nch):
+        self.owner = owner
+        self.torch = owner.torch
+        self.lib = owner.lib
+        self.device = owner.device
+        self.B, self.N, self.W = owner.B, owner.N, owner.W
+        self.chunk_len, self.nch = chunk_len, nch
+        w = owner._tp
+        self.Ut, self.Wt, self.de, self.Phi = w["Ut"], w["Wt"], w["de"], w["Phi"]
+        self.d = w["d"][:self.B * self.N].view(self.B, self.N)
+        self.c = owner._pack[3]
+        self.t = owner.t
+        self.info = owner.info
+        self._v1 = None
+        self._D = None
+
+    def _sweep(self, mode, Y, scale):
+        torch = self.torch
+        lib, p = self.lib, _lib.ptr
+        B, N, R = Y.shape
+        if R > self.RMAX:               # tile the right-hand sides
+            return torch.cat([self._sweep(mode, Y[:, :, r0:r0 + self.RMAX].contiguous(), scale)
+                              for r0 in range(0, R, self.RMAX)], dim=2)
+        Y = Y.contiguous()
+        Z = torch.empty_like(Y)
+        f64 = dict(dtype=torch.float64, device=self.device)
+        F = torch.zeros((B * self.nch, 64 * R), **f64)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        args = (mode, B, N, self.chunk_len, self.nch, self.W, R)
+        rows = (p(self.c), p(self.Ut), p(self.Wt), p(self.d), p(self.de))
+        if self.nch > 1:
+            rc = lib.gf_chunk_linear(*args, int(scale), 0, *rows, p(Y), p(Z), p(F), st)
+            _lib.check(rc, "gf_chunk_linear")
+            if mode == _lib.GF_MATMUL_LOWER and self._D is None:
+                self._D = torch.empty((B * self.nch, 64), **f64)
+            rc = lib.gf_chunk_linear_combine(
+                *args, p(self.c), p(self.de),
+                None if mode == _lib.GF_MATMUL_LOWER else p(self.Phi),
+                p(self._D) if mode == _lib.GF_MATMUL_LOWER else None, p(F), st)
+            _lib.check(rc, "gf_chunk_linear_combine")
+        rc = lib.gf_chunk_linear(*args, int(scale), 1, *rows, p(Y), p(Z), p(F), st)
+        _lib.check(rc, "gf_chunk_linear")
+        return Z
+
+    def solve_lower(self, Y):
+        return self._sweep(_lib.GF_SOLVE_LOWER, Y, 0)
+
+    def solve_upper(self, Y, scale=None):
+        return self._sweep(_lib.GF_SOLVE_UPPER, Y, 0 if scale is None else 1)
+
+    def apply_inverse(self, Y):
+        return self._sweep(_lib.GF_SOLVE_UPPER, self._sweep(_lib.GF_SOLVE_LOWER, Y, 0), 1)
+
+    def dot_tril(self, Y):
+        return self._sweep(_lib.GF_MATMUL_LOWER, Y, 1)
+
+    # prediction at new times: short sequential hop kernels on unscaled generator rows
+    def _unscaled(self):
+        if self._v1 is None:
+            o = self.owner
+            if o._coeffs_list is None:
+                raise RuntimeError("prediction at new times needs the construction-time "
+                                   "coefficients (use_coefficients() replaced them)")
+            self._v1 = DeviceBatch(o._coeffs_list, o.t, diag=o.diag, device=self.device)
+        return self._v1
+
+    def matrices_at(self, tstar):
+        return self._unscaled().matrices_at(tstar)
+
+    def predict_at(self, alpha, ts, Us, Vs, other=None):
+        return self._unscaled().predict_at(alpha, ts, Us, Vs, other=other)
+
+
 class StreamingBatch:
     """
     B independent log-likelihood evaluations streamed through fixed-size tile buffers.
@@ -345,6 +429,7 @@ class StreamingBatch:
                 raise ValueError("dimension mismatch")
             self.diag, self._dpad = padded(diag)
         self._coeff_host = (real, comp, diag_add, c)
+        self._coeffs_list = list(coeffs_list)
         B, ld = self.B, self.ld
         # W <= 64: block-scaled one-wave-per-problem kernels (k_build2 / k_factor2)
         self.scaled = bool(self.lib.gf_scaled_supported(self.W)) and not force_v1
@@ -419,6 +504,7 @@ class StreamingBatch:
 
     def use_coefficients(self, pack):
         self._pack = pack
+        self._coeffs_list = None
 
     def _build_tile(self, k, buf, stream):
         n0 = k * self.tile_rows
@@ -541,28 +627,26 @@ class StreamingBatch:
         return out
 
     # -- exact time-parallel evaluation (few problems, long series) ------------------------
-    def log_likelihood_time_parallel(self, chunk_len=None):
-        """
-        One evaluation per problem with the time axis swept in parallel chunks and stitched by
-        the exact LFT combine (gf_chunk_sweep / gf_chunk_transition / gf_chunk_combine).
-        Same result as :meth:`log_likelihood` to rounding; ~3.5x the flops but O(N / nch)
-        sequential depth -- the latency path for B = 1.  Needs the fused kernel's conditions.
-        """
+    def _tp_chunking(self, chunk_len):
+        N, B = self.N, self.B
+        block = self._pack[5]
+        if chunk_len is None:
+            # ~128 chunks per problem: beyond that the (sequential, ~0.12 ms/chunk) combine
+            # outweighs the shorter sweeps (measured at N = 1e6, W = 60: DESIGN.md 4.3)
+            chunk_len = max(1024, -(-N // max(1, 128 // B)))
+        chunk_len = max(block, (int(chunk_len) + 63) // 64 * 64)
+        return chunk_len, -(-N // chunk_len)
+
+    def _tp_run(self, chunk_len=None, store=False):
+        """Chunk-parallel factor + forward solve.  store=True also keeps the factor in scaled
+        form (u~, w~ rows, reset spans, per-chunk true transitions) for :class:`ScaledFactor`."""
         if not self._fused_ok():
             raise ValueError("time-parallel evaluation needs W <= 63 and |d t| < 1.6e6")
         torch = self.torch
         lib, p = self.lib, _lib.ptr
         N, B = self.N, self.B
         real, comp, diag_add, _, cmax, block, _ = self._pack
-        if chunk_len is None:
-            # ~128 chunks per problem: beyond that the (sequential, ~0.12 ms/chunk) combine
-            # outweighs the shorter sweeps (measured at N = 1e6, W = 60: DESIGN.md 4.3)
-            chunk_len = max(1024, -(-N // max(1, 128 // B)))
-        chunk_len = max(block, (int(chunk_len) + 63) // 64 * 64)
-        nch = -(-N // chunk_len)
-        self._tp_used = nch > 1
-        if nch == 1:
-            return self.log_likelihood()
+        chunk_len, nch = self._tp_chunking(chunk_len)
         f64 = dict(dtype=torch.float64, device=self.device)
         key = (chunk_len, nch)
         if getattr(self, "_tp_key", None) != key:
@@ -577,26 +661,41 @@ class StreamingBatch:
                 acc=torch.empty((B, 2), **f64))
             self._tp_key = key
         w = self._tp
+        if store and "Ut" not in w:
+            w["Ut"] = torch.empty((B * N, 64), **f64)
+            w["Wt"] = torch.empty((B * N, 64), **f64)
+            w["de"] = torch.empty((B * N,), **f64)
         st = torch.cuda.current_stream(self.device).cuda_stream
         w["S"].zero_(); w["F"].zero_(); w["info"].zero_()
         coeffs = (p(real[0]), p(real[1]), p(comp[0]), p(comp[1]), p(comp[2]), p(comp[3]))
         tyd = (p(self.t), self._bs(self.t), p(self.diag),
                0 if self.diag is None else self._bs(self.diag), p(self.y), self._bs(self.y))
+        none3 = (None, None, None)
+
+        def transition():
+            rc = lib.gf_chunk_transition(B, N, chunk_len, nch, self.Jr, self.Jc, block, *coeffs,
+                                         p(cmax), p(self.t), self._bs(self.t), p(w["d"]),
+                                         p(w["z"]), p(w["r"]), p(w["h"]), p(w["Phi"]),
+                                         p(w["G"]), p(w["m"]), st)
+            _lib.check(rc, "gf_chunk_transition")
+
+        if nch > 1:
+            rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, self.Jr, self.Jc, block, *coeffs,
+                                    p(diag_add), p(cmax), *tyd, p(w["d"]), p(w["z"]), p(w["r"]),
+                                    *none3, p(w["S"]), p(w["F"]), p(w["info"]), st)
+            _lib.check(rc, "gf_chunk_sweep")
+            transition()
+            rc = lib.gf_chunk_combine(B, nch, p(w["Phi"]), p(w["G"]), p(w["m"]), p(w["S"]),
+                                      p(w["F"]), st)
+            _lib.check(rc, "gf_chunk_combine")
+        stores = (p(w["Ut"]), p(w["Wt"]), p(w["de"])) if store else none3
         rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, self.Jr, self.Jc, block, *coeffs,
-                                p(diag_add), p(cmax), *tyd, p(w["d"]), p(w["z"]), p(w["r"]),
+                                p(diag_add), p(cmax), *tyd, p(w["d"]), p(w["z"]),
+                                p(w["r"]) if (store and nch > 1) else None, *stores,
                                 p(w["S"]), p(w["F"]), p(w["info"]), st)
         _lib.check(rc, "gf_chunk_sweep")
-        rc = lib.gf_chunk_transition(B, N, chunk_len, nch, self.Jr, self.Jc, block, *coeffs,
-                                     p(cmax), p(self.t), self._bs(self.t), p(w["d"]), p(w["z"]),
-                                     p(w["r"]), p(w["h"]), p(w["Phi"]), p(w["G"]), p(w["m"]), st)
-        _lib.check(rc, "gf_chunk_transition")
-        rc = lib.gf_chunk_combine(B, nch, p(w["Phi"]), p(w["G"]), p(w["m"]), p(w["S"]),
-                                  p(w["F"]), st)
-        _lib.check(rc, "gf_chunk_combine")
-        rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, self.Jr, self.Jc, block, *coeffs,
-                                p(diag_add), p(cmax), *tyd, p(w["d"]), p(w["z"]), None,
-                                p(w["S"]), p(w["F"]), p(w["info"]), st)
-        _lib.check(rc, "gf_chunk_sweep")
+        if store and nch > 1:
+            transition()                    # on the TRUE rows: Phi = true chunk transitions
         rc = lib.gf_reduce_tile(B, N, p(w["d"]), p(w["z"]), p(w["work"]), p(w["acc"]), 1, st)
         _lib.check(rc, "gf_reduce_tile")
         # a chunk that failed marks its problem
@@ -604,7 +703,27 @@ class StreamingBatch:
         out = torch.empty((B,), **f64)
         rc = lib.gf_loglike_finish(B, N, p(w["acc"]), p(self.info), p(out), None, st)
         _lib.check(rc, "gf_loglike_finish")
-        return out
+        self._tp_used = True
+        return out, chunk_len, nch
+
+    def log_likelihood_time_parallel(self, chunk_len=None):
+        """
+        One evaluation per problem with the time axis swept in parallel chunks and stitched by
+        the exact LFT combine (gf_chunk_sweep / gf_chunk_transition / gf_chunk_combine).
+        Same result as :meth:`log_likelihood` to rounding; ~3.5x the flops but O(N / nch)
+        sequential depth -- the latency path for B = 1.  Needs the fused kernel's conditions.
+        """
+        if not self._fused_ok():
+            raise ValueError("time-parallel evaluation needs W <= 63 and |d t| < 1.6e6")
+        if self._tp_chunking(chunk_len)[1] == 1:
+            self._tp_used = False
+            return self.log_likelihood()
+        return self._tp_run(chunk_len, store=False)[0]
+
+    def stored_factor(self, chunk_len=None):
+        """Factorise (time-parallel) and keep the factor for triangular sweeps."""
+        _, chunk_len, nch = self._tp_run(chunk_len, store=True)
+        return ScaledFactor(self, chunk_len, nch)
 
     def set_y(self, resid):
         """Replace the right-hand side(s) (same shape as at construction)."""

@@ -73,7 +73,7 @@ class ConditionalDistribution:
             eng, other = gp._engine, None
         else:
             # different kernel: its generator matrices at the observed times and at t*
-            other = DeviceBatch([self.kernel.get_device_coefficients()], gp._engine.t,
+            other = DeviceBatch([self.kernel.get_device_coefficients()], gp._t,
                                 device=gp._engine.device)
             eng = other
         ts, Us, Vs = eng.matrices_at(xs)
@@ -269,9 +269,14 @@ class GaussianProcess:
         if self._factor is None:
             if self._t is None:
                 raise RuntimeError("The process must be initialized with compute")
-            self._factor = DeviceBatch([self.kernel.get_device_coefficients()], self._t,
-                                       diag=self._diag, device=self._device)
-            info = self._factor.factor(keep_W=True)
+            if self._fast is not None:
+                # time-parallel factorisation kept in scaled form
+                self._factor = self._fast.stored_factor()
+                info = self._fast.info
+            else:
+                self._factor = DeviceBatch([self.kernel.get_device_coefficients()], self._t,
+                                           diag=self._diag, device=self._device)
+                info = self._factor.factor(keep_W=True)
             if int(info[0].item()) and np.isfinite(self._log_det):
                 raise LinAlgError("failed to factorize or solve matrix")
         return self._factor

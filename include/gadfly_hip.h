@@ -154,7 +154,10 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
  *   3. gf_chunk_combine    sequential LFT combine over the chunks (64x64 pivoted solves in LDS):
  *                          S_state/F_state slot c <- TRUE start state of chunk c.
  *   4. gf_chunk_sweep      final pass from those states (r_out = NULL): d, z equal the
- *                          sequential result to rounding; reduce with gf_reduce_tile.
+ *                          sequential result to rounding; reduce with gf_reduce_tile.  With
+ *                          Ut_out, Wt_out [B][N][64] and de_out [B][N] the pass also stores the
+ *                          factor in scaled form (rows u~, w~ = r/d and the reset spans) for
+ *                          gf_chunk_linear.
  * Same argument conventions and padding rules as gf_loglike_fused; dbar and rbar must be
  * readable two rows past the end.  Width 1..63, phases |d t| < 1.6e6.
  */
@@ -164,7 +167,8 @@ int gf_chunk_sweep(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc,
                    const double *diag_add, const double *cmax,
                    const double *t, int64_t t_bs, const double *diag, int64_t diag_bs,
                    const double *y, int64_t y_bs,
-                   double *d, double *z, double *r_out, double *S_state, double *F_state,
+                   double *d, double *z, double *r_out, double *Ut_out, double *Wt_out,
+                   double *de_out, double *S_state, double *F_state,
                    int32_t *info, void *stream);
 int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc, int block,
                         const double *ar, const double *cr, const double *ac,
@@ -175,6 +179,27 @@ int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int Jr, in
                         void *stream);
 int gf_chunk_combine(int B, int nch, const double *Phi, const double *G, const double *m,
                      double *S_state, double *F_state, void *stream);
+
+/*
+ * Triangular sweeps on the stored scaled factor, time-parallel (same modes as gf_solve):
+ *   gf_chunk_linear(store=0)   local pass: every chunk from F_state (zeroed by the caller),
+ *                              leaves its end state there; nothing else is written.
+ *   gf_chunk_linear_combine    F_state slot c <- true start state of chunk c.  GF_SOLVE_LOWER /
+ *                              GF_SOLVE_UPPER need Phi [B*nch][64*64], the chunk transitions of the
+ *                              TRUE factor (gf_chunk_transition run on the final pass' d, z, r
+ *                              rows; the backward sweep uses its transpose); GF_MATMUL_LOWER
+ *                              needs c, de and D_work [B*nch][64] instead.
+ *   gf_chunk_linear(store=1)   final pass: Z rows.
+ * Y, Z are [B][N][R] (Z may alias Y); F_state is [B*nch][64*R]; scale != 0 divides the input
+ * rows by d (solves) or multiplies them by sqrt(d) (GF_MATMUL_LOWER), as in gf_solve.
+ */
+int gf_chunk_linear(int mode, int B, int64_t N, int64_t chunk_len, int nch, int W, int R,
+                    int scale, int store, const double *c,
+                    const double *Ut, const double *Wt, const double *d, const double *de,
+                    const double *Y, double *Z, double *F_state, void *stream);
+int gf_chunk_linear_combine(int mode, int B, int64_t N, int64_t chunk_len, int nch, int W, int R,
+                            const double *c, const double *de, const double *Phi,
+                            double *D_work, double *F_state, void *stream);
 
 /*
  * Log-likelihood reductions (fixed-shape tree, deterministic):
