@@ -60,7 +60,7 @@ SIGNATURES = {
     "gf_solve": (_int, [_int, _int, _i64, _int, _int, _int] + [_vp] * 6 + [_vp]),
     "gf_general_matmul": (_int, [_int, _i64, _i64, _int, _int, _vp,
                                  _vp, _i64, _vp, _vp,
-                                 _vp, _i64, _vp, _vp, _vp, _vp,
+                                 _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                                  _vp, _vp, _vp]),
 }
 

@@ -1727,11 +1727,16 @@ struct GmmArgs {
     const double *U1, *V1;
     const double *t2; int64_t t2_bs;
     const double *U2, *V2, *P2, *alpha;
+    const int64_t *qidx;            // [B][M]: number of observed rows with t2 <= t1[m]
     double *work;
 };
 
+// Rows are streamed in unrolled blocks of GB (all loads of a block are issued before its
+// FMAs: one dependent FMA per row instead of one memory round trip per row); a query is
+// emitted when the sweep passes its row:  lower: after row qidx-1;  upper: after row qidx.
 template <int CT>
 __global__ void __launch_bounds__(64) k_gmm(const GmmArgs A) {
+    constexpr int GB = 8;
     const int lane = threadIdx.x, b = blockIdx.x, dir = blockIdx.y;
     const int64_t M = A.M, N = A.N;
     const int ld = A.ld;
@@ -1741,70 +1746,112 @@ __global__ void __launch_bounds__(64) k_gmm(const GmmArgs A) {
     const double *__restrict__ G2 = (dir == 0 ? A.V2 : A.U2) + (size_t)b * N * ld;   // data-side rows
     const double *__restrict__ P2 = A.P2 + (size_t)b * N * ld;
     const double *__restrict__ al = A.alpha + (size_t)b * N;
+    const int64_t *__restrict__ qi = A.qidx + (size_t)b * M;
     double *out = A.work + ((size_t)b * 2 + dir) * M;
     bool colok[CT];
+    int col[CT];
     double F[CT], cj[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const int j = c * 64 + lane;
         colok[c] = j < A.W;
+        col[c] = colok[c] ? j : 0;      // pad lanes re-read column 0 and are masked in registers
         F[c] = 0.0;
         cj[c] = colok[c] ? A.c[(size_t)b * A.W + j] : 0.0;
     }
-    bool have = false;
-    double last = 0.0;
+    auto emit = [&](int64_t m, double tdata) {
+        const double dt = (dir == 0) ? (tdata - t1[m]) : (t1[m] - tdata);   // <= 0
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+            if (colok[c]) acc = fma(Q1[(size_t)m * ld + col[c]] * exp(cj[c] * dt), F[c], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) out[m] = acc;
+    };
     if (dir == 0) {
+        int64_t m = 0;
+        while (m < M && qi[m] == 0) { if (lane == 0) out[m] = 0.0; ++m; }
+        int64_t next = (m < M) ? qi[m] : (N + 1);          // emit after row next-1
         int64_t n = 0;
-        for (int64_t m = 0; m < M; ++m) {
-            const double tm = t1[m];
-            while (n < N && t2[n] <= tm) {
-                const double an = al[n];
+        for (; n + GB <= N; n += GB) {
+            double pr[GB][CT], gr[GB][CT], an[GB];
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+                an[k] = al[n + k];
 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
-                    if (colok[c]) {
-                        const size_t o = (size_t)n * ld + c * 64 + lane;
-                        const double pj = have ? P2[o] : 1.0;    // exp(c (t2[n-1] - t2[n]))
-                        F[c] = fma(pj, F[c], G2[o] * an);
-                    }
+                    const size_t o = (size_t)(n + k) * ld + col[c];
+                    pr[k][c] = P2[o];                       // exp(c (t2[n-1] - t2[n])); row 0: 1
+                    gr[k][c] = G2[o];
                 }
-                last = t2[n]; have = true; ++n;
             }
-            double acc = 0.0;
-            if (have) {
-                const double dt = last - tm;
 #pragma unroll
-                for (int c = 0; c < CT; ++c)
-                    if (colok[c]) acc = fma(Q1[(size_t)m * ld + c * 64 + lane] * exp(cj[c] * dt), F[c], acc);
-                acc = wave_sum(acc);
+            for (int k = 0; k < GB; ++k) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c) F[c] = colok[c] ? fma(pr[k][c], F[c], gr[k][c] * an[k]) : 0.0;
+                while (next == n + k + 1) {                 // wave-uniform, rare
+                    emit(m, t2[n + k]);
+                    ++m;
+                    next = (m < M) ? qi[m] : (N + 1);
+                }
             }
-            if (lane == 0) out[m] = acc;
+        }
+        for (; n < N; ++n) {
+            const double a1 = al[n];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const size_t o = (size_t)n * ld + col[c];
+                F[c] = colok[c] ? fma(P2[o], F[c], G2[o] * a1) : 0.0;
+            }
+            while (next == n + 1) {
+                emit(m, t2[n]);
+                ++m;
+                next = (m < M) ? qi[m] : (N + 1);
+            }
         }
     } else {
+        int64_t m = M - 1;
+        while (m >= 0 && qi[m] == N) { if (lane == 0) out[m] = 0.0; --m; }
+        int64_t next = (m >= 0) ? qi[m] : -1;               // emit after row next (descending)
         int64_t n = N - 1;
-        for (int64_t m = M - 1; m >= 0; --m) {
-            const double tm = t1[m];
-            while (n >= 0 && t2[n] > tm) {
-                const double an = al[n];
+        for (; n - GB + 1 >= 0; n -= GB) {
+            double pr[GB][CT], gr[GB][CT], an[GB];
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+                const int64_t r = n - k;
+                an[k] = al[r];
 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
-                    if (colok[c]) {
-                        const size_t o = (size_t)n * ld + c * 64 + lane;
-                        // exp(c (t2[n] - t2[n+1])) is propagator row n+1
-                        const double pj = have ? P2[o + ld] : 1.0;
-                        F[c] = fma(pj, F[c], G2[o] * an);
-                    }
+                    const size_t o = (size_t)r * ld + col[c];
+                    // exp(c (t2[r] - t2[r+1])) is propagator row r+1 (the last row decays nothing)
+                    pr[k][c] = (r + 1 < N) ? P2[o + ld] : 1.0;
+                    gr[k][c] = G2[o];
                 }
-                last = t2[n]; have = true; --n;
             }
-            double acc = 0.0;
-            if (have) {
-                const double dt = tm - last;
 #pragma unroll
-                for (int c = 0; c < CT; ++c)
-                    if (colok[c]) acc = fma(Q1[(size_t)m * ld + c * 64 + lane] * exp(cj[c] * dt), F[c], acc);
-                acc = wave_sum(acc);
+            for (int k = 0; k < GB; ++k) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c) F[c] = colok[c] ? fma(pr[k][c], F[c], gr[k][c] * an[k]) : 0.0;
+                while (next == n - k) {
+                    emit(m, t2[n - k]);
+                    --m;
+                    next = (m >= 0) ? qi[m] : -1;
+                }
             }
-            if (lane == 0) out[m] = acc;
+        }
+        for (; n >= 0; --n) {
+            const double a1 = al[n];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const size_t o = (size_t)n * ld + col[c];
+                const double pj = (n + 1 < N) ? P2[o + ld] : 1.0;
+                F[c] = colok[c] ? fma(pj, F[c], G2[o] * a1) : 0.0;
+            }
+            while (next == n) {
+                emit(m, t2[n]);
+                --m;
+                next = (m >= 0) ? qi[m] : -1;
+            }
         }
     }
 }
@@ -2175,18 +2222,18 @@ int gf_general_matmul(int B, int64_t M, int64_t N, int W, int ld,
                       const double *c,
                       const double *t1, int64_t t1_bs, const double *U1, const double *V1,
                       const double *t2, int64_t t2_bs, const double *U2, const double *V2,
-                      const double *P2, const double *alpha,
+                      const double *P2, const double *alpha, const int64_t *qidx,
                       double *work, double *mu, void *stream) {
     if (B < 1 || N < 1 || M < 1) return set_err("gf_general_matmul: empty problem (M=%s%lld, N=%lld)", "", M, N);
     if (W < 1 || W > GF_MAX_WIDTH) return set_err("gf_general_matmul: width %s%lld unsupported (max %lld)", "", W, GF_MAX_WIDTH);
     if (ld < W || (ld & 15)) return set_err("gf_general_matmul: ld=%s%lld must be a multiple of 16 and >= W=%lld", "", ld, W);
-    if (!c || !t1 || !U1 || !V1 || !t2 || !U2 || !V2 || !P2 || !alpha || !work || !mu)
+    if (!c || !t1 || !U1 || !V1 || !t2 || !U2 || !V2 || !P2 || !alpha || !qidx || !work || !mu)
         return set_err("gf_general_matmul: null pointer%s", "");
     GmmArgs A;
     A.M = M; A.N = N; A.W = W; A.ld = ld; A.c = c;
     A.t1 = t1; A.t1_bs = t1_bs; A.U1 = U1; A.V1 = V1;
     A.t2 = t2; A.t2_bs = t2_bs; A.U2 = U2; A.V2 = V2; A.P2 = P2; A.alpha = alpha;
-    A.work = work;
+    A.qidx = qidx; A.work = work;
     hipStream_t st = (hipStream_t)stream;
     if (W <= 64)       hipLaunchKernelGGL(k_gmm<1>, dim3(B, 2), dim3(64), 0, st, A);
     else if (W <= 128) hipLaunchKernelGGL(k_gmm<2>, dim3(B, 2), dim3(64), 0, st, A);

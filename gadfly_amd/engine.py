@@ -261,11 +261,14 @@ class DeviceBatch:
         f64 = dict(dtype=torch.float64, device=self.device)
         work = torch.empty((B * 2 * M,), **f64)
         mu = torch.empty((B, M), **f64)
+        # number of observed rows at or before each query time (device searchsorted)
+        qidx = torch.searchsorted(self.t.expand(B, N).contiguous(),
+                                  ts.expand(B, M).contiguous(), right=True).contiguous()
         p = _lib.ptr
         st = self.lib.gf_general_matmul(
             B, M, N, src.W, src.ld, p(src.c),
             p(ts), self._bs(ts), p(Us), p(Vs),
-            p(self.t), self._bs(self.t), p(src.U), p(src.V), p(src.P), p(alpha),
+            p(self.t), self._bs(self.t), p(src.U), p(src.V), p(src.P), p(alpha), p(qidx),
             p(work), p(mu), self._stream())
         _lib.check(st, "gf_general_matmul")
         return mu

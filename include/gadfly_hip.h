@@ -235,13 +235,14 @@ int gf_solve(int mode, int B, int64_t N, int W, int ld, int R,
  *   mu[m] = sum_{t2[n] <= t1[m]} (U1[m] o e^{-c (t1[m]-t2[n])}) . V2[n] alpha[n]
  *         + sum_{t2[n] >  t1[m]} (V1[m] o e^{-c (t2[n]-t1[m])}) . U2[n] alpha[n]
  *   c [B][W]; U1, V1 [B][M][ld]; U2, V2, P2 [B][N][ld]; t1 [B|1][M]; t2 [B|1][N]
+ *   qidx [B][M] (int64): number of observed rows with t2 <= t1[m] (searchsorted, side "right");
  *   work: B * 2 * M doubles.
  */
 int gf_general_matmul(int B, int64_t M, int64_t N, int W, int ld,
                       const double *c,
                       const double *t1, int64_t t1_bs, const double *U1, const double *V1,
                       const double *t2, int64_t t2_bs, const double *U2, const double *V2,
-                      const double *P2, const double *alpha,
+                      const double *P2, const double *alpha, const int64_t *qidx,
                       double *work, double *mu, void *stream);
 
 #ifdef __cplusplus
