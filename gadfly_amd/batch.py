@@ -55,7 +55,8 @@ class BatchedLogLikelihood:
         eng = self.engine
         if pack is not None:
             eng.use_coefficients(pack)
-        return eng.log_likelihood()
+        # small batches of long series are chunked in time as well (exact, see engine.evaluate)
+        return eng.evaluate()[0]
 
     def evaluate(self, kernels=None):
         out = self.evaluate_device(None if kernels is None else self.pack(kernels))

@@ -634,9 +634,11 @@ class StreamingBatch:
         N, B = self.N, self.B
         block = self._pack[5]
         if chunk_len is None:
-            # ~128 chunks per problem: beyond that the (sequential, ~0.12 ms/chunk) combine
-            # outweighs the shorter sweeps (measured at N = 1e6, W = 60: DESIGN.md 4.3)
-            chunk_len = max(1024, -(-N // max(1, 128 // B)))
+            # enough chunks to put ~1536 waves in flight (B * nch), but at most ~128 per
+            # problem: beyond that the sequential ~0.12 ms/chunk combine outweighs the shorter
+            # sweeps (measured at N = 1e6, W = 60: DESIGN.md 4.3)
+            nch = min(128, max(1, 1536 // B))
+            chunk_len = max(1024, -(-N // nch))
         chunk_len = max(block, (int(chunk_len) + 63) // 64 * 64)
         return chunk_len, -(-N // chunk_len)
 
@@ -741,7 +743,9 @@ class StreamingBatch:
         """(loglike (B,), logdet (B,)) device tensors; picks the time-parallel evaluation for
         few long series (B * N large per problem, B small) unless told otherwise."""
         if time_parallel is None:
-            time_parallel = self._fused_ok() and self.B <= 16 and self.N >= 16384
+            # chunking costs ~3.5x the flops: it pays while the batch alone fills less than
+            # ~1/8 of the 2048 wave slots
+            time_parallel = self._fused_ok() and self.B <= 128 and self.N >= 8192
         if time_parallel and self._fused_ok():
             out = self.log_likelihood_time_parallel()
             acc = self._tp["acc"] if getattr(self, "_tp_key", None) and self._tp_used else self.acc
