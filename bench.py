@@ -37,8 +37,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1_000_000, help="cadences per light curve")
-    ap.add_argument("--j", type=int, default=30, help="SHO terms (celerite width = 2J)")
+    ap.add_argument("--rows", "--n", dest="n", type=int, default=1_000_000,
+                    help="cadences per light curve")
+    ap.add_argument("--terms", "--j", dest="j", type=int, default=30,
+                    help="SHO terms (celerite width = 2J)")
     ap.add_argument("--evals", type=int, default=2048,
                     help="independent evaluations (walkers) per rank per step")
     ap.add_argument("--tile-rows", type=int, default=8192, help="rows per streamed tile")
@@ -66,13 +68,20 @@ def main():
                          "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # one rank per GPU; (local % device_count only matters when rehearsing N ranks on fewer GPUs)
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     dist = None
+    # "nccl" is RCCL on ROCm; GADFLY_BENCH_BACKEND=gloo is for rehearsals on a single GPU
+    backend = os.environ.get("GADFLY_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
 
     N, J, E = args.n, args.j, args.evals
     W = 2 * J
@@ -116,7 +125,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64,
+                            device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
