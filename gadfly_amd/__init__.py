@@ -7,8 +7,9 @@ call does, and fails loudly without them (no CPU fallback).
 """
 from .core import (  # noqa: F401
     Hyperparameters, StellarOscillatorKernel, SolarOscillatorKernel,
-    ShotNoiseKernel,
+    ShotNoiseKernel, Filter,
 )
+from . import scale  # noqa: F401
 from .gp import GaussianProcess, ConditionalDistribution, LinAlgError  # noqa: F401
 from .batch import BatchedLogLikelihood, log_likelihood_batch  # noqa: F401
 from . import terms  # noqa: F401

@@ -9,11 +9,11 @@ core.py:19-25) for the GP hot path: same constructor signatures, attribute names
 the default-exposure warning (core.py:381-390).  The celerite term algebra the
 reference inherits from ``celerite2.terms`` lives in :mod:`gadfly_amd.terms`.
 
-Out of scope this round: the asteroseismic scaling
-relations behind ``Hyperparameters.for_star`` (reference core.py:107-333 +
-scale.py, need astropy.modeling and tynt).  ``for_star`` therefore delegates to
-an optional ``gadfly_amd.scale`` module and raises ``NotImplementedError`` when it
-is absent; ``Filter`` and the PSD plotting helpers are not part of the path.
+The asteroseismic scaling relations behind ``Hyperparameters.for_star`` (reference
+core.py:107-333 + scale.py) live in :mod:`gadfly_amd.scale` as a unit-free port
+(scipy instead of astropy.modeling); named ``tynt`` bandpasses need ``tynt``, the
+bolometric "SOHO VIRGO" pseudo-filter and user-supplied curves do not.  The PSD
+plotting helpers are not part of the path (gadfly/psd.py is left as-is).
 """
 import json
 import os
@@ -22,12 +22,14 @@ import numpy as np
 
 from . import terms as _terms
 from . import units as _units
+from .scale import Filter  # noqa: F401  (reference core.py exports Filter)
 
 __all__ = [
     "Hyperparameters",
     "StellarOscillatorKernel",
     "SolarOscillatorKernel",
     "ShotNoiseKernel",
+    "Filter",
 ]
 
 dirname = os.path.dirname(os.path.abspath(__file__))
@@ -84,19 +86,11 @@ class Hyperparameters(list):
                  bandpass=None, name=None, quiet=False, magnitude=None):
         """Asteroseismic scaling of the solar fit (reference core.py:107-333).
 
-        Host-side, run once per star, outside the GP hot path: delegated to the
-        optional :mod:`gadfly_amd.scale` port.
+        Host-side, run once per star, outside the GP hot path: see
+        :func:`gadfly_amd.scale.hyperparameters_for_star` (masses, radii, luminosities in
+        solar units, temperature in K, or astropy Quantities).
         """
-        try:
-            from . import scale as _scale
-        except ImportError as err:
-            raise NotImplementedError(
-                "Hyperparameters.for_star needs the asteroseismic scaling "
-                "relations (reference scale.py), which are outside the GP hot "
-                "path and not part of this build yet; construct Hyperparameters "
-                "from explicit (S0, w0, Q) triples, or use "
-                "gadfly_amd.synth.solar_like_hyperparameters()."
-            ) from err
+        from . import scale as _scale
         return _scale.hyperparameters_for_star(
             cls, mass, radius, temperature, luminosity, bandpass=bandpass,
             name=name, quiet=quiet, magnitude=magnitude)

@@ -83,8 +83,10 @@ def test_kernel_api_surface():
     raw = gadfly_amd.Hyperparameters.from_soho_virgo()
     assert len(raw) == 9 and raw.name == "SOHO VIRGO/PMO6"
     assert "w0" not in raw[5]["hyperparameters"]
-    with pytest.raises(NotImplementedError):
-        gadfly_amd.SolarOscillatorKernel(texp=60.0)
+    with pytest.raises(ValueError, match="tynt"):          # default Kepler bandpass needs tynt
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            gadfly_amd.SolarOscillatorKernel(texp=60.0)
     lo, up = gadfly_amd.ShotNoiseKernel.kepler_mag_to_noise_amplitude(12.0)
     assert 0 < lo < up
 
@@ -96,3 +98,54 @@ def test_get_psd_matches_sum_of_sho_with_exposure():
     w = 2 * np.pi * np.linspace(3.0, 4000.0, 300)
     ref = sum(_sho_psd(w, **p["hyperparameters"]) for p in hp) * np.sinc(0.5 * k.delta * w / np.pi) ** 2
     np.testing.assert_allclose(k.get_psd(w), ref, rtol=1e-12)
+
+
+def test_scaling_relations_to_solar():
+    """reference gadfly/tests/test_core.py:54-66"""
+    from gadfly_amd import scale
+    ones = np.array([scale.amplitude_with_wavelength("SOHO VIRGO", 5777.0),
+                     scale.nu_max(1.0, 5777.0, 1.0), scale.delta_nu(1.0, 1.0),
+                     scale.tau_gran(1.0, 5777.0, 1.0), scale.granulation_amplitude(1.0, 5777.0, 1.0),
+                     scale.p_mode_amplitudes(1.0, 5777.0, 1.0), scale.tau_eff(3090.0)])
+    np.testing.assert_allclose(ones, np.ones_like(ones))
+    assert scale.amplitude_with_wavelength("SOHO VIRGO", 5777.0) == 1      # test_core.py:70
+    # a Kepler-like top hat (0.43-0.89 micron) lands near the tynt Kepler value 2.795 (test_core.py:71-73)
+    wl = np.linspace(0.3, 1.1, 400)
+    alpha = scale.amplitude_with_wavelength((wl, ((wl > 0.43) & (wl < 0.89)).astype(float)), 5777.0)
+    assert 2.4 < alpha < 3.2
+    assert np.isclose(scale.c_K(5934.0), 1.0)
+    # the Kiefer envelope is 1 at nu_max by construction and decays away from it
+    env = scale.p_mode_intensity(5777.0, np.array([3090.0, 2000.0, 4500.0]), 3090.0, 135.1)
+    assert np.isclose(env[0], 1.0) and 0 < env[1] < 1 and 0 < env[2] < 1
+
+
+def test_solar_kernel_for_star():
+    """SolarOscillatorKernel = for_star at solar parameters (reference core.py:430-461):
+    5 granulation terms verbatim + 81 Broomhall modes with the solar-case reduction."""
+    import json
+    from gadfly_amd.core import default_hyperparameter_path, _sho_psd
+    k = gadfly_amd.SolarOscillatorKernel(texp=60.0, bandpass="SOHO VIRGO")
+    hp = k.hyperparameters
+    assert len(hp) == 86 and len(k) == 172
+    raw = json.load(open(default_hyperparameter_path))
+    for got, want in zip(hp[:5], raw[:5]):
+        assert got["hyperparameters"] == want["hyperparameters"]
+    from gadfly_amd.scale import broomhall_p_mode_freqs
+    nu, ell = broomhall_p_mode_freqs()
+    osc = {r["metadata"]["degree"]: r["hyperparameters"] for r in raw[5:]}
+    for j, p in enumerate(hp[5:]):
+        h, o = p["hyperparameters"], osc[int(ell[j])]
+        assert np.isclose(h["w0"], 2 * np.pi * nu[j])
+        Gamma = nu[j] / (2 * o["Q"])
+        assert np.isclose(h["Q"], o["Q"] * 1.02 / Gamma)
+        assert h["S0"] > 0 and p["metadata"]["degree"] == int(ell[j])
+    # the strongest modes sit near nu_max (envelope)
+    S0 = np.array([p["hyperparameters"]["S0"] * p["hyperparameters"]["Q"] ** 2 for p in hp[5:]])
+    assert abs(nu[np.argmax(S0)] - 3090.0) < 400.0
+    # other stars scale nu_max
+    hp2 = gadfly_amd.Hyperparameters.for_star(1.2, 1.5, 6000.0, 3.0, bandpass="SOHO VIRGO", name="x")
+    assert hp2.name == "x" and len(hp2) == 86
+    w = np.array([p["hyperparameters"]["w0"] for p in hp2[5:]])
+    from gadfly_amd import scale
+    assert np.isclose(np.median(w) / np.median(2 * np.pi * nu),
+                      scale.nu_max(1.2, 6000.0, 1.5), rtol=0.1)
