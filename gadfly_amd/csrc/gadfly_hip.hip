@@ -97,6 +97,15 @@ __device__ __forceinline__ double wave_max(double v) {
     return fmax(fmax(r1, r2), fmax(r3, r4));
 }
 
+// 1/x for normal positive x: hardware estimate + two Newton steps (error <= ~1 ulp); the
+// IEEE division sequence costs ~14 VALU instructions on a path every row waits for.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 // Order LDS traffic of ONE wave: lane-form writes before uniform (broadcast) reads.
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS operations of one wave execute in issue order, so wavefront scope (a pure
@@ -888,7 +897,7 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
             fail = (int32_t)(gf > 0x7fffffff ? 0x7fffffff : gf);
             break;
         }
-        const double inv = 1.0 / dn;
+        const double inv = fast_rcp(dn);
         zq = zn * inv;
         q = fl ? zq : r * inv;
         if (rg) rg[(size_t)n * 64] = r;             // r~ rows for k_phi (chunk mode)
@@ -1059,249 +1068,430 @@ k_gram(const int64_t N, const int64_t chunk_len, const int nch,
     }
 }
 
+// ---- dense 64x64 helpers for the chunk combines (one workgroup of 256 threads) ---------------
+// LDS matrices are row-major with leading dimension CB_LD (conflict-free rows); global
+// matrices are stored [j][i] (column-major = the lane-major layout of the sweep states).
+constexpr int CB_LD = 65, CB_LA = 130;
+
+__device__ __forceinline__ void cb_load(double *dst, const double *__restrict__ src, int tid,
+                                        int ld = CB_LD) {
+    _Pragma("unroll 16")
+    for (int e = tid; e < 4096; e += 256) { const int j = e >> 6, i = e & 63; dst[i * ld + j] = src[e]; }
+}
+
+// acc[a][c] (+)= sum_k A[4ty+a][k] * B[k][4tx+c]   (TB: use B^T, i.e. B[4tx+c][k])
+template <bool TA, bool TB>
+__device__ __forceinline__ void cb_matmul(double (&acc)[4][4], const double *A, int lda,
+                                          const double *B, int ldb, int tx, int ty) {
+    for (int k = 0; k < 64; ++k) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            av[a] = TA ? A[k * lda + 4 * ty + a] : A[(4 * ty + a) * lda + k];
+            bv[a] = TB ? B[(4 * tx + a) * ldb + k] : B[k * ldb + 4 * tx + a];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a][c] = fma(av[a], bv[c], acc[a][c]);
+    }
+}
+
+__device__ __forceinline__ void cb_store_lds(double *dst, int ld, const double (&acc)[4][4], int tx, int ty) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dst[(4 * ty + a) * ld + 4 * tx + c] = acc[a][c];
+}
+
+// Gauss-Jordan with IMPLICIT partial pivoting on the 64 x 129 augmented system Au = [A | RHS],
+// held in registers: thread (rgp, jj) owns rows rgp*8..+7 x columns {jj, jj+32, jj+64, jj+96}
+// (+ column 128 for jj == 0).  Per step only the pivot column (for the search) and the pivot
+// row travel through LDS (scratch >= 400 doubles); rows are never swapped or normalised,
+// eliminated columns are never revisited.  Every wave repeats the 64-candidate DPP arg-max, so
+// a step needs two barriers.  On exit Au[:, 64:129] = A^-1 RHS.
+__device__ __forceinline__ void cb_gauss_jordan(double *Au, double *scratch, int tid) {
+    constexpr int LA = CB_LA;
+    const int jj = tid & 31, rgp = tid >> 5, lane = tid & 63;
+    double *pcol = scratch;                 // [64]  candidate column
+    double *prow = scratch + 64;            // [129] pivot row
+    double *pinvr = scratch + 64 + 136;     // [64]  1 / pivot of the row
+    int *rowvar = reinterpret_cast<int *>(scratch + 64 + 136 + 64);     // [64] variable solved by row
+    double R[8][5];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int cc = 0; cc < 5; ++cc) {
+            const int j = (cc < 4) ? (jj + 32 * cc) : 128;
+            R[a][cc] = (cc < 4 || jj == 0) ? Au[(rgp * 8 + a) * LA + j] : 0.0;
+        }
+    bool used = false;                      // lane-form: row `lane` already served as a pivot
+    __syncthreads();
+    if (jj == 0) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) pcol[rgp * 8 + a] = R[a][0];
+    }
+    __syncthreads();
+    for (int k = 0; k < 64; ++k) {
+        const double cand = used ? -1.0 : fabs(pcol[lane]);
+        const double vm = wave_max(cand);
+        const unsigned long long hit = __ballot(cand == vm);
+        const int pv = (int)__ffsll((long long)hit) - 1;
+        if (lane == pv) used = true;
+        if ((pv >> 3) == rgp) {             // owners of row pv publish it
+            const int a = pv & 7;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                double v = 0.0;
+#pragma unroll
+                for (int a2 = 0; a2 < 8; ++a2) v = (a2 == a) ? R[a2][cc] : v;
+                prow[jj + 32 * cc] = v;
+            }
+            if (jj == 0) {
+                double v = 0.0;
+#pragma unroll
+                for (int a2 = 0; a2 < 8; ++a2) v = (a2 == a) ? R[a2][4] : v;
+                prow[128] = v;
+            }
+        }
+        if (tid == 0) rowvar[pv] = k;
+        __syncthreads();
+        const double pinv = 1.0 / prow[k];
+        if (tid == 0) pinvr[pv] = pinv;
+        double fr[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const int i = rgp * 8 + a;
+            fr[a] = (i == pv) ? 0.0 : pcol[i] * pinv;
+        }
+        const int kn = k + 1;
+#pragma unroll
+        for (int cc = 0; cc < 5; ++cc) {
+            const int j = (cc < 4) ? (jj + 32 * cc) : 128;
+            if (j > k && (cc < 4 || jj == 0)) {
+                const double pk = prow[j];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) R[a][cc] = fma(-fr[a], pk, R[a][cc]);
+            }
+        }
+        __syncthreads();                    // everyone is done with pcol / prow
+        if (kn < 64 && jj == (kn & 31)) {
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                double v = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) v = (cc == (kn >> 5)) ? R[a][cc] : v;
+                pcol[rgp * 8 + a] = v;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {           // variable rowvar[i] = (right part of row i) / pivot(i)
+        const int i = rgp * 8 + a;
+        const int kv = rowvar[i];
+        const double sc = pinvr[i];
+        Au[kv * LA + 64 + jj] = R[a][2] * sc;
+        Au[kv * LA + 96 + jj] = R[a][3] * sc;
+        if (jj == 0) Au[kv * LA + 128] = R[a][4] * sc;
+    }
+    __syncthreads();
+}
+
+// One application of a chunk map to a state, in LDS:  on entry Xs = X, Ys = Y (LDS); Phi, G, m,
+// Xbar, Ybar of the map are read from global.  On exit Xs = X+, Ys = Y+.
+//   A = I - X G ;  [K | v] = A^-1 [X | Y - X m] ;  X+ = Xbar + Phi K Phi^T ;  Y+ = Ybar + Phi v
+__device__ __forceinline__ void cb_apply(double *Xs, double *Au, double *Bs, double *Ys, double *vs,
+                                         const double *__restrict__ Pg, const double *__restrict__ Gg,
+                                         const double *__restrict__ mg, const double *__restrict__ Xbar,
+                                         const double *__restrict__ Ybar, const double (&xreg)[16],
+                                         const double yreg, int tid) {
+    // Xbar/Ybar: global pointers, or nullptr to take them from registers (xreg[q] = element
+    // e = tid + 256 q of the [j][i] layout, yreg = element tid)
+    constexpr int LD = CB_LD, LA = CB_LA;
+    const int tx = tid & 15, ty = tid >> 4;
+    cb_load(Bs, Gg, tid);
+    if (tid < 64) vs[tid] = mg[tid];
+    __syncthreads();
+    {
+        double acc[4][4] = {};
+        cb_matmul<false, false>(acc, Xs, LD, Bs, LD, tx, ty);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int i = 4 * ty + a, j = 4 * tx + cc;
+                Au[i * LA + j] = ((i == j) ? 1.0 : 0.0) - acc[a][cc];
+                Au[i * LA + 64 + j] = Xs[i * LD + j];
+            }
+    }
+    if (tid < 64) {                         // rhs = Y - X m
+        double sacc = Ys[tid];
+        for (int k = 0; k < 64; ++k) sacc = fma(-Xs[tid * LD + k], vs[k], sacc);
+        Au[tid * LA + 128] = sacc;
+    }
+    __syncthreads();
+    cb_gauss_jordan(Au, Bs, tid);
+    // Bs <- Phi ; Xs <- Z = Phi K  (K symmetrised)
+    cb_load(Bs, Pg, tid);
+    if (tid < 64) vs[tid] = Au[tid * LA + 128];
+    __syncthreads();
+    {
+        double acc[4][4] = {};
+        for (int k = 0; k < 64; ++k) {
+            double pa[4], kb[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                pa[a] = Bs[(4 * ty + a) * LD + k];
+                kb[a] = 0.5 * (Au[k * LA + 64 + 4 * tx + a] + Au[(4 * tx + a) * LA + 64 + k]);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) acc[a][cc] = fma(pa[a], kb[cc], acc[a][cc]);
+        }
+        __syncthreads();
+        cb_store_lds(Xs, LD, acc, tx, ty);
+    }
+    double ynew = 0.0;
+    if (tid < 64) {                         // Y+ = Ybar + Phi v
+        ynew = Ybar ? Ybar[tid] : yreg;
+        for (int k = 0; k < 64; ++k) ynew = fma(Bs[tid * LD + k], vs[k], ynew);
+    }
+    __syncthreads();
+    {                                       // X+ = Xbar + Z Phi^T  -> Au left half as staging
+        double acc[4][4] = {};
+        cb_matmul<false, true>(acc, Xs, LD, Bs, LD, tx, ty);
+        __syncthreads();
+        cb_store_lds(Au, LA, acc, tx, ty);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {              // add Xbar (coalesced) and symmetrise
+        const int e = tid + 256 * q, j = e >> 6, i = e & 63;
+        Xs[i * LD + j] = (Xbar ? Xbar[e] : xreg[q]) + 0.5 * (Au[i * LA + j] + Au[j * LA + i]);
+    }
+    if (tid < 64) Ys[tid] = ynew;
+    __syncthreads();
+}
+
 // Sequential LFT combine over the chunks of each problem (one workgroup per problem).
-// All 64x64 matrices are stored [j][i] (column-major); pad rows/columns are zero.
-//   A = I - X G ;  [K | v] = A^-1 [X | Y - X m]  (Gauss-Jordan, partial pivoting, in LDS)
-//   X+ = Xbar_c + Phi_c K Phi_c^T ;  Y+ = Ybar_c + Phi_c v
 // S_state/F_state slot c holds (Xbar_end, Ybar_end) of chunk c on entry and the TRUE start
 // state of chunk c on exit (slot 0 <- 0).
 __global__ void __launch_bounds__(256)
 k_combine(const int nch, const double *__restrict__ Phi_, const double *__restrict__ G_,
           const double *__restrict__ m_, double *__restrict__ S_state,
           double *__restrict__ F_state) {
-    constexpr int LD = 65, LA = 130;
+    constexpr int LD = CB_LD, LA = CB_LA;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *Xs = lds;                       // [64][LD]   X  (row i, col j) at Xs[i*LD + j]
-    double *Au = Xs + 64 * LD;              // [64][LA]   [A | X | rhs]
-    double *Bs = Au + 64 * LA;              // [64][LD]   temp
+    double *Xs = lds;                       // [64][LD]
+    double *Au = Xs + 64 * LD;              // [64][LA]
+    double *Bs = Au + 64 * LA;              // [64][LD]
     double *Ys = Bs + 64 * LD;              // [64]
     double *vs = Ys + 64;                   // [64]
-    __shared__ int s_piv;
     const int pr = blockIdx.x;
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int tid = threadIdx.x;
     for (int e = tid; e < 64 * LD; e += 256) Xs[e] = 0.0;
     if (tid < 64) Ys[tid] = 0.0;
     __syncthreads();
-
     for (int c = 0; c < nch; ++c) {
         const size_t slot = (size_t)pr * nch + c;
         double *Sg = S_state + slot * 4096;
         double *Fg = F_state + slot * 64;
-        const double *Pg = Phi_ + slot * 4096;
-        const double *Gg = G_ + slot * 4096;
-        const double *mg = m_ + slot * 64;
-        // this chunk's nominal end state (needed after the solve) -> registers, through LDS so
-        // that the global reads stay coalesced
-        double xbar[4][4], ybar = 0.0;
-        _Pragma("unroll 16")
-        for (int e = tid; e < 4096; e += 256) { const int j = e >> 6, i = e & 63; Bs[i * LD + j] = Sg[e]; }
-        if (tid < 64) { ybar = Fg[tid]; vs[tid] = mg[tid]; }
-        __syncthreads();
+        // keep this chunk's nominal end state, publish its TRUE start state
+        double xbar[16], ybar = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, j = e >> 6, i = e & 63;
+            xbar[q] = Sg[e];
+            Sg[e] = Xs[i * LD + j];
+        }
+        if (tid < 64) { ybar = Fg[tid]; Fg[tid] = Ys[tid]; }
+        if (c == nch - 1) break;
+        cb_apply(Xs, Au, Bs, Ys, vs, Phi_ + slot * 4096, G_ + slot * 4096, m_ + slot * 64,
+                 nullptr, nullptr, xbar, ybar, tid);
+    }
+}
+
+// ---- log-depth tree combine (Blelloch scan over the chunk maps) -----------------------------
+// Map of a chunk: M = (Phi, G, Xbar, Ybar, m).  Up-sweep: map[right] <- map[right] o map[left]
+//   D = (I - Xbar1 G2)^-1 ;  Phi12 = Phi2 D Phi1 ;  Xbar12 = Xbar2 + Phi2 D Xbar1 Phi2^T
+//   G12 = G1 + Phi1^T G2 D Phi1 ;  v = D (Ybar1 - Xbar1 m2) ;  Ybar12 = Ybar2 + Phi2 v
+//   m12 = m1 + Phi1^T (m2 - G2 v)                      (1 = left, applied first; 2 = right)
+// Down-sweep on states: s[left] <- s[right] ; s[right] <- map[left](s[right]).
+// Slots are (problem, index) with P = power-of-two indices per problem; identity maps pad.
+struct TreeArgs {
+    int P, d;                               // level: pairs (idx - d, idx), idx = (k+1) 2d - 1
+    double *Phi, *G, *S, *F, *m;            // maps [B*P][...]
+    double *Xst, *Yst;                      // states [B*P][4096] / [64]
+};
+
+__global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
+    constexpr int LD = CB_LD, LA = CB_LA;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *M0 = lds;                       // [64][LD]
+    double *Au = M0 + 64 * LD;              // [64][LA]  = AL | AR
+    double *M1 = Au + 64 * LA;              // [64][LD]
+    double *v1 = M1 + 64 * LD;              // [64] x 4 small vectors
+    const int pairs = A.P / (2 * A.d);
+    const int pr = blockIdx.x / pairs, k = blockIdx.x - pr * pairs;
+    const int ir = (k + 1) * 2 * A.d - 1, il = ir - A.d;
+    const size_t L = (size_t)pr * A.P + il, Rr = (size_t)pr * A.P + ir;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    double *w = v1, *vv = v1 + 64, *g2v = v1 + 128, *tmpv = v1 + 192;
+    // a. M0 = Xbar1, M1 = G2 ;  AL = I - Xbar1 G2 ; AR = I ; col 128 = Ybar1 - Xbar1 m2
+    cb_load(M0, A.S + L * 4096, tid);
+    cb_load(M1, A.G + Rr * 4096, tid);
+    if (tid < 64) tmpv[tid] = A.m[Rr * 64 + tid];
+    __syncthreads();
+    {
+        double acc[4][4] = {};
+        cb_matmul<false, false>(acc, M0, LD, M1, LD, tx, ty);
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) xbar[a][cc] = Bs[(4 * ty + a) * LD + 4 * tx + cc];
-        __syncthreads();
-        // publish the TRUE start state of chunk c
-        _Pragma("unroll 16")
-        for (int e = tid; e < 4096; e += 256) { const int j = e >> 6, i = e & 63; Sg[e] = Xs[i * LD + j]; }
-        if (tid < 64) Fg[tid] = Ys[tid];
-        if (c == nch - 1) break;
-        // Bs <- G ;  A = I - X G  (4x4 block per thread) ; rhs columns
-        _Pragma("unroll 16")
-        for (int e = tid; e < 4096; e += 256) { const int j = e >> 6, i = e & 63; Bs[i * LD + j] = Gg[e]; }
-        __syncthreads();
-        {
-            double acc[4][4] = {};
-            for (int k = 0; k < 64; ++k) {
-                double xa[4], gb[4];
-#pragma unroll
-                for (int a = 0; a < 4; ++a) { xa[a] = Xs[(4 * ty + a) * LD + k]; gb[a] = Bs[k * LD + 4 * tx + a]; }
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) acc[a][cc] = fma(xa[a], gb[cc], acc[a][cc]);
+            for (int c = 0; c < 4; ++c) {
+                const int i = 4 * ty + a, j = 4 * tx + c;
+                Au[i * LA + j] = ((i == j) ? 1.0 : 0.0) - acc[a][c];
+                Au[i * LA + 64 + j] = (i == j) ? 1.0 : 0.0;
             }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    const int i = 4 * ty + a, j = 4 * tx + cc;
-                    Au[i * LA + j] = ((i == j) ? 1.0 : 0.0) - acc[a][cc];
-                    Au[i * LA + 64 + j] = Xs[i * LD + j];
-                }
-        }
-        if (tid < 64) {                     // rhs = Y - X m
-            double sacc = Ys[tid];
-            for (int k = 0; k < 64; ++k) sacc = fma(-Xs[tid * LD + k], vs[k], sacc);
-            Au[tid * LA + 128] = sacc;
-        }
-        __syncthreads();
-        // Gauss-Jordan with IMPLICIT partial pivoting on the 64 x 129 augmented system, held in
-        // registers: thread (rgp, jj) owns rows rgp*8..+7 x columns {jj, jj+32, jj+64, jj+96}
-        // (+ column 128 for jj == 0).  Per step only the pivot column (for the search) and the
-        // pivot row travel through LDS; rows are never swapped or normalised, eliminated
-        // columns are never revisited.  Every wave repeats the 64-candidate DPP arg-max, so a
-        // step needs two barriers.
-        {
-            const int jj = tid & 31, rgp = tid >> 5, lane = tid & 63;
-            double *pcol = Bs;                  // [64]  candidate column
-            double *prow = Bs + 64;             // [129] pivot row
-            double *pinvr = Bs + 64 + 136;      // [64]  1 / pivot of the row
-            int *rowvar = reinterpret_cast<int *>(Bs + 64 + 136 + 64);     // [64] variable solved by row
-            double R[8][5];
-#pragma unroll
-            for (int a = 0; a < 8; ++a)
-#pragma unroll
-                for (int cc = 0; cc < 5; ++cc) {
-                    const int j = (cc < 4) ? (jj + 32 * cc) : 128;
-                    R[a][cc] = (cc < 4 || jj == 0) ? Au[(rgp * 8 + a) * LA + j] : 0.0;
-                }
-            bool used = false;                  // lane-form: row `lane` already served as a pivot
-            __syncthreads();
-            if (jj == 0) {                      // column 0 -> pcol
-#pragma unroll
-                for (int a = 0; a < 8; ++a) pcol[rgp * 8 + a] = R[a][0];
-            }
-            __syncthreads();
-            for (int k = 0; k < 64; ++k) {
-                // arg-max over unused rows (every wave, identical result)
-                const double cand = used ? -1.0 : fabs(pcol[lane]);
-                const double vm = wave_max(cand);
-                const unsigned long long hit = __ballot(cand == vm);
-                const int pv = (int)__ffsll((long long)hit) - 1;
-                if (lane == pv) used = true;
-                // owners of row pv publish it
-                if ((pv >> 3) == rgp) {
-                    const int a = pv & 7;
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) {
-                        double v = 0.0;
-#pragma unroll
-                        for (int a2 = 0; a2 < 8; ++a2) v = (a2 == a) ? R[a2][cc] : v;
-                        prow[jj + 32 * cc] = v;
-                    }
-                    if (jj == 0) {
-                        double v = 0.0;
-#pragma unroll
-                        for (int a2 = 0; a2 < 8; ++a2) v = (a2 == a) ? R[a2][4] : v;
-                        prow[128] = v;
-                    }
-                }
-                if (tid == 0) rowvar[pv] = k;
-                __syncthreads();
-                const double pinv = 1.0 / prow[k];
-                if (tid == 0) pinvr[pv] = pinv;
-                double fr[8];
-#pragma unroll
-                for (int a = 0; a < 8; ++a) {
-                    const int i = rgp * 8 + a;
-                    fr[a] = (i == pv) ? 0.0 : pcol[i] * pinv;
-                }
-                const int kn = k + 1;           // next pivot column lives in column slot kn>>5
-#pragma unroll
-                for (int cc = 0; cc < 5; ++cc) {
-                    const int j = (cc < 4) ? (jj + 32 * cc) : 128;
-                    if (j > k && (cc < 4 || jj == 0)) {
-                        const double pk = prow[j];
-#pragma unroll
-                        for (int a = 0; a < 8; ++a) R[a][cc] = fma(-fr[a], pk, R[a][cc]);
-                    }
-                }
-                __syncthreads();                // everyone is done with pcol / prow
-                if (kn < 64 && jj == (kn & 31)) {
-#pragma unroll
-                    for (int a = 0; a < 8; ++a) {
-                        double v = 0.0;
-#pragma unroll
-                        for (int cc = 0; cc < 2; ++cc) v = (cc == (kn >> 5)) ? R[a][cc] : v;
-                        pcol[rgp * 8 + a] = v;
-                    }
-                }
-                __syncthreads();
-            }
-            // solution rows: variable rowvar[i] = (right part of row i) / pivot(i)
-#pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const int i = rgp * 8 + a;
-                const int kv = rowvar[i];
-                const double sc = pinvr[i];
-                Au[kv * LA + 64 + jj] = R[a][2] * sc;
-                Au[kv * LA + 96 + jj] = R[a][3] * sc;
-                if (jj == 0) Au[kv * LA + 128] = R[a][4] * sc;
-            }
-            __syncthreads();
-        }
-        // K = Au[:, 64:128] (symmetrised), v = Au[:, 128];  Bs <- Phi ; Xs <- Z = Phi K
-        _Pragma("unroll 16")
-        for (int e = tid; e < 4096; e += 256) { const int j = e >> 6, i = e & 63; Bs[i * LD + j] = Pg[e]; }
-        if (tid < 64) vs[tid] = Au[tid * LA + 128];
-        __syncthreads();
-        {
-            double acc[4][4] = {};
-            for (int k = 0; k < 64; ++k) {
-                double pa[4], kb[4];
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    pa[a] = Bs[(4 * ty + a) * LD + k];
-                    kb[a] = 0.5 * (Au[k * LA + 64 + 4 * tx + a] + Au[(4 * tx + a) * LA + 64 + k]);
-                }
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) acc[a][cc] = fma(pa[a], kb[cc], acc[a][cc]);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) Xs[(4 * ty + a) * LD + 4 * tx + cc] = acc[a][cc];
-        }
-        double ynew = 0.0;
-        if (tid < 64) {                     // Y+ = Ybar + Phi v
-            ynew = ybar;
-            for (int k = 0; k < 64; ++k) ynew = fma(Bs[tid * LD + k], vs[k], ynew);
-        }
-        __syncthreads();
-        {                                   // X+ = Xbar + Z Phi^T
-            double acc[4][4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) acc[a][cc] = xbar[a][cc];
-            for (int k = 0; k < 64; ++k) {
-                double za[4], pb2[4];
-#pragma unroll
-                for (int a = 0; a < 4; ++a) { za[a] = Xs[(4 * ty + a) * LD + k]; pb2[a] = Bs[(4 * tx + a) * LD + k]; }
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) acc[a][cc] = fma(za[a], pb2[cc], acc[a][cc]);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) Xs[(4 * ty + a) * LD + 4 * tx + cc] = acc[a][cc];
-        }
-        if (tid < 64) Ys[tid] = ynew;
-        __syncthreads();
-        // symmetrise X (kills rounding asymmetry of the two-sided product)
-        {
-            double sym[4][4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc)
-                    sym[a][cc] = 0.5 * (Xs[(4 * ty + a) * LD + 4 * tx + cc] + Xs[(4 * tx + cc) * LD + 4 * ty + a]);
-            __syncthreads();
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) Xs[(4 * ty + a) * LD + 4 * tx + cc] = sym[a][cc];
-        }
-        __syncthreads();
     }
+    if (tid < 64) {
+        double sacc = A.F[L * 64 + tid];
+        for (int kk = 0; kk < 64; ++kk) sacc = fma(-M0[tid * LD + kk], tmpv[kk], sacc);
+        Au[tid * LA + 128] = sacc;
+    }
+    __syncthreads();
+    cb_gauss_jordan(Au, M1, tid);           // AR = D, col 128 = v   (M1 serves as scratch ...
+    cb_load(M1, A.G + Rr * 4096, tid);      // ... so G2 is loaded again)
+    if (tid < 64) vv[tid] = Au[tid * LA + 128];
+    __syncthreads();
+    if (tid < 64) {                         // g2v = G2 v ;  m12 pieces need it
+        double sacc = 0.0;
+        for (int kk = 0; kk < 64; ++kk) sacc = fma(M1[tid * LD + kk], vv[kk], sacc);
+        g2v[tid] = sacc;
+    }
+    // c. AL = D Xbar1
+    {
+        double acc[4][4] = {};
+        cb_matmul<false, false>(acc, Au + 64, LA, M0, LD, tx, ty);
+        __syncthreads();
+        cb_store_lds(Au, LA, acc, tx, ty);
+    }
+    __syncthreads();
+    // d. M0 = Phi2 ;  AL <- Phi2 (D Xbar1) ;  Xbar12 = Xbar2 + AL Phi2^T ;  Ybar12 = Ybar2 + Phi2 v
+    cb_load(M0, A.Phi + Rr * 4096, tid);
+    __syncthreads();
+    {
+        double acc[4][4] = {};
+        cb_matmul<false, false>(acc, M0, LD, Au, LA, tx, ty);
+        __syncthreads();
+        cb_store_lds(Au, LA, acc, tx, ty);
+    }
+    if (tid < 64) {
+        double sacc = A.F[Rr * 64 + tid];
+        for (int kk = 0; kk < 64; ++kk) sacc = fma(M0[tid * LD + kk], vv[kk], sacc);
+        w[tid] = sacc;                      // Ybar12 (stored at the end)
+    }
+    __syncthreads();
+    {
+        double acc[4][4] = {};
+        cb_matmul<false, true>(acc, Au, LA, M0, LD, tx, ty);
+        __syncthreads();
+        cb_store_lds(Au, LA, acc, tx, ty);
+    }
+    __syncthreads();
+    {
+        double *Sr = A.S + Rr * 4096;
+        _Pragma("unroll 16")
+        for (int e = tid; e < 4096; e += 256) {
+            const int j = e >> 6, i = e & 63;
+            Sr[e] += 0.5 * (Au[i * LA + j] + Au[j * LA + i]);
+        }
+    }
+    __syncthreads();
+    // e. AL = Phi1 ;  AR <- D Phi1 ;  Phi12 = Phi2 (D Phi1)
+    cb_load(Au, A.Phi + L * 4096, tid, LA);
+    __syncthreads();
+    {
+        double acc[4][4] = {};
+        cb_matmul<false, false>(acc, Au + 64, LA, Au, LA, tx, ty);
+        __syncthreads();
+        cb_store_lds(Au + 64, LA, acc, tx, ty);
+    }
+    __syncthreads();
+    {
+        double acc[4][4] = {};
+        cb_matmul<false, false>(acc, M0, LD, Au + 64, LA, tx, ty);
+        double *Pr = A.Phi + Rr * 4096;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Pr[(size_t)(4 * tx + c) * 64 + 4 * ty + a] = acc[a][c];
+    }
+    __syncthreads();
+    // f. M1 <- G2 (D Phi1) ;  G12 = G1 + Phi1^T M1 ;  m12 = m1 + Phi1^T (m2 - G2 v)
+    {
+        double acc[4][4] = {};
+        cb_matmul<false, false>(acc, M1, LD, Au + 64, LA, tx, ty);
+        __syncthreads();
+        cb_store_lds(M1, LD, acc, tx, ty);
+    }
+    __syncthreads();
+    {
+        double acc[4][4] = {};
+        cb_matmul<true, false>(acc, Au, LA, M1, LD, tx, ty);
+        __syncthreads();
+        cb_store_lds(M0, LD, acc, tx, ty);  // Phi2 no longer needed
+    }
+    if (tid < 64) {
+        double sacc = A.m[L * 64 + tid];
+        for (int kk = 0; kk < 64; ++kk) sacc = fma(Au[kk * LA + tid], tmpv[kk] - g2v[kk], sacc);
+        A.m[Rr * 64 + tid] = sacc;
+        A.F[Rr * 64 + tid] = w[tid];
+    }
+    __syncthreads();
+    {
+        double *Gr = A.G + Rr * 4096;
+        const double *Gl = A.G + L * 4096;
+        _Pragma("unroll 16")
+        for (int e = tid; e < 4096; e += 256) {
+            const int j = e >> 6, i = e & 63;
+            Gr[e] = Gl[e] + 0.5 * (M0[i * LD + j] + M0[j * LD + i]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_tree_apply(const TreeArgs A) {
+    constexpr int LD = CB_LD, LA = CB_LA;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *Xs = lds;
+    double *Au = Xs + 64 * LD;
+    double *Bs = Au + 64 * LA;
+    double *Ys = Bs + 64 * LD;
+    double *vs = Ys + 64;
+    const int pairs = A.P / (2 * A.d);
+    const int pr = blockIdx.x / pairs, k = blockIdx.x - pr * pairs;
+    const int ir = (k + 1) * 2 * A.d - 1, il = ir - A.d;
+    const size_t L = (size_t)pr * A.P + il, Rr = (size_t)pr * A.P + ir;
+    const int tid = threadIdx.x;
+    double *Xr = A.Xst + Rr * 4096, *Xl = A.Xst + L * 4096;
+    // s[left] <- s[right] (incoming state) ;  s[right] <- map[left](s[right])
+    _Pragma("unroll 16")
+    for (int e = tid; e < 4096; e += 256) {
+        const int j = e >> 6, i = e & 63;
+        const double v = Xr[e];
+        Xl[e] = v;
+        Xs[i * LD + j] = v;
+    }
+    if (tid < 64) { const double v = A.Yst[Rr * 64 + tid]; A.Yst[L * 64 + tid] = v; Ys[tid] = v; }
+    __syncthreads();
+    const double noreg[16] = {};
+    cb_apply(Xs, Au, Bs, Ys, vs, A.Phi + L * 4096, A.G + L * 4096, A.m + L * 64,
+             A.S + L * 4096, A.F + L * 64, noreg, 0.0, tid);
+    _Pragma("unroll 16")
+    for (int e = tid; e < 4096; e += 256) { const int j = e >> 6, i = e & 63; Xr[e] = Xs[i * LD + j]; }
+    if (tid < 64) A.Yst[Rr * 64 + tid] = Ys[tid];
 }
 
 // ------------------------------------------------------------------------------------
@@ -2107,11 +2297,16 @@ int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int Jr, in
     return check_launch("gf_chunk_transition");
 }
 
+static size_t cb_lds_bytes(bool with_xn) {
+    (void)with_xn;
+    return sizeof(double) * (64 * CB_LD + 64 * CB_LA + 64 * CB_LD + 256);
+}
+
 int gf_chunk_combine(int B, int nch, const double *Phi, const double *G, const double *m,
                      double *S_state, double *F_state, void *stream) {
     if (B < 1 || nch < 1) return set_err("gf_chunk_combine: empty problem%s", "");
     if (!Phi || !G || !m || !S_state || !F_state) return set_err("gf_chunk_combine: null pointer%s", "");
-    const size_t lds = sizeof(double) * (64 * 65 + 64 * 130 + 64 * 65 + 128);
+    const size_t lds = cb_lds_bytes(true);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)k_combine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2119,6 +2314,39 @@ int gf_chunk_combine(int B, int nch, const double *Phi, const double *G, const d
     }
     hipLaunchKernelGGL(k_combine, dim3(B), dim3(256), lds, (hipStream_t)stream, nch, Phi, G, m, S_state, F_state);
     return check_launch("gf_chunk_combine");
+}
+
+// Tree (log-depth) version of gf_chunk_combine.  Maps live in slots [B][P] with P a power of two
+// >= nch; the caller fills slots c < nch with the chunk maps (Phi, G, m and Xbar/Ybar = the
+// nominal end states) and the rest with identity maps (Phi = I, everything else 0).  On exit
+// Xst/Yst slot c hold the TRUE start state of chunk c.  The map arrays are overwritten.
+int gf_chunk_combine_tree(int B, int P, double *Phi, double *G, double *m, double *S, double *F,
+                          double *Xst, double *Yst, void *stream) {
+    if (B < 1 || P < 2 || (P & (P - 1))) return set_err("gf_chunk_combine_tree: P=%s%lld must be a power of two >= 2", "", P);
+    if (!Phi || !G || !m || !S || !F || !Xst || !Yst) return set_err("gf_chunk_combine_tree: null pointer%s", "");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = cb_lds_bytes(false);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_tree_compose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)k_tree_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    TreeArgs A;
+    A.P = P; A.Phi = Phi; A.G = G; A.S = S; A.F = F; A.m = m; A.Xst = Xst; A.Yst = Yst;
+    for (int d = 1; d < P; d *= 2) {        // up-sweep
+        A.d = d;
+        hipLaunchKernelGGL(k_tree_compose, dim3(B * (P / (2 * d))), dim3(256), lds, st, A);
+    }
+    for (int b = 0; b < B; ++b) {           // root state = zero
+        (void)hipMemsetAsync(Xst + ((size_t)b * P + P - 1) * 4096, 0, sizeof(double) * 4096, st);
+        (void)hipMemsetAsync(Yst + ((size_t)b * P + P - 1) * 64, 0, sizeof(double) * 64, st);
+    }
+    for (int d = P / 2; d >= 1; d /= 2) {   // down-sweep
+        A.d = d;
+        hipLaunchKernelGGL(k_tree_apply, dim3(B * (P / (2 * d))), dim3(256), lds, st, A);
+    }
+    return check_launch("gf_chunk_combine_tree");
 }
 
 #define GF_LINR_CASE(Rw) case Rw: hipLaunchKernelGGL((k_linR<Rw>), dim3(B * nch, (R + 63) / 64), dim3(64), 0, st, A); break;

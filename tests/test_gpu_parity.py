@@ -373,6 +373,46 @@ def test_time_parallel_batch_of_two(hip):
         assert abs(ll[i] - ref) <= RTOL_LL * abs(ref)
 
 
+TREE_CASES = [
+    ("solar", dict(J=30, N=5000), 512, 1),       # 10 chunks -> P = 16 (identity padding)
+    ("solar", dict(J=30, N=4096), 512, 1),       # 8 chunks  -> P = 8 (no padding)
+    ("solar", dict(J=6, N=3000), 64, 1),         # 47 chunks -> P = 64
+    ("solar", dict(J=20, N=2500, jitter_t=True), 128, 1),
+    ("solar", dict(J=30, N=3000, gaps=True), 192, 1),
+    ("generic", dict(kind="mixed", N=900), 64, 1),
+    ("solar", dict(J=12, N=2600), 384, 2),       # batch of two
+]
+
+
+@pytest.mark.parametrize("case", TREE_CASES, ids=lambda c: f"{c[0]}-{c[1]}-L{c[2]}-B{c[3]}")
+def test_time_parallel_tree_combine(hip, case):
+    """The log-depth (Blelloch) combine gives the chunk start states of the sequential combine:
+    same log-likelihood, d_n and z_n as the sequential evaluation and as the oracle."""
+    from gadfly_amd.engine import StreamingBatch
+    from oracle import cref
+    kind, kw, L, B = case
+    prob = _make((kind, kw))
+    k, t, y = prob["kernel"], prob["t"], prob["y"]
+    co = k.get_device_coefficients()
+    eng = StreamingBatch([co] * B, t, y, diag=prob["diag_user"])
+    N = len(t)
+    eng.tree_min_chunks = 1 << 30                   # sequential combine
+    ll_lin = eng.log_likelihood_time_parallel(chunk_len=L).cpu().numpy()
+    S_lin = eng._tp["S"].clone(); F_lin = eng._tp["F"].clone()
+    d_lin = eng._tp["d"][:B * N].clone(); z_lin = eng._tp["z"][:B * N].clone()
+    eng.tree_min_chunks = 2                         # tree combine
+    ll_tree = eng.log_likelihood_time_parallel(chunk_len=L).cpu().numpy()
+    assert "tree" in eng._tp
+    ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y)
+    assert info == 0
+    for b in range(B):
+        assert abs(ll_tree[b] - ref) <= RTOL_LL * abs(ref), (ll_tree[b], ref)
+        assert abs(ll_tree[b] - ll_lin[b]) <= 1e-10 * abs(ref)
+    assert _relmax(eng._tp["d"][:B * N].cpu().numpy(), d_lin.cpu().numpy()) < 1e-9
+    zs = float(z_lin.abs().max())
+    assert float((eng._tp["z"][:B * N] - z_lin).abs().max()) < 1e-8 * zs
+
+
 def test_gaussian_process_fast_path_long_series(hip):
     """compute + log_likelihood of the drop-in class on a series long enough to take the
     time-parallel engine, against the oracle; then a predict() that builds the stored factor."""
