@@ -1113,10 +1113,10 @@ __device__ __forceinline__ void cb_store_lds(double *dst, int ld, const double (
 __device__ __forceinline__ void cb_gauss_jordan(double *Au, double *scratch, int tid) {
     constexpr int LA = CB_LA;
     const int jj = tid & 31, rgp = tid >> 5, lane = tid & 63;
-    double *pcol = scratch;                 // [64]  candidate column
-    double *prow = scratch + 64;            // [129] pivot row
-    double *pinvr = scratch + 64 + 136;     // [64]  1 / pivot of the row
-    int *rowvar = reinterpret_cast<int *>(scratch + 64 + 136 + 64);     // [64] variable solved by row
+    double *pcol = scratch;                 // [2][64] candidate column (double-buffered)
+    double *prow = scratch + 128;           // [129]   pivot row
+    double *pinvr = scratch + 128 + 136;    // [64]    1 / pivot of the row
+    int *rowvar = reinterpret_cast<int *>(scratch + 128 + 136 + 64);    // [64] variable solved by row
     double R[8][5];
 #pragma unroll
     for (int a = 0; a < 8; ++a)
@@ -1133,37 +1133,37 @@ __device__ __forceinline__ void cb_gauss_jordan(double *Au, double *scratch, int
     }
     __syncthreads();
     for (int k = 0; k < 64; ++k) {
-        const double cand = used ? -1.0 : fabs(pcol[lane]);
+        const double *pc = pcol + 64 * (k & 1);
+        double *pn = pcol + 64 * ((k & 1) ^ 1);
+        const double cval = pc[lane];
+        const double cand = used ? -1.0 : fabs(cval);
         const double vm = wave_max(cand);
         const unsigned long long hit = __ballot(cand == vm);
-        const int pv = (int)__ffsll((long long)hit) - 1;
+        const int pv = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)hit) - 1);
         if (lane == pv) used = true;
-        if ((pv >> 3) == rgp) {             // owners of row pv publish it
-            const int a = pv & 7;
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                double v = 0.0;
-#pragma unroll
-                for (int a2 = 0; a2 < 8; ++a2) v = (a2 == a) ? R[a2][cc] : v;
-                prow[jj + 32 * cc] = v;
-            }
-            if (jj == 0) {
-                double v = 0.0;
-#pragma unroll
-                for (int a2 = 0; a2 < 8; ++a2) v = (a2 == a) ? R[a2][4] : v;
-                prow[128] = v;
-            }
+        // every wave knows the pivot value from its own search lanes: reciprocal and the row
+        // multipliers are formed while the owners publish the pivot row
+        const int lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(cval) & 0xffffffffLL), pv);
+        const int hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(cval) >> 32), pv);
+        const double pval = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+        const double pinv = fast_rcp(pval);
+        if ((pv >> 3) == rgp) {             // owners of row pv publish it (pv is wave-uniform)
+#define CB_PUB(a)                                                                        \
+    case a:                                                                              \
+        prow[jj] = R[a][0]; prow[jj + 32] = R[a][1]; prow[jj + 64] = R[a][2];            \
+        prow[jj + 96] = R[a][3]; if (jj == 0) prow[128] = R[a][4];                       \
+        break;
+            switch (pv & 7) { CB_PUB(0) CB_PUB(1) CB_PUB(2) CB_PUB(3) CB_PUB(4) CB_PUB(5) CB_PUB(6) CB_PUB(7) }
+#undef CB_PUB
         }
-        if (tid == 0) rowvar[pv] = k;
-        __syncthreads();
-        const double pinv = 1.0 / prow[k];
-        if (tid == 0) pinvr[pv] = pinv;
+        if (tid == 0) { rowvar[pv] = k; pinvr[pv] = pinv; }
         double fr[8];
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
             const int i = rgp * 8 + a;
-            fr[a] = (i == pv) ? 0.0 : pcol[i] * pinv;
+            fr[a] = (i == pv) ? 0.0 : pc[i] * pinv;
         }
+        __syncthreads();
         const int kn = k + 1;
 #pragma unroll
         for (int cc = 0; cc < 5; ++cc) {
@@ -1174,15 +1174,9 @@ __device__ __forceinline__ void cb_gauss_jordan(double *Au, double *scratch, int
                 for (int a = 0; a < 8; ++a) R[a][cc] = fma(-fr[a], pk, R[a][cc]);
             }
         }
-        __syncthreads();                    // everyone is done with pcol / prow
-        if (kn < 64 && jj == (kn & 31)) {
+        if (kn < 64 && jj == (kn & 31)) {   // next candidate column -> the other buffer
 #pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                double v = 0.0;
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) v = (cc == (kn >> 5)) ? R[a][cc] : v;
-                pcol[rgp * 8 + a] = v;
-            }
+            for (int a = 0; a < 8; ++a) pn[rgp * 8 + a] = (kn >> 5) ? R[a][1] : R[a][0];
         }
         __syncthreads();
     }

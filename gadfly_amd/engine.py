@@ -634,11 +634,11 @@ class StreamingBatch:
         N, B = self.N, self.B
         block = self._pack[5]
         if chunk_len is None:
-            # enough chunks to put ~1536 waves in flight (B * nch), but at most ~128 per
-            # problem: beyond that the sequential ~0.12 ms/chunk combine outweighs the shorter
-            # sweeps (measured at N = 1e6, W = 60: DESIGN.md 4.3)
-            nch = min(128, max(1, 1536 // B))
-            chunk_len = max(1024, -(-N // nch))
+            # B * nch ~ 2048 waves = 2 per SIMD, the occupancy the sweep kernels are built for
+            # (measured optimum for B = 1 ... 128 at N = 2.6e5 ... 1e6, W = 60: DESIGN.md 4.3);
+            # below ~512 rows per chunk the extra tree levels cost more than the sweeps save
+            nch = max(1, 2048 // B)
+            chunk_len = max(512, -(-N // nch))
         chunk_len = max(block, (int(chunk_len) + 63) // 64 * 64)
         return chunk_len, -(-N // chunk_len)
 
@@ -778,7 +778,7 @@ class StreamingBatch:
         if time_parallel is None:
             # chunking costs ~3.5x the flops: it pays while the batch alone fills less than
             # ~1/8 of the 2048 wave slots
-            time_parallel = self._fused_ok() and self.B <= 128 and self.N >= 8192
+            time_parallel = self._fused_ok() and self.B <= 256 and self.N >= 8192
         if time_parallel and self._fused_ok():
             out = self.log_likelihood_time_parallel()
             acc = self._tp["acc"] if getattr(self, "_tp_key", None) and self._tp_used else self.acc
