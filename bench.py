@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--overlap", action="store_true",
                     help="build tile k+1 on a side stream during the sweep of tile k (slower: "
                          "the build waves displace one of the two sweep waves per SIMD)")
+    ap.add_argument("--kernel", choices=["auto", "blocked", "fused"], default="auto",
+                    help="sweep kernel: blocked = k_factor4 (FP64 MFMA, rank-16 blocks), "
+                         "fused = k_factor3 (vector FMA); auto takes blocked when supported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=0,
                     help="rows of the CPU-baseline sample (0 = full N, one evaluation)")
@@ -105,6 +108,10 @@ def main():
                                          overlap_build=args.overlap)
     packs = [ev.pack(walkers(s)) for s in range(nsteps)]
     eng = ev.engine
+    if args.kernel == "fused":
+        eng.allow_blocked = False
+    elif args.kernel == "blocked" and not eng._blocked_ok():
+        raise SystemExit("--kernel blocked: not supported for this term structure / cadence")
     eng.time_factor = True
     torch.cuda.synchronize()
 
@@ -184,8 +191,10 @@ def main():
             pass
         result["roofline"] = {
             "bound": "hbm",
-            "kernel": "k_factor3 (fused build + factor + forward solve)"
-                      if getattr(eng, "_fused_ok", lambda: False)() else "k_factor",
+            "kernel": {"blocked": "k_factor4 (fused build + factor + forward solve, rank-16 blocks "
+                                  "on v_mfma_f64_16x16x4)",
+                       "fused": "k_factor3 (fused build + factor + forward solve)"}.get(
+                           getattr(eng, "kernel_used", ""), "k_factor"),
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
             "kernel_ms": fac_avg_ms, "launches_timed": len(fac_ms),

@@ -45,6 +45,9 @@ SIGNATURES = {
                          + [_vp] * 5 + [_vp]),
     "gf_loglike_fused": (_int, [_int, _i64, _i64, _int, _int, _int] + [_vp] * 8
                          + [_vp, _i64, _vp, _i64, _vp, _i64] + [_vp] * 5 + [_vp]),
+    "gf_blocked_supported": (_int, [_int, _int, _int]),
+    "gf_loglike_blocked": (_int, [_int, _i64, _i64, _int, _int, _int] + [_vp] * 8
+                         + [_vp, _i64, _vp, _i64, _vp, _i64] + [_vp] * 5 + [_vp]),
     "gf_chunk_sweep": (_int, [_int, _i64, _i64, _int, _int, _int, _int] + [_vp] * 8
                        + [_vp, _i64, _vp, _i64, _vp, _i64] + [_vp] * 9 + [_vp]),
     "gf_chunk_linear": (_int, [_int, _int, _i64, _i64, _int, _int, _int, _int, _int]

@@ -917,6 +917,333 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
 }
 
 // ------------------------------------------------------------------------------------
+// k_factor4: the fused sweep in BLOCKED (rank-16) form on the FP64 matrix pipe.
+//
+// k_factor3 spends 2 W^2 vector FMAs per row and is bound by the rate at which one wave can
+// issue vector instructions (~300 per row, 120 of them the FMAs).  Sixteen consecutive rows of
+// one scaling block can be taken together (scaled coordinates: no decay inside a block):
+//     P  = T U~                        (64 x 16)   U~ = [u~_0 .. u~_15], T the state at block start
+//     B  = V~ - P
+//     H  = B^T U~  (+ diag)            (16 x 16)   = conditional covariance of the 16 rows
+//     H  = L D L^T,  N = L^-T          (16 x 16, in LDS: the only sequential part)
+//     R~ = B N D^-1/2                  (64 x 16)   columns r~_m / sqrt(d_m)
+//     T += R~ R~^T
+// which is the same arithmetic re-associated (d_m = H_mm - sum_k<m c_km^2 / d_k, c_km = r_k.u~_m);
+// scratch/proto_block.py checks it against the sequential recurrence (d to 1e-13).  The four
+// products run as v_mfma_f64_16x16x4_f64 (10 per row): one issue slot per 1024 FMAs instead of 16.
+//
+// Layout.  Lane = (m, g) = (lane & 15, lane >> 4).  T lives in accumulator layout as 4 x 4 tiles:
+// T[it][jt][r] @ lane (j, g) = T(16 it + 4 r + g, 16 jt + j).  A register in that layout is
+// directly a B operand (its K index is the row 4 r + g) and, read transposed, an A operand, so
+// T, B^T and R~^T never leave the accumulator layout; only V~/B pass through LDS (to reach the
+// A layout for H).  U~ is generated in A layout: lane (m, k) makes u~_m(k + 4 q), q = 0..15.
+// State columns are PERMUTED so that a lane's 16 columns are 8 (cos, sin) pairs: logical column
+// l = 2 kappa + s sits at physical index (kappa >> 3) + 4 (2 (kappa & 7) + s); column 63 carries
+// the forward solve (v~_63 = y, u~_63 = 0: T(.,63) = F~, r~_m(63) = z_m / sqrt(d_m)).
+// Rows past a reset (new scaling block, gap) or past the end of the tile are "null" rows
+// (u~ = v~ = 0, H_mm = 1): they change nothing.  Needs Jr even, W <= 62, block >= 16.
+// ------------------------------------------------------------------------------------
+typedef double d4 __attribute__((ext_vector_type(4)));
+#define GF_MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+constexpr int F4_TAB = 8;           // doubles per (cos, sin) pair in the constants table
+
+__device__ __forceinline__ int f4_logical(int p) {      // physical -> logical column
+    const int k = p & 3, q = p >> 2;
+    return 2 * (8 * k + (q >> 1)) + (q & 1);
+}
+// 16 x 64 staging matrix in LDS, row stride 64 with the column XOR-swizzled by the row (a fixed
+// column read down 16 rows and 16 consecutive columns of 4 rows both spread over the banks)
+__device__ __forceinline__ int f4_vs(int row, int col) { return row * 64 + (col ^ (4 * row)); }
+
+__global__ void __launch_bounds__(64, 2)
+k_factor4(const int64_t N, const int64_t n_first, const int Jr, const int Jc, const int block,
+          const double gap,
+          const double *__restrict__ ar_, const double *__restrict__ cr_,
+          const double *__restrict__ ac_, const double *__restrict__ bc_,
+          const double *__restrict__ cc_, const double *__restrict__ dc_,
+          const double *__restrict__ diag_add_, const double *__restrict__ cmax_,
+          const double *__restrict__ t_, const int64_t t_bs,
+          const double *__restrict__ diag_, const int64_t diag_bs,
+          const double *__restrict__ y_, const int64_t y_bs,
+          double *__restrict__ d_, double *__restrict__ z_,
+          double *__restrict__ S_state, double *__restrict__ F_state,
+          int32_t *__restrict__ info) {
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    if (info[b] != 0) return;
+    const int m = lane & 15, g = lane >> 4;
+    const int W = Jr + 2 * Jc;
+    const double *__restrict__ tg = t_ + (size_t)b * t_bs + n_first;
+    const double *__restrict__ yg = y_ + (size_t)b * y_bs + n_first;
+    const double *__restrict__ gg = diag_ ? diag_ + (size_t)b * diag_bs + n_first : nullptr;
+    double *__restrict__ dg = d_ + (size_t)b * N;
+    double *__restrict__ zg = z_ + (size_t)b * N;
+    double *__restrict__ Sg = S_state + (size_t)b * 4096;
+    double *__restrict__ Fg = F_state + (size_t)b * 64;
+    const double cmax = cmax_[b];
+
+    // 19 KB of LDS per wave: eight waves (2 per SIMD) fit one CU's 160 KB
+    __shared__ __attribute__((aligned(16))) double tab[32 * F4_TAB];
+    __shared__ __attribute__((aligned(16))) double Us[16 * 64];     // u~ operands, [q][lane]
+    __shared__ __attribute__((aligned(16))) double Vs[16 * 64];     // V~^T, then B^T (swizzled)
+    __shared__ __attribute__((aligned(16))) double es[64];
+    __shared__ __attribute__((aligned(16))) double rp[16];      // pivot row, permuted [m & 3][m >> 2]
+    __shared__ __attribute__((aligned(16))) double gk[16];      // row k of L^-1, [g][r]
+    __shared__ __attribute__((aligned(16))) double db[32];      // d_m, sqrt(d_m)
+
+    // ---- constants table: pair kappa = lane < 32 -------------------------------------------
+    // u~_0 = (A0 co + B0 si) rho_0 ,  u~_1 = (A1 own1 + B1 co) rho_1 ,  v~_0 = co / rho_0 ,
+    // v~_1 = own1 / rho_1 ,  own1 = si (complex pair) or co = 1 (two real columns, rf = 1).
+    // Pad pairs have zero coefficients: their u~ vanish, so whatever their v~ put into the pad
+    // rows and columns of T never reaches a real entry (and is not stored).
+    double suma = 0.0;
+    if (lane < 32) {
+        double c0 = 0, c1 = 0, dd = 0, rf = 0, A0 = 0, B0 = 0, A1 = 0, B1 = 0;
+        const int l0 = 2 * lane;
+        if (l0 + 1 < Jr) {                  // two real columns
+            c0 = cr_[(size_t)b * Jr + l0]; c1 = cr_[(size_t)b * Jr + l0 + 1];
+            A0 = ar_[(size_t)b * Jr + l0]; A1 = ar_[(size_t)b * Jr + l0 + 1];
+            rf = 1.0;
+            suma = A0 + A1;
+        } else if (l0 >= Jr && l0 + 1 < W) {
+            const size_t ck = (size_t)b * Jc + ((l0 - Jr) >> 1);
+            c0 = c1 = cc_[ck]; dd = dc_[ck];
+            A0 = A1 = ac_[ck]; B0 = bc_[ck]; B1 = -B0;
+            suma = A0;
+        }
+        double *tp = tab + lane * F4_TAB;
+        tp[0] = c0; tp[1] = c1; tp[2] = dd; tp[3] = rf;
+        tp[4] = A0; tp[5] = B0; tp[6] = A1; tp[7] = B1;
+    }
+    suma = wave_sum(suma);
+    const double dshift = diag_add_[b] - suma;          // a_n - v~_n.u~_n = diag_n + dshift
+    // decay rate of this lane's physical column (lane = physical index)
+    wave_lds_fence();
+    const double c_col = tab[(8 * (lane & 3) + (lane >> 3)) * F4_TAB + ((lane >> 2) & 1)];
+
+    // ---- state -> accumulator layout ------------------------------------------------------
+    d4 T[4][4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lr = f4_logical(16 * it + 4 * r + g), lc = f4_logical(16 * jt + m);
+                const double vS = Sg[(size_t)lc * 64 + lr];
+                const double vF = Fg[(lr == 63) ? lc : lr];
+                const bool isF = (lr == 63) != (lc == 63);
+                const int lo = (lr == 63) ? lc : lr, hi = (lr == 63) ? lr : lc;
+                double v = isF ? vF : vS;
+                if (!(lo < W && (hi < W || isF))) v = 0.0;
+                T[it][jt][r] = v;
+            }
+
+    // reference time of the scaling block that precedes the first row (see RowGen::init)
+    double tref = tg[0];
+    if (n_first > 0) {
+        int64_t q = -1;
+        while (!(((n_first + q) & (block - 1)) == 0 || cmax * (tg[q] - tg[q - 1]) > gap)) --q;
+        tref = tg[q];
+    }
+
+    int32_t fail = 0;
+    for (int64_t n = 0; n < N;) {
+        // ---- extent of this block: up to 16 rows, ends before the next reset row --------------
+        const int64_t ri = n + m;
+        const bool in_tile = ri < N;
+        const int64_t rc = in_tile ? ri : N - 1;
+        const double tm = tg[rc];
+        const double tprev = (n_first + rc > 0) ? tg[rc - 1] : tm;
+        const double ym = yg[rc];
+        const double gm = gg ? gg[rc] : 0.0;
+        const bool rs_m = in_tile && ((((n_first + ri) & (block - 1)) == 0) || (cmax * (tm - tprev) > gap));
+        const unsigned int mb = (unsigned int)(__ballot(rs_m) & 0xffffull);
+        const unsigned int later = mb >> 1;
+        int cnt = later ? (int)__ffs((int)later) : 16;
+        if ((int64_t)cnt > N - n) cnt = (int)(N - n);
+        const double t0 = read_lane(tm, 0);
+        if ((mb & 1u) && (n_first + n) > 0) {       // reset row: T <- E T E, new reference time
+            const double de = t0 - tref;
+            wave_lds_fence();
+            es[lane] = fm_exp(-c_col * de);
+            wave_lds_fence();
+            double ec[4];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) ec[jt] = es[16 * jt + m];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const d4 er = d4{es[16 * it + g], es[16 * it + 4 + g], es[16 * it + 8 + g], es[16 * it + 12 + g]};
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[it][jt][r] *= er[r] * ec[jt];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (mb & 1u) tref = t0;
+        const bool valid = m < cnt;
+
+        // ---- generator rows: lane (m, g) makes columns g + 4 q of row m ------------------------
+        // u~ goes to LDS as this lane's own A operands (kept out of the registers: with T and
+        // the polynomial constants of sincos / exp live they would not fit), V~^T to the
+        // staging matrix
+        const double dl = tm - tref;
+        wave_lds_fence();
+#pragma unroll
+        for (int pq = 0; pq < 8; ++pq) {
+            const double *tp = tab + (8 * g + pq) * F4_TAB;
+            const d4 k0 = *reinterpret_cast<const d4 *>(tp);        // c0 c1 dd rf
+            const d4 k1 = *reinterpret_cast<const d4 *>(tp + 4);    // A0 B0 A1 B1
+            double si, co;
+            fm_sincos(k0[2] * tm, &si, &co);
+            const double r0 = fm_exp(-k0[0] * dl), r1 = fm_exp(-k0[1] * dl);
+            const double i0 = fast_rcp(r0), i1 = fast_rcp(r1);
+            const double own1 = fma(k0[3], co - si, si);
+            const double u0 = fma(k1[0], co, k1[1] * si) * r0;
+            const double u1 = fma(k1[2], own1, k1[3] * co) * r1;
+            const double v0 = co * i0;
+            double v1 = own1 * i1;
+            if (pq == 7 && g == 3) v1 = ym;                          // column 63: forward solve
+            Us[(2 * pq) * 64 + lane] = valid ? u0 : 0.0;
+            Us[(2 * pq + 1) * 64 + lane] = valid ? u1 : 0.0;
+            Vs[f4_vs(m, g + 4 * (2 * pq))] = valid ? v0 : 0.0;
+            Vs[f4_vs(m, g + 4 * (2 * pq + 1))] = valid ? v1 : 0.0;
+        }
+        const double avv = valid ? (gm + dshift) : 1.0;
+
+        // ---- P^T = U~^T T ;  B^T = V~^T - P^T  (accumulator layout, kept in LDS) ---------------
+        __builtin_amdgcn_sched_barrier(0);
+        wave_lds_fence();
+        {
+            d4 acc[4];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) acc[jt] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const double uq = Us[q * 64 + lane];
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) acc[jt] = GF_MFMA64(uq, T[q >> 2][jt][q & 3], acc[jt]);
+            }
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double *vp = &Vs[f4_vs(g + 4 * r, 16 * jt + m)];
+                    *vp = *vp - acc[jt][r];         // same lane reads and writes the element
+                }
+            wave_lds_fence();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- H = B^T U~ (+ diagonal) -----------------------------------------------------------
+        d4 Hh;
+        {
+            d4 h[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                h[it] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    h[it] = GF_MFMA64(Vs[f4_vs(m, 16 * it + 4 * r + g)], Us[(4 * it + r) * 64 + lane], h[it]);
+            }
+            Hh = (h[0] + h[1]) + (h[2] + h[3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (g + 4 * r == m) Hh[r] += avv;
+
+        // ---- 16 x 16 LDL^T with L^-1 alongside; element (g + 4 r, m) lives at lane (m, g) ------
+        d4 Gm;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Gm[r] = (g + 4 * r == m) ? 1.0 : 0.0;
+        double dm = 1.0;
+        int fk = 16;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int kg = k & 3, kr = k >> 2;
+            wave_lds_fence();
+            if (g == kg) rp[(m & 3) * 4 + (m >> 2)] = Hh[kr];
+            if (m == k) *reinterpret_cast<d4 *>(&gk[g * 4]) = Gm;
+            wave_lds_fence();
+            const double ckm = rp[(m & 3) * 4 + (m >> 2)];
+            const d4 ckr = *reinterpret_cast<const d4 *>(&rp[g * 4]);
+            const d4 gkv = *reinterpret_cast<const d4 *>(&gk[g * 4]);
+            const double dk = rp[kg * 4 + kr];
+            if (k < cnt && !(dk > 0.0) && fk == 16) fk = k;
+            const double f = ckm * fast_rcp(dk);
+            if (m == k) dm = dk;
+            if (m > k) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (g + 4 * r > k) Hh[r] = fma(-ckr[r], f, Hh[r]);
+                    Gm[r] = fma(-f, gkv[r], Gm[r]);
+                }
+            }
+        }
+        if (fk < 16) {                              // wave-uniform (dk is)
+            const int64_t gf = n_first + n + fk + 1;
+            fail = (int32_t)(gf > 0x7fffffff ? 0x7fffffff : gf);
+            break;
+        }
+        const double sq = sqrt(dm);
+        const double rsq = fast_rcp(sq);
+        wave_lds_fence();
+        if (g == 0) { db[m] = dm; db[16 + m] = sq; }
+        wave_lds_fence();
+
+        // ---- R~^T = (N D^-1/2)^T B^T ;  T += R~ R~^T -------------------------------------------
+        __builtin_amdgcn_sched_barrier(0);
+        d4 Rt[4];
+        {
+            d4 Mg;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Mg[r] = Gm[r] * rsq;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) Rt[jt] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+                    Rt[jt] = GF_MFMA64(Mg[r], Vs[f4_vs(g + 4 * r, 16 * jt + m)], Rt[jt]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) T[it][jt] = GF_MFMA64(Rt[it][r], Rt[jt][r], T[it][jt]);
+
+        // ---- outputs: d_m (lanes 0..15), z_m = r~_m(63) sqrt(d_m) (lanes (15, g)) -------------
+        if (g == 0 && valid) dg[n + m] = dm;
+        if (m == 15) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (g + 4 * r < cnt) zg[n + g + 4 * r] = Rt[3][r] * db[16 + g + 4 * r];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        n += cnt;
+    }
+    if (fail) {
+        if (lane == 0) info[b] = fail;
+        return;
+    }
+    // ---- accumulator layout -> state ---------------------------------------------------------
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lr = f4_logical(16 * it + 4 * r + g), lc = f4_logical(16 * jt + m);
+                const double v = T[it][jt][r];
+                if (lc == 63) { if (lr < W) Fg[lr] = v; }
+                else if (lr != 63 && lr < W && lc < W) Sg[(size_t)lc * 64 + lr] = v;
+            }
+}
+
+// ------------------------------------------------------------------------------------
 // Exact time-parallel evaluation of ONE series (Lainiotis-type partitioning; the numpy
 // derivation and its verification against the sequential recurrence are in DESIGN.md 4.3).
 // The series is cut into nch chunks.  With X = S (+ pending update) handed from chunk to chunk:
@@ -2244,6 +2571,33 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
     return fused_launch("gf_loglike_fused", B, N, n_first, N, 1, Jr, Jc, block, ar, cr, ac, bc, cc, dc,
                         diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, nullptr,
                         nullptr, nullptr, nullptr, S_state, F_state, info, stream);
+}
+
+// Blocked (rank-16, FP64 MFMA) form of gf_loglike_fused; same arguments and results.
+int gf_blocked_supported(int Jr, int Jc, int block) {
+    const int W = Jr + 2 * Jc;
+    return (W >= 1 && W <= 62 && (Jr & 1) == 0 && block >= 16 && block <= 64 && !(block & (block - 1))) ? 1 : 0;
+}
+
+int gf_loglike_blocked(int B, int64_t N, int64_t n_first, int Jr, int Jc, int block,
+                       const double *ar, const double *cr, const double *ac,
+                       const double *bc, const double *cc, const double *dc,
+                       const double *diag_add, const double *cmax,
+                       const double *t, int64_t t_bs, const double *diag, int64_t diag_bs,
+                       const double *y, int64_t y_bs,
+                       double *d, double *z, double *S_state, double *F_state,
+                       int32_t *info, void *stream) {
+    if (B < 1 || N < 1) return set_err("gf_loglike_blocked: empty problem (N=%s%lld)", "", N);
+    if (!gf_blocked_supported(Jr, Jc, block))
+        return set_err("gf_loglike_blocked: needs Jr even, W <= 62, block in {16, 32, 64} (block=%s%lld)", "", block);
+    if (n_first < 0 || (n_first % block) != 0) return set_err("gf_loglike_blocked: n_first=%s%lld must be a non-negative multiple of block=%lld", "", n_first, block);
+    if (!t || !y || !d || !z || !S_state || !F_state || !info || !diag_add || !cmax)
+        return set_err("gf_loglike_blocked: null pointer%s", "");
+    const double gap = SC_SPAN / (double)(block - 1);
+    hipLaunchKernelGGL(k_factor4, dim3(B), dim3(64), 0, (hipStream_t)stream, N, n_first, Jr, Jc, block, gap,
+                       ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs,
+                       d, z, S_state, F_state, info);
+    return check_launch("gf_loglike_blocked");
 }
 
 int gf_chunk_sweep(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc, int block,

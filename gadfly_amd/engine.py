@@ -381,7 +381,7 @@ class StreamingBatch:
     """
 
     def __init__(self, coeffs_list, t, y, diag=None, tile_rows=8192, device=None,
-                 force_v1=False, overlap_build=False, allow_fused=True):
+                 force_v1=False, overlap_build=False, allow_fused=True, allow_blocked=False):
         torch = _lib.require_device()
         self.torch = torch
         self.lib = _lib.load()
@@ -438,6 +438,11 @@ class StreamingBatch:
         self.scaled = bool(self.lib.gf_scaled_supported(self.W)) and not force_v1
         # W <= 63 and phases inside the fused kernel's sincos range: nothing is materialised
         self.allow_fused = bool(allow_fused) and self.scaled and self.W <= 63
+        # ... and, for an even number of real columns and scaling blocks of >= 16 rows, the
+        # blocked (rank-16) form of the same sweep on v_mfma_f64 (k_factor4).  Off by default:
+        # on gfx950 FP64 MFMA and vector instructions do not execute concurrently and run at the
+        # same FMA rate, so the blocked form is no faster than k_factor3
+        self.allow_blocked = bool(allow_blocked)
         T = int(min(max(int(tile_rows), 1), self.N))
         if T < self.N:
             T = max(64, T // 64 * 64)         # tiles start on a reset row (any block <= 64)
@@ -486,6 +491,10 @@ class StreamingBatch:
     def _fused_ok(self):
         """Phases d*t must stay inside fm_sincos's Cody-Waite range (|x| < 1.6e6)."""
         return self.allow_fused and self._pack[6] * self._tmax < 1.6e6
+
+    def _blocked_ok(self):
+        return (self.allow_blocked and self._fused_ok()
+                and bool(self.lib.gf_blocked_supported(self.Jr, self.Jc, self._pack[5])))
 
     def _make_pack(self, real, comp, diag_add, c):
         dev = self._dev
@@ -602,6 +611,9 @@ class StreamingBatch:
         lib, p = self.lib, _lib.ptr
         T, N, B = self.tile_rows, self.N, self.B
         real, comp, diag_add, _, cmax, block, _ = self._pack
+        blocked = self._blocked_ok()
+        sweep = lib.gf_loglike_blocked if blocked else lib.gf_loglike_fused
+        self.kernel_used = "blocked" if blocked else "fused"
         for k in range((N + T - 1) // T):
             n0 = k * T
             rows = min(T, N - n0)
@@ -609,14 +621,14 @@ class StreamingBatch:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(main)
-            st = lib.gf_loglike_fused(
+            st = sweep(
                 B, rows, n0, self.Jr, self.Jc, block,
                 p(real[0]), p(real[1]), p(comp[0]), p(comp[1]), p(comp[2]), p(comp[3]),
                 p(diag_add), p(cmax), p(self.t), self._bs(self.t),
                 p(self.diag), 0 if self.diag is None else self._bs(self.diag),
                 p(self.y), self._bs(self.y), p(self.d), p(self.z),
                 p(self.S_state), p(self.F_state), p(self.info), main.cuda_stream)
-            _lib.check(st, "gf_loglike_fused")
+            _lib.check(st, "gf_loglike_blocked" if blocked else "gf_loglike_fused")
             if self.time_factor:
                 e1.record(main)
                 self.factor_events.append((e0, e1, rows))

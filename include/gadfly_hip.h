@@ -143,6 +143,23 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
                      int32_t *info, void *stream);
 
 /*
+ * The same fused sweep in blocked (rank-16) form on the FP64 matrix pipe: sixteen
+ * rows of one scaling block are taken together, P = T U~, H = (V~ - P)^T U~ = L D L^T, T += R~ R~^T
+ * run as v_mfma_f64_16x16x4_f64 and only the 16 x 16 LDL^T is sequential.  Same arguments, state
+ * hand-off (S_state/F_state) and results (d, z to rounding) as gf_loglike_fused, but t, y, diag
+ * need no padding.  gf_blocked_supported: Jr even, W <= 62, block in {16, 32, 64}.
+ */
+int gf_blocked_supported(int Jr, int Jc, int block);
+int gf_loglike_blocked(int B, int64_t N, int64_t n_first, int Jr, int Jc, int block,
+                       const double *ar, const double *cr, const double *ac,
+                       const double *bc, const double *cc, const double *dc,
+                       const double *diag_add, const double *cmax,
+                       const double *t, int64_t t_bs, const double *diag, int64_t diag_bs,
+                       const double *y, int64_t y_bs,
+                       double *d, double *z, double *S_state, double *F_state,
+                       int32_t *info, void *stream);
+
+/*
  * Exact time-parallel evaluation of ONE long series (or a few): the N rows are cut into nch
  * chunks of chunk_len rows (a multiple of `block`; the last chunk may be shorter) that are swept
  * concurrently, then stitched with an exact linear-fractional combine:

@@ -231,11 +231,11 @@ STREAM_CASES = [
 
 
 @pytest.mark.parametrize("case", STREAM_CASES, ids=lambda c: f"{c[0]}-{c[1]}-T{c[2]}")
-@pytest.mark.parametrize("mode", ["fused", "scaled", "v1"])
+@pytest.mark.parametrize("mode", ["blocked", "fused", "scaled", "v1"])
 def test_streaming_loglike(hip, case, mode):
     """Tile-streamed evaluation (all three kernel families) against the oracle, including the
     state hand-off between tiles and the block-scaled coordinates' reset rows."""
-    force_v1, allow_fused = mode == "v1", mode == "fused"
+    force_v1, allow_fused = mode == "v1", mode in ("fused", "blocked")
     from gadfly_amd.engine import StreamingBatch
     from oracle import cref
     kind, kw, tile = case
@@ -243,10 +243,14 @@ def test_streaming_loglike(hip, case, mode):
     k, t, y = prob["kernel"], prob["t"], prob["y"]
     co = k.get_device_coefficients()
     eng = StreamingBatch([co], t, y, diag=prob["diag_user"], tile_rows=tile, force_v1=force_v1,
-                         allow_fused=allow_fused)
-    if mode == "fused":
+                         allow_fused=allow_fused, allow_blocked=(mode == "blocked"))
+    if allow_fused:
         assert eng._fused_ok() == (eng.W <= 63)
+    if mode == "blocked" and not eng._blocked_ok():
+        pytest.skip("blocked kernel needs Jr even, W <= 62, block >= 16")
     ll = float(eng.log_likelihood()[0])
+    if mode == "blocked":
+        assert eng.kernel_used == "blocked"
     ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y)
     assert info == 0
     assert abs(ll - ref) <= RTOL_LL * abs(ref), (ll, ref)
