@@ -707,9 +707,8 @@ k_factor2(const int64_t N, const int64_t n_first, const int ld, const int W,
 // exchange:  u~ = (uA * own + uB * other) * rho,  v~ = own / rho  with
 //   even column: own = cos, uA = a, uB = +b ;  odd column: own = sin, uA = a, uB = -b ;
 //   real column: d = 0 (cos = 1), uA = a_r, uB = 0.
-// rho_n = rho_{n-1} * exp(-c dt_n): the exp is re-evaluated only when dt moves by more than
-// 1e-5/cmax from its cached value; the rounding-level jitter of a uniform cadence is absorbed
-// exactly by exp(-x) = 1 - x + x^2/2 (|x| < 1e-5 => truncation < 2e-16).
+// Between reset rows (anchors: exact fm_sincos, rho = 1) the rho-scaled phasor advances by a cached
+// one-cadence rotation with a second-order correction for cadence jitter (RowGen::next).
 // Valid while |d t| < 1.6e6 (fm_sincos's Cody-Waite range): the caller checks and otherwise
 // uses the k_build2 + k_factor2 pair.
 //
@@ -719,12 +718,13 @@ k_factor2(const int64_t N, const int64_t n_first, const int ld, const int W,
 // k_phi) and the final pass (true start states from k_combine).
 // ------------------------------------------------------------------------------------
 struct RowGen {
-    // per-lane column constants
-    double cj, dj, uA, uB, cmax, gap;
+    // per-lane column constants: u~ = (k1 cu + k2 su), v~ = own / rho^2 with (cu, su) =
+    // rho (cos, sin)(d t); lanes 2k, 2k+1 carry the same (cu, su)
+    double cj, dj, k1, k2, cmax, wmax, gap;
     bool is_sin, colok;
     int block;
-    // running scale state
-    double rho, irho, p_ref, ip_ref, dt_ref, tref, t_m1;
+    // running state: rho-scaled phasor, 1 / rho^2, cached one-cadence multipliers
+    double cu, su, irho2, Er, Ei, G2, dt_ref, tref, t_m1;
 
     __device__ __forceinline__ void init(int lane, int b, int Jr, int Jc, int block_, double gap_,
                                          const double *ar_, const double *cr_, const double *ac_,
@@ -732,23 +732,25 @@ struct RowGen {
                                          const double *cmax_, const double *tg, int64_t n_first) {
         const int W = Jr + 2 * Jc;
         colok = lane < W;
-        cj = 0.0; dj = 0.0; uA = 0.0; uB = 0.0; is_sin = false;
+        cj = 0.0; dj = 0.0; k1 = 0.0; k2 = 0.0; is_sin = false;
         if (lane < Jr) {
             cj = cr_[(size_t)b * Jr + lane];
-            uA = ar_[(size_t)b * Jr + lane];
+            k1 = ar_[(size_t)b * Jr + lane];
         } else if (colok) {
             const int k = (lane - Jr) >> 1;
             const size_t ck = (size_t)b * Jc + k;
             is_sin = ((lane - Jr) & 1) != 0;
             cj = cc_[ck];
             dj = dc_[ck];
-            uA = ac_[ck];
-            uB = is_sin ? -bc_[ck] : bc_[ck];
+            // cos column: a cos + b sin ;  sin column: a sin - b cos
+            k1 = is_sin ? -bc_[ck] : ac_[ck];
+            k2 = is_sin ? ac_[ck] : bc_[ck];
         }
         cmax = cmax_[b];
+        wmax = wave_max(fmax(cj, fabs(dj)));
         block = block_;
         gap = gap_;
-        rho = 1.0; irho = 1.0; p_ref = 1.0; ip_ref = 1.0; dt_ref = -1.0;
+        cu = 1.0; su = 0.0; irho2 = 1.0; Er = 1.0; Ei = 0.0; G2 = 1.0; dt_ref = -1.0;
         // reference time of the block that precedes the first row (for its decay); tg points
         // at the first row, earlier rows are at negative indices
         tref = tg[0];
@@ -760,7 +762,14 @@ struct RowGen {
         t_m1 = (n_first > 0) ? tg[-1] : tg[0];
     }
 
-    // generate global row g at time tn: u~, v~, reset flag and (for reset rows) the decay span
+    // generate global row g at time tn: u~, v~, reset flag and (for reset rows) the decay span.
+    // Reset rows (every `block` <= 64 rows, and after gaps) are anchors: rho = 1 and the phase is
+    // theta = d t_n as ONE rounded multiply through fm_sincos.  Between anchors the phasor
+    // advances by the cached one-cadence multiplier exp((-c + i d) dt_ref), corrected to second
+    // order for the deviation of this row's spacing from dt_ref (rounding-level jitter of a
+    // regular cadence: |(c, d) ddt| < 2e-6 => truncation < 2e-18 per row); any other spacing
+    // refreshes the cache (sincos + exp, as an anchor costs).  Per-row rounding accumulates over
+    // at most 63 rows (~1e-14); scratch/proto_rot.py: log-likelihood to 1e-14, d_n to 4e-11.
     __device__ __forceinline__ void next(const double tn, const int64_t g, double &ut, double &vt,
                                          bool &rst, double &de) {
         const double dt = tn - t_m1;
@@ -769,27 +778,33 @@ struct RowGen {
         if (rst) {                                  // wave-uniform
             de = (g > 0) ? (tn - tref) : 0.0;
             tref = tn;
-            rho = 1.0;
-            irho = 1.0;
+            fm_sincos(dj * tn, &su, &cu);           // real columns: d = 0 -> (1, 0)
+            irho2 = 1.0;
         } else {
             double ddt = dt - dt_ref;
-            if (!(fabs(ddt) * cmax < 1e-5)) {       // wave-uniform: new cadence -> new exp
-                p_ref = fm_exp(-cj * dt);
-                ip_ref = 1.0 / p_ref;
+            if (!(fabs(ddt) * wmax < 2e-6)) {       // wave-uniform: new cadence -> new multipliers
+                double si, co;
+                fm_sincos(dj * dt, &si, &co);
+                const double pr = fm_exp(-cj * dt);
+                Er = pr * co;
+                Ei = pr * si;
+                G2 = fast_rcp(pr * pr);
                 dt_ref = dt;
                 ddt = 0.0;
             }
-            const double x = cj * ddt;              // exp(-x), exp(+x) to second order
-            const double hx = 0.5 * x;
-            rho *= p_ref * fma(x, hx - 1.0, 1.0);
-            irho *= ip_ref * fma(x, hx + 1.0, 1.0);
+            const double xr = -cj * ddt, xi = dj * ddt;
+            const double qr = 1.0 + fma(0.5, fma(xr, xr, -xi * xi), xr);    // exp(xr + i xi)
+            const double qi = fma(xr, xi, xi);
+            const double Mr = fma(Er, qr, -Ei * qi), Mi = fma(Er, qi, Ei * qr);
+            const double c2 = fma(cu, Mr, -su * Mi);
+            su = fma(cu, Mi, su * Mr);
+            cu = c2;
+            const double x2 = -2.0 * xr;
+            irho2 *= G2 * (1.0 + fma(0.5 * x2, x2, x2));
             de = -1.0;
         }
-        double si, co;
-        fm_sincos(dj * tn, &si, &co);               // ONE rounded multiply for the phase
-        const double own = is_sin ? si : co, oth = is_sin ? co : si;
-        ut = fma(uA, own, uB * oth) * rho;          // pad lanes: uA = uB = 0
-        vt = colok ? own * irho : 0.0;
+        ut = fma(k1, cu, k2 * su);                  // pad lanes: k1 = k2 = 0
+        vt = colok ? (is_sin ? su : cu) * irho2 : 0.0;
     }
 };
 
