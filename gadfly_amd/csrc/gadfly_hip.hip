@@ -747,7 +747,7 @@ struct RowGen {
             k2 = is_sin ? ac_[ck] : bc_[ck];
         }
         cmax = cmax_[b];
-        wmax = wave_max(fmax(cj, fabs(dj)));
+        wmax = read_lane(wave_max(fmax(cj, fabs(dj))), 0);      // uniform: lives in SGPRs
         block = block_;
         gap = gap_;
         cu = 1.0; su = 0.0; irho2 = 1.0; Er = 1.0; Ei = 0.0; G2 = 1.0; dt_ref = -1.0;
