@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--overlap", action="store_true",
                     help="build tile k+1 on a side stream during the sweep of tile k (slower: "
                          "the build waves displace one of the two sweep waves per SIMD)")
-    ap.add_argument("--kernel", choices=["auto", "blocked", "fused"], default="auto",
+    ap.add_argument("--kernel", choices=["auto", "blocked", "fused", "pipelined"], default="auto",
                     help="sweep kernel: blocked = k_factor4 (FP64 MFMA, rank-16 blocks), "
                          "fused = k_factor3 (vector FMA); auto takes blocked when supported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -108,7 +108,9 @@ def main():
                                          overlap_build=args.overlap)
     packs = [ev.pack(walkers(s)) for s in range(nsteps)]
     eng = ev.engine
-    if args.kernel == "fused":
+    if args.kernel == "pipelined":
+        eng.lib.gf_set_pipelined(1)
+    if args.kernel in ("fused", "pipelined"):
         eng.allow_blocked = False
     elif args.kernel == "blocked" and not eng._blocked_ok():
         raise SystemExit("--kernel blocked: not supported for this term structure / cadence")
@@ -193,7 +195,9 @@ def main():
             "bound": "hbm",
             "kernel": {"blocked": "k_factor4 (fused build + factor + forward solve, rank-16 blocks "
                                   "on v_mfma_f64_16x16x4)",
-                       "fused": "k_factor3 (fused build + factor + forward solve)"}.get(
+                       "fused": "k_factor5 (fused build + factor + forward solve, post work of row n-1 "
+                                "interleaved with sweep n)" if args.kernel == "pipelined" else
+                                "k_factor3 (fused build + factor + forward solve)"}.get(
                            getattr(eng, "kernel_used", ""), "k_factor"),
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": traffic,

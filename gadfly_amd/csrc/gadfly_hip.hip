@@ -17,6 +17,8 @@
 // No CUDA compatibility layer, no Triton, no CPU fallback.
 
 #include <hip/hip_runtime.h>
+#include <utility>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 #include <math.h>
@@ -62,6 +64,13 @@ __device__ __forceinline__ double read_lane(double v, int l) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
+}
+
+// Tell the compiler a value is wave-uniform (it then lives in SGPRs and branches on it are scalar)
+__device__ __forceinline__ int64_t uni64(int64_t v) {
+    const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL));
+    const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return ((int64_t)hi << 32) | (unsigned int)lo;
 }
 
 // Fixed-shape tree sum over the 64 lanes, result broadcast to every lane (deterministic).
@@ -505,6 +514,9 @@ __global__ void __launch_bounds__(256) k_build2(const Build2Args A) {
 // batches in flight ahead of the FMAs, so the LDS latency is paid once per sweep and not once
 // per read (hipcc otherwise parks every read right in front of its use).
 constexpr int SW_BR = 4, SW_AHEAD = 2;
+#ifndef GF_CHAIN_PRIO
+#define GF_CHAIN_PRIO 1
+#endif
 
 // issue the reads of the first SW_AHEAD batches (done early, under the reduction of the
 // previous row: the operands do not depend on it)
@@ -770,41 +782,76 @@ struct RowGen {
     // regular cadence: |(c, d) ddt| < 2e-6 => truncation < 2e-18 per row); any other spacing
     // refreshes the cache (sincos + exp, as an anchor costs).  Per-row rounding accumulates over
     // at most 63 rows (~1e-14); scratch/proto_rot.py: log-likelihood to 1e-14, d_n to 4e-11.
-    __device__ __forceinline__ void next(const double tn, const int64_t g, double &ut, double &vt,
-                                         bool &rst, double &de) {
-        const double dt = tn - t_m1;
+    // The pieces of next(): kind of the row at time tn (0 = plain rotation step, 1 = the cached
+    // multipliers must be refreshed first, 2 = reset row / anchor); wave-uniform.
+    __device__ __forceinline__ int peek(const double tn, const int64_t g, double &dt, double &ddt) const {
+        dt = tn - t_m1;
+        ddt = dt - dt_ref;
+        if (((g & (block - 1)) == 0) || (cmax * dt > gap)) return 2;
+        return (fabs(ddt) * wmax < 2e-6) ? 0 : 1;
+    }
+    __device__ __forceinline__ void anchor(const double tn, const int64_t g, double &de) {
+        de = (g > 0) ? (tn - tref) : 0.0;
+        tref = tn;
         t_m1 = tn;
-        rst = ((g & (block - 1)) == 0) || (cmax * dt > gap);
-        if (rst) {                                  // wave-uniform
-            de = (g > 0) ? (tn - tref) : 0.0;
-            tref = tn;
-            fm_sincos(dj * tn, &su, &cu);           // real columns: d = 0 -> (1, 0)
-            irho2 = 1.0;
-        } else {
-            double ddt = dt - dt_ref;
-            if (!(fabs(ddt) * wmax < 2e-6)) {       // wave-uniform: new cadence -> new multipliers
-                double si, co;
-                fm_sincos(dj * dt, &si, &co);
-                const double pr = fm_exp(-cj * dt);
-                Er = pr * co;
-                Ei = pr * si;
-                G2 = fast_rcp(pr * pr);
-                dt_ref = dt;
-                ddt = 0.0;
-            }
-            const double xr = -cj * ddt, xi = dj * ddt;
-            const double qr = 1.0 + fma(0.5, fma(xr, xr, -xi * xi), xr);    // exp(xr + i xi)
-            const double qi = fma(xr, xi, xi);
-            const double Mr = fma(Er, qr, -Ei * qi), Mi = fma(Er, qi, Ei * qr);
-            const double c2 = fma(cu, Mr, -su * Mi);
-            su = fma(cu, Mi, su * Mr);
-            cu = c2;
-            const double x2 = -2.0 * xr;
-            irho2 *= G2 * (1.0 + fma(0.5 * x2, x2, x2));
-            de = -1.0;
-        }
+        fm_sincos(dj * tn, &su, &cu);               // real columns: d = 0 -> (1, 0)
+        irho2 = 1.0;
+    }
+    __device__ __forceinline__ void refresh(const double dt) {
+        double si, co;
+        fm_sincos(dj * dt, &si, &co);
+        const double pr = fm_exp(-cj * dt);
+        Er = pr * co;
+        Ei = pr * si;
+        G2 = fast_rcp(pr * pr);
+        dt_ref = read_lane(dt, 0);                  // uniform: keep it in SGPRs
+    }
+    __device__ __forceinline__ void step(const double tn, const double ddt) {
+        t_m1 = tn;
+        const double xr = -cj * ddt, xi = dj * ddt;
+        const double qr = 1.0 + fma(0.5, fma(xr, xr, -xi * xi), xr);    // exp(xr + i xi)
+        const double qi = fma(xr, xi, xi);
+        const double Mr = fma(Er, qr, -Ei * qi), Mi = fma(Er, qi, Ei * qr);
+        const double c2 = fma(cu, Mr, -su * Mi);
+        su = fma(cu, Mi, su * Mr);
+        cu = c2;
+        const double x2 = -2.0 * xr;
+        irho2 *= G2 * (1.0 + fma(0.5 * x2, x2, x2));
+    }
+    __device__ __forceinline__ void emit(double &ut, double &vt) const {
         ut = fma(k1, cu, k2 * su);                  // pad lanes: k1 = k2 = 0
         vt = colok ? (is_sin ? su : cu) * irho2 : 0.0;
+    }
+    __device__ __forceinline__ void next(const double tn, const int64_t g, double &ut, double &vt,
+                                         bool &rst, double &de) {
+        double dt, ddt;
+        const int kind = peek(tn, g, dt, ddt);
+        rst = kind == 2;
+        if (kind == 2) {                            // wave-uniform
+            anchor(tn, g, de);
+        } else {
+            if (kind == 1) { refresh(dt); ddt = 0.0; }      // wave-uniform: new cadence
+            step(tn, ddt);
+            de = -1.0;
+        }
+        emit(ut, vt);
+    }
+
+    // Park / restore the ten per-lane doubles in LDS (buf[10][64]): a kernel that needs its
+    // registers while no row is being generated spills them here instead of to scratch.
+    __device__ __forceinline__ void park(double *buf, int lane) const {
+        buf[0 * 64 + lane] = cj; buf[1 * 64 + lane] = dj; buf[2 * 64 + lane] = k1; buf[3 * 64 + lane] = k2;
+        buf[4 * 64 + lane] = cu; buf[5 * 64 + lane] = su; buf[6 * 64 + lane] = irho2;
+        buf[7 * 64 + lane] = Er; buf[8 * 64 + lane] = Ei; buf[9 * 64 + lane] = G2;
+    }
+    __device__ __forceinline__ void park_state(double *buf, int lane) const {       // what next() changes
+        buf[4 * 64 + lane] = cu; buf[5 * 64 + lane] = su; buf[6 * 64 + lane] = irho2;
+        buf[7 * 64 + lane] = Er; buf[8 * 64 + lane] = Ei; buf[9 * 64 + lane] = G2;
+    }
+    __device__ __forceinline__ void unpark(const double *buf, int lane) {
+        cj = buf[0 * 64 + lane]; dj = buf[1 * 64 + lane]; k1 = buf[2 * 64 + lane]; k2 = buf[3 * 64 + lane];
+        cu = buf[4 * 64 + lane]; su = buf[5 * 64 + lane]; irho2 = buf[6 * 64 + lane];
+        Er = buf[7 * 64 + lane]; Ei = buf[8 * 64 + lane]; G2 = buf[9 * 64 + lane];
     }
 };
 
@@ -890,7 +937,12 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
             q = 0.0;
             zq = 0.0;
         }
+        __builtin_amdgcn_s_setprio(0);
         const double tmp = sweep_run<ROWS, false>(T, ab, wb, s_u, s_w, q, 0.0);
+        // the serial part of the row (reduction, reciprocal, next row's operands) wins the issue
+        // arbitration against the partner wave's FMA stream: its instructions are dependent and
+        // each lost slot lengthens the chain, the partner's are not
+        __builtin_amdgcn_s_setprio(GF_CHAIN_PRIO);
         const double r = fl ? 0.0 : (vt_c - tmp);
         // next row's operands: generated here, where the operand ring is dead (register budget)
         G.next(t_n1, g0 + n + 1, ut, vt, rst, de);
@@ -928,6 +980,350 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     for (int i = 0; i < ROWS; ++i) {
         const double v = fma(s_w[i], q, T[i]);
         if (fl) Fg[i] = v; else Sg[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_factor5: k_factor3 with the per-row serial chain taken off the sweep's critical path.
+//
+// In k_factor3 the sweep of row n+1 folds the rank-1 update of row n, so it cannot start before
+// q_n = r_n / d_n is known: sweep -> DPP reduction -> reciprocal -> sweep is one dependent chain
+// and a wave spends more than half of every row waiting on it (one wave alone: 2300 cycles per
+// row for ~900 cycles of issued work; two waves per SIMD do not cover it).  Here T stays ONE
+// update behind:
+//     sweep n :  T += r_{n-2} q_{n-2}^T ;  tmp_p = T u~_n                    (= T_{n-2} u~_n)
+//     tmp_n   =  tmp_p + q_{n-1} sigma_{n-1} ,   sigma_{n-1} = r_{n-1} . u~_n
+//     d_n     =  a_n - (u~_n . tmp_p + sigma_{n-1}^2 / d_{n-1}) ;  z_n = y_n - tmp_n[63]
+//     r_n = v~_n - tmp_n ;  q_n = r_n / d_n ;  sigma_n = r_n . u~_{n+1}
+// which is the same arithmetic (T_{n-1} u~_n = T_{n-2} u~_n + q_{n-1} (r_{n-1} . u~_n)).  Sweep n
+// needs only r_{n-2}, q_{n-2} and u~_n, all known one row earlier, so the "post" work of row n-1
+// (two DPP reductions, the reciprocal, r and q) is independent of it and is issued in stages
+// BETWEEN the sweep's FMA batches; the only chain left from row to row is d_{n-1} -> d_n (a few
+// scalar operations).  Costs one more reduction per row.  Reset rows drain the pipeline (fold
+// both pending updates, decay) and restart it.  Same arguments, state hand-off and results as
+// k_factor3, chunk mode included.
+// ------------------------------------------------------------------------------------
+template <class F, int... K>
+__device__ __forceinline__ void static_for(F &&f, std::integer_sequence<int, K...>) {
+    (f(std::integral_constant<int, K>{}), ...);
+}
+
+//   MODE 0:  T_i += xw_i q ;  acc += xa_i T_i     (fold + mat-vec; hook(k) after batch k)
+//   MODE 1:  T_i  = (T_i + xw_i q) (xa_i el)      (fold + decay)
+//   MODE 2:  T_i += xw_i q                         (fold only)
+constexpr int PP_BR = 4, PP_AHEAD = 2;  // 4-row batches, 2 batches (8 rows) of LDS look-ahead
+template <int ROWS, int MODE, class Hook>
+__device__ __forceinline__ double sweep_pipe(double (&T)[ROWS], double (&ab)[PP_AHEAD + 1][PP_BR],
+                                             double (&wb)[PP_AHEAD + 1][PP_BR], const double *xa,
+                                             const double *xw, const double q, const double el,
+                                             Hook &&hook) {
+    constexpr int BR = PP_BR, NB = ROWS / BR, AHEAD = PP_AHEAD;
+    static_assert(ROWS % BR == 0, "ROWS must be a multiple of 4");
+    double acc0 = 0.0, acc1 = 0.0;
+    static_for([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k + AHEAD < NB) {
+#pragma unroll
+            for (int r = 0; r < BR; ++r) {
+                if constexpr (MODE != 2) ab[(k + AHEAD) % (AHEAD + 1)][r] = xa[(k + AHEAD) * BR + r];
+                wb[(k + AHEAD) % (AHEAD + 1)][r] = xw[(k + AHEAD) * BR + r];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int c = k % (AHEAD + 1);
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int r = 0; r < BR; ++r)
+                T[k * BR + r] = fma(wb[c][r], q, T[k * BR + r]) * (ab[c][r] * el);
+        } else if constexpr (MODE == 2) {
+#pragma unroll
+            for (int r = 0; r < BR; ++r) T[k * BR + r] = fma(wb[c][r], q, T[k * BR + r]);
+        } else {
+            T[k * BR + 0] = fma(wb[c][0], q, T[k * BR + 0]);
+            T[k * BR + 1] = fma(wb[c][1], q, T[k * BR + 1]);
+            T[k * BR + 2] = fma(wb[c][2], q, T[k * BR + 2]);
+            T[k * BR + 3] = fma(wb[c][3], q, T[k * BR + 3]);
+            acc0 = fma(ab[c][0], T[k * BR + 0], acc0);
+            acc1 = fma(ab[c][1], T[k * BR + 1], acc1);
+            acc0 = fma(ab[c][2], T[k * BR + 2], acc0);
+            acc1 = fma(ab[c][3], T[k * BR + 3], acc1);
+            asm volatile("" : "+v"(acc0), "+v"(acc1));
+            hook(kc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }, std::make_integer_sequence<int, NB>{});
+    return acc0 + acc1;
+}
+
+template <int ROWS>
+__device__ __forceinline__ void pipe_preload(double (&ab)[PP_AHEAD + 1][PP_BR],
+                                             double (&wb)[PP_AHEAD + 1][PP_BR],
+                                             const double *xa, const double *xw) {
+    constexpr int NB = ROWS / PP_BR;
+#pragma unroll
+    for (int k = 0; k < PP_AHEAD && k < NB; ++k) {
+#pragma unroll
+        for (int r = 0; r < PP_BR; ++r) { ab[k][r] = xa[k * PP_BR + r]; wb[k][r] = xw[k * PP_BR + r]; }
+    }
+}
+
+// STORES: the chunk-mode extras (r~, u~, w~ rows, reset spans) are compiled in; the plain
+// log-likelihood sweep (gf_loglike_fused) runs the variant without them.
+// No global memory access in the hot loop: t, y, diag come through a 64-row LDS window refilled
+// 32 rows at a time, d and z leave through a 32-row LDS buffer flushed with coalesced stores
+// (base pointers and prefetched scalars would otherwise not fit the SGPR file next to the
+// pipeline's state and end up, via VGPRs, in scratch).
+template <int ROWS, bool STORES>
+__global__ void __launch_bounds__(64, 2)
+k_factor5(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int nch,
+          const int Jr, const int Jc, const int block, const double gap,
+          const double *__restrict__ ar_, const double *__restrict__ cr_,
+          const double *__restrict__ ac_, const double *__restrict__ bc_,
+          const double *__restrict__ cc_, const double *__restrict__ dc_,
+          const double *__restrict__ diag_add_, const double *__restrict__ cmax_,
+          const double *__restrict__ t_, const int64_t t_bs,
+          const double *__restrict__ diag_, const int64_t diag_bs,
+          const double *__restrict__ y_, const int64_t y_bs,
+          double *__restrict__ d_, double *__restrict__ z_, double *__restrict__ r_out,
+          double *__restrict__ Ut_out, double *__restrict__ Wt_out, double *__restrict__ de_out,
+          double *__restrict__ S_state, double *__restrict__ F_state,
+          int32_t *__restrict__ info) {
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;                       // state slot = problem * nch + chunk
+    if (info[b] != 0) return;
+    const int pr = b / nch, ch = b - pr * nch;
+    const int64_t c0 = (int64_t)ch * chunk_len;
+    const int rows = (int)((N - c0 < chunk_len) ? (N - c0) : chunk_len);    // < 2^31 rows per chunk / tile
+    const int64_t g0 = n_first + c0;
+    const size_t pb = (size_t)pr * N + c0;
+    const double *__restrict__ tg = t_ + (size_t)pr * t_bs + g0;
+    const double *__restrict__ yg = y_ + (size_t)pr * y_bs + g0;
+    const double *__restrict__ gg = diag_ ? diag_ + (size_t)pr * diag_bs + g0 : nullptr;
+    double *__restrict__ dg = d_ + pb;
+    double *__restrict__ zg = z_ + pb;
+    double *__restrict__ Sg = S_state + (size_t)b * (64 * 64) + (size_t)lane * 64;
+    double *__restrict__ Fg = F_state + (size_t)b * 64;
+    const double diag_add = diag_add_[pr];
+
+    RowGen G;
+    G.init(lane, pr, Jr, Jc, block, gap, ar_, cr_, ac_, bc_, cc_, dc_, cmax_, tg, g0);
+
+    __shared__ double s_gen[10 * 64];   // the generator's per-lane state, parked during the sweeps
+    __shared__ __attribute__((aligned(16))) double s_w[2][64];   // r_{n-2} | r_{n-1}  (by parity)
+    __shared__ __attribute__((aligned(16))) double s_u[2][64];   // u~_n    | u~_{n+1}
+    __shared__ __attribute__((aligned(16))) double s_e[64];      // block decay E at reset rows
+    __shared__ double s_in[3][64];      // t, y, diag of rows [n, n + 32 ...) at slot row & 63
+    __shared__ double s_out[2][32];     // d, z of the last <= 32 rows at slot row & 31
+    __shared__ double s_v[2][64];       // v~_n | v~_{n+1} (lane form, by parity)
+    const bool fl = lane == 63;     // pad lane carrying the forward solve (W < 64)
+
+    double T[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) T[i] = fl ? Fg[i] : Sg[i];
+    int32_t fail = 0;
+
+    // rows [first, first + 32) of t, y, diag into the window (the caller pads the series by three
+    // elements: row rows + 2 is the last one that may be read)
+    auto refill = [&](const int first) {
+        if (lane < 32) {
+            int i = first + lane;
+            if (i > rows + 2) i = rows + 2;
+            const int slot = (first + lane) & 63;
+            s_in[0][slot] = tg[i];
+            s_in[1][slot] = yg[i];
+            s_in[2][slot] = gg ? gg[i] : 0.0;
+        }
+    };
+    // d, z of rows [m & ~31, m] to memory (lanes 0..31: d, lanes 32..63: z)
+    auto flush = [&](const int m) {
+        const int first = m & ~31;
+        const int k = lane & 31;
+        if (first + k <= m) {
+            double *dst = (lane < 32) ? dg : zg;
+            dst[first + k] = s_out[lane >> 5][k];
+        }
+    };
+    refill(0);
+    refill(32);
+
+    // row m = n - 1 ("previous") and row n lane values; scalars of row m
+    double u_m = 0.0, u_n, v_n;                     // (v~ rows and a, y of row m wait in LDS)
+    double tp = 0.0;                                // tmp_p of row m
+    double qo = 0.0, sgo = 0.0, invo = 1.0;         // q_{m-1}, sigma_{m-1}, 1 / d_{m-1}
+    double de_n;
+    bool rst_n;
+    G.next(tg[0], g0, u_n, v_n, rst_n, de_n);
+    G.park(s_gen, lane);
+    s_w[0][lane] = 0.0; s_w[1][lane] = 0.0;
+    s_u[0][lane] = u_n;
+    s_v[0][lane] = v_n;
+    wave_lds_fence();
+
+    double ab[PP_AHEAD + 1][PP_BR], wb[PP_AHEAD + 1][PP_BR];
+    auto nohook = [](auto) {};
+    constexpr int NS = 19, NB = ROWS / PP_BR;
+    int n = 0;              // row within this chunk (g0 is a multiple of block: the block phase is n's)
+
+    // post work of row m = n - 1 in NS branch-free stages; results in the variables below
+    double x, tm, r_m = 0.0, d_m = 1.0, z_m = 0.0, inv = 1.0, q_m = 0.0, xs, sg_m = 0.0;
+    double *swn = s_w[1];
+    auto post = [&](auto sc) {
+        constexpr int st = decltype(sc)::value;
+        if constexpr (st == 0) { x = u_m * tp; tm = fma(qo, sgo, tp); }
+        else if constexpr (st == 1) x += dpp_get<0xB1, 0xf>(x);
+        else if constexpr (st == 2) x += dpp_get<0x4E, 0xf>(x);
+        else if constexpr (st == 3) x += dpp_get<0x141, 0xf>(x);
+        else if constexpr (st == 4) x += dpp_get<0x140, 0xf>(x);
+        else if constexpr (st == 5) x += dpp_get<0x142, 0xa>(x);
+        else if constexpr (st == 6) x += dpp_get<0x143, 0xc>(x);
+        else if constexpr (st == 7) {
+            const double sp = read_lane(x, 63), t63 = read_lane(tm, 63);
+            const int mm = n - 1;
+            d_m = (s_in[2][mm & 63] + diag_add) - fma(sgo * invo, sgo, sp);
+            z_m = s_in[1][mm & 63] - t63;
+            r_m = fl ? 0.0 : (s_v[mm & 1][lane] - tm);
+            swn[lane] = r_m;                        // operand of the fold in sweep n+1
+        }
+        else if constexpr (st == 8) inv = __builtin_amdgcn_rcp(d_m);
+        else if constexpr (st == 9) inv = fma(fma(-d_m, inv, 1.0), inv, inv);
+        else if constexpr (st == 10) inv = fma(fma(-d_m, inv, 1.0), inv, inv);
+        else if constexpr (st == 11) { q_m = (fl ? z_m : r_m) * inv; xs = r_m * u_n; }
+        else if constexpr (st == 12) xs += dpp_get<0xB1, 0xf>(xs);
+        else if constexpr (st == 13) xs += dpp_get<0x4E, 0xf>(xs);
+        else if constexpr (st == 14) xs += dpp_get<0x141, 0xf>(xs);
+        else if constexpr (st == 15) xs += dpp_get<0x140, 0xf>(xs);
+        else if constexpr (st == 16) xs += dpp_get<0x142, 0xa>(xs);
+        else if constexpr (st == 17) xs += dpp_get<0x143, 0xc>(xs);
+        else if constexpr (st == 18) sg_m = read_lane(xs, 63);
+    };      // (no branches in the stages: a branch would cut the sweep's basic block in two)
+
+    // results of row m = n - 1 out; false if its pivot is not positive
+    auto emit = [&](const double q_st) -> bool {
+        const int m = n - 1;
+        if (!(read_lane(d_m, 0) > 0.0)) {           // (uniform by construction; say so)
+            const int64_t gf = g0 + m + 1;
+            fail = (int32_t)(gf > 0x7fffffff ? 0x7fffffff : gf);
+            return false;
+        }
+        if constexpr (STORES) {
+            const size_t o = (pb + (size_t)m) * 64 + lane;
+            if (r_out) r_out[o] = r_m;
+            if (Ut_out) { Ut_out[o] = u_m; Wt_out[o] = fl ? 0.0 : q_st; }
+        }
+        const int slot = m & 31;
+        s_out[0][slot] = d_m;                       // every lane writes the same value
+        s_out[1][slot] = z_m;
+        if (slot == 31 || m == rows - 1) {          // wave-uniform, once per 32 rows
+            wave_lds_fence();
+            flush(m);
+        }
+        return true;
+    };
+    // make row n the "previous" one; (u_c, v_c) is row n+1, already generated
+    auto rotate = [&](const double tp_new, const double u_c, const double v_c) {
+        s_u[(n + 1) & 1][lane] = u_c;
+        s_v[(n + 1) & 1][lane] = v_c;
+        tp = tp_new;
+        u_m = u_n; u_n = u_c;
+        qo = q_m; sgo = sg_m; invo = inv;
+        n = __builtin_amdgcn_readfirstlane(n + 1);
+        if ((n & 31) == 0) refill(n + 31);          // wave-uniform, once per 32 rows; row n-1's
+                                                    // slot (read by its post work) stays intact
+        wave_lds_fence();
+    };
+    // row n+1 with everything the generator may need (anchor, refreshed multipliers); only
+    // called outside the inner loop, which handles plain rotation steps itself
+    auto advance_any = [&](const double tp_new) {
+        double u_c = 0.0, v_c = 0.0;
+        rst_n = false; de_n = -1.0;
+        if (n + 1 < rows) {
+            G.unpark(s_gen, lane);
+            G.next(read_lane(s_in[0][(n + 1) & 63], 0), g0 + n + 1, u_c, v_c, rst_n, de_n);
+            G.park_state(s_gen, lane);
+        }
+        rotate(tp_new, u_c, v_c);
+    };
+
+    for (;;) {
+        // ---- row n opens a scaling block (or n == rows): drain the pipeline, decay, restart ----
+        if (rst_n || n == 0 || n == rows) {
+            const int par = n & 1;
+            double *swc = s_w[par], *suc = s_u[par];
+            swn = s_w[par ^ 1];
+            if (n > 0) {
+                static_for(post, std::make_integer_sequence<int, NS>{});
+                wave_lds_fence();
+                pipe_preload<ROWS>(ab, wb, swc, swc);                       // fold update n-2
+                (void)sweep_pipe<ROWS, 2>(T, ab, wb, swc, swc, qo, 0.0, nohook);
+                if (!emit(q_m)) break;
+            }
+            if (n == rows) {
+                pipe_preload<ROWS>(ab, wb, swn, swn);                       // fold update n-1
+                (void)sweep_pipe<ROWS, 2>(T, ab, wb, swn, swn, q_m, 0.0, nohook);
+                break;
+            }
+            if constexpr (STORES) { if (de_out && lane == 0) de_out[pb + n] = rst_n ? de_n : -1.0; }
+            const double el = fm_exp(-s_gen[lane] * (rst_n ? de_n : 0.0));  // c_j; pad lanes: 0 -> 1
+            s_e[lane] = el;
+            wave_lds_fence();
+            pipe_preload<ROWS>(ab, wb, s_e, swn);                           // fold update n-1, decay
+            (void)sweep_pipe<ROWS, 1>(T, ab, wb, s_e, swn, q_m, el, nohook);
+            pipe_preload<ROWS>(ab, wb, suc, swc);
+            const double tp_new = sweep_pipe<ROWS, 0>(T, ab, wb, suc, swc, 0.0, 0.0, nohook);
+            q_m = 0.0; sg_m = 0.0; inv = 1.0;                               // nothing pending any more
+            advance_any(tp_new);
+            continue;
+        }
+        // ---- rows inside the block: sweep n with the post work of row n-1 between its batches;
+        //      the loop itself only takes plain rotation steps of the generator ----------------
+        double tp_last = 0.0;
+        {
+            // loop-invariant, wave-uniform scalars of the generator's row test (peek), held in
+            // SGPRs explicitly: the inner loop never refreshes the cadence or re-anchors
+            const double dtr = read_lane(G.dt_ref, 0), cmx = read_lane(G.cmax, 0);
+            const double wmx = read_lane(G.wmax, 0), gp = read_lane(G.gap, 0);
+            const int bmask = __builtin_amdgcn_readfirstlane(G.block - 1);
+            const int nrows = __builtin_amdgcn_readfirstlane(rows);
+            double tm1 = read_lane(G.t_m1, 0);
+            for (;;) {
+                const int par = n & 1;
+                double *swc = s_w[par], *suc = s_u[par];
+                swn = s_w[par ^ 1];
+                if constexpr (STORES) { if (de_out && lane == 0) de_out[pb + n] = -1.0; }
+                pipe_preload<ROWS>(ab, wb, suc, swc);
+                const double tp_new = sweep_pipe<ROWS, 0>(T, ab, wb, suc, swc, qo, 0.0, [&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    constexpr int lo = k * NS / NB, hi = (k + 1) * NS / NB;
+                    static_for([&](auto jc) { post(std::integral_constant<int, lo + decltype(jc)::value>{}); },
+                               std::make_integer_sequence<int, hi - lo>{});
+                });
+                tp_last = tp_new;
+                if (!emit(q_m)) break;
+                if (n + 1 >= nrows) break;
+                // kind of row n+1 (RowGen::peek; g0 is a multiple of block, so the block phase is n's)
+                const double t_next = read_lane(s_in[0][(n + 1) & 63], 0);
+                const double dt = t_next - tm1, ddt = dt - dtr;
+                if ((((n + 1) & bmask) == 0) || (cmx * dt > gp) || !(fabs(ddt) * wmx < 2e-6)) break;
+                tm1 = t_next;
+                G.unpark(s_gen, lane);
+                G.step(t_next, ddt);
+                double u_c, v_c;
+                G.emit(u_c, v_c);
+                G.park_state(s_gen, lane);
+                rotate(tp_new, u_c, v_c);
+            }
+            G.t_m1 = tm1;
+        }
+        if (fail) break;
+        advance_any(tp_last);       // row n+1 is a reset row, needs new multipliers, or does not exist
+    }
+    if (fail) {
+        if (lane == 0) info[b] = fail;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        if (fl) Fg[i] = T[i]; else Sg[i] = T[i];
     }
 }
 
@@ -2539,7 +2935,10 @@ int gf_factor_scaled(int B, int64_t N, int64_t n_first, int W, int ld, const dou
     return check_launch("gf_factor_scaled");
 }
 
-#define GF_F3_CASE(R) case R: hipLaunchKernelGGL((k_factor3<R>), dim3(B * nch), dim3(64), 0, st, N, n_first, chunk_len, nch, Jr, Jc, block, gap, ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out, Ut_out, Wt_out, de_out, S_state, F_state, info); break;
+#define GF_F3_ARGS dim3(B * nch), dim3(64), 0, st, N, n_first, chunk_len, nch, Jr, Jc, block, gap, ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out, Ut_out, Wt_out, de_out, S_state, F_state, info
+#define GF_F3_CASE(R) case R: if (!g_pipelined) hipLaunchKernelGGL((k_factor3<R>), GF_F3_ARGS); else if (r_out || Ut_out || de_out) hipLaunchKernelGGL((k_factor5<R, true>), GF_F3_ARGS); else hipLaunchKernelGGL((k_factor5<R, false>), GF_F3_ARGS); break;
+static int g_pipelined = 0;         // gf_set_pipelined(1) selects the pipelined k_factor5 (experimental, slower: DESIGN.md 4.2)
+
 
 static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int64_t chunk_len, int nch,
                         int Jr, int Jc, int block,
@@ -2573,6 +2972,12 @@ static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int6
         default: return set_err("%s: internal dispatch error", who);
     }
     return check_launch(who);
+}
+
+int gf_set_pipelined(int on) {
+    const int old = g_pipelined;
+    g_pipelined = on ? 1 : 0;
+    return old;
 }
 
 int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int block,

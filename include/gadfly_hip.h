@@ -143,6 +143,15 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
                      int32_t *info, void *stream);
 
 /*
+ * gf_set_pipelined(1) makes gf_loglike_fused / gf_chunk_sweep run the software-pipelined sweep
+ * (k_factor5: the reductions, reciprocal and r, q of row n-1 are issued between the FMA batches of
+ * sweep n).  Experimental and currently slower than the default k_factor3 (DESIGN.md 4.2 has the
+ * counters); kept, parity-tested, for A/B measurements.  Process-wide switch, returns the
+ * previous setting; results agree to rounding.
+ */
+int gf_set_pipelined(int on);
+
+/*
  * The same fused sweep in blocked (rank-16) form on the FP64 matrix pipe: sixteen
  * rows of one scaling block are taken together, P = T U~, H = (V~ - P)^T U~ = L D L^T, T += R~ R~^T
  * run as v_mfma_f64_16x16x4_f64 and only the 16 x 16 LDL^T is sequential.  Same arguments, state
