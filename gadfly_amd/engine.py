@@ -302,8 +302,10 @@ class ScaledFactor:
         self.B, self.N, self.W = owner.B, owner.N, owner.W
         self.chunk_len, self.nch = chunk_len, nch
         w = owner._tp
-        self.Ut, self.Wt, self.de, self.Phi = w["Ut"], w["Wt"], w["de"], w["Phi"]
-        self.d = w["d"][:self.B * self.N].view(self.B, self.N)
+        self.Ut, self.Wt, self.de, self.Phi = w["Ut"], w["Wt"], w["de"], w["PhiT"]
+        # own copy of the pivots: the shared buffer holds the nominal pass' values while a later
+        # evaluation is in flight
+        self.d = w["d"][:self.B * self.N].view(self.B, self.N).clone()
         self.c = owner._pack[3]
         self.t = owner.t
         self.info = owner.info
@@ -682,6 +684,9 @@ class StreamingBatch:
             w["Ut"] = torch.empty((B * N, 64), **f64)
             w["Wt"] = torch.empty((B * N, 64), **f64)
             w["de"] = torch.empty((B * N,), **f64)
+            # the factor's own copy of the chunk transitions: a later non-storing evaluation
+            # (log_likelihood of another y) refills "Phi" with the NOMINAL pass' transitions
+            w["PhiT"] = torch.empty((B * nch, 4096), **f64)
         st = torch.cuda.current_stream(self.device).cuda_stream
         w["S"].zero_(); w["F"].zero_(); w["info"].zero_()
         coeffs = (p(real[0]), p(real[1]), p(comp[0]), p(comp[1]), p(comp[2]), p(comp[3]))
@@ -689,10 +694,10 @@ class StreamingBatch:
                0 if self.diag is None else self._bs(self.diag), p(self.y), self._bs(self.y))
         none3 = (None, None, None)
 
-        def transition():
+        def transition(phi="Phi"):
             rc = lib.gf_chunk_transition(B, N, chunk_len, nch, self.Jr, self.Jc, block, *coeffs,
                                          p(cmax), p(self.t), self._bs(self.t), p(w["d"]),
-                                         p(w["z"]), p(w["r"]), p(w["h"]), p(w["Phi"]),
+                                         p(w["z"]), p(w["r"]), p(w["h"]), p(w[phi]),
                                          p(w["G"]), p(w["m"]), st)
             _lib.check(rc, "gf_chunk_transition")
 
@@ -710,7 +715,7 @@ class StreamingBatch:
                                 p(w["S"]), p(w["F"]), p(w["info"]), st)
         _lib.check(rc, "gf_chunk_sweep")
         if store and nch > 1:
-            transition()                    # on the TRUE rows: Phi = true chunk transitions
+            transition("PhiT")              # on the TRUE rows: the true chunk transitions
         rc = lib.gf_reduce_tile(B, N, p(w["d"]), p(w["z"]), p(w["work"]), p(w["acc"]), 1, st)
         _lib.check(rc, "gf_reduce_tile")
         # a chunk that failed marks its problem

@@ -437,6 +437,37 @@ def test_gaussian_process_fast_path_long_series(hip):
     assert gp._factor is not None
     alpha = cref.solve_upper(t, c, U, W_ref, cref.solve_lower(t, c, U, W_ref, y - 1.5) / d_ref)
     assert _relmax(mu, y - prob["diag_user"] * alpha) < TOL_VEC
+    # the stored factor must survive later evaluations that reuse the time-parallel buffers
+    # (log_likelihood of another y refills the shared transition / pivot work arrays)
+    y2 = y[::-1].copy()
+    ref2, _ = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y2 - 1.5)
+    assert abs(gp.log_likelihood(y2) - ref2) <= RTOL_LL * abs(ref2)
+    assert _relmax(gp.apply_inverse(y - 1.5), alpha) < TOL_VEC
+
+
+def test_full_size_round_trip(hip):
+    """BASELINE.json's full size (N = 1e6, J = 30) through size-independent identities:
+    y = L n  =>  y^T K^-1 y = n^T n  (dot_tril, then apply_inverse), and the log-likelihood of that
+    y equals -(n^T n + log det K + N log 2 pi) / 2.  Exercises the time-parallel factor (tree
+    combine), the stored scaled factor and its chunk-parallel sweeps at the benchmark's shape."""
+    import gadfly_amd
+    from gadfly_amd.synth import solar_like_hyperparameters, uniform_times
+    N, J = 1_000_000, 30
+    k = gadfly_amd.StellarOscillatorKernel(solar_like_hyperparameters(J), texp=60.0)
+    t = uniform_times(N, 60.0)
+    gp = gadfly_amd.GaussianProcess(k, t=t, yerr=30.0)
+    rng = np.random.Generator(np.random.PCG64(2024))
+    n = rng.normal(size=N)
+    y = gp.dot_tril(n)
+    alpha = gp.apply_inverse(y)
+    nn = float(n @ n)
+    assert abs(float(y @ alpha) - nn) <= 1e-8 * nn
+    ll = gp.log_likelihood(y)
+    ref = -0.5 * (nn + gp._log_det + N * np.log(2.0 * np.pi))
+    assert abs(ll - ref) <= RTOL_LL * abs(ref), (ll, ref)
+    # linearity of the solve at full size
+    a2 = gp.apply_inverse(2.5 * y)
+    assert _relmax(a2, 2.5 * alpha) < 1e-10
 
 
 @pytest.mark.parametrize("case", [TP_CASES[0], TP_CASES[1], TP_CASES[4], TP_CASES[5]],
