@@ -2778,6 +2778,177 @@ __global__ void __launch_bounds__(64) k_gmm(const GmmArgs A) {
     }
 }
 
+// ---- chunk-parallel form (long series): the recurrence F <- p o F + g alpha is linear with a
+// DIAGONAL transition, so chunks of rows are swept concurrently:
+//   k_gmm_chunk<CT, 0>  local pass from F = 0: end state F_loc and the chunk's decay D = prod p
+//   k_gmm_scan          F_start of every chunk (sequential over chunks, 64-wide FMAs)
+//   k_gmm_chunk<CT, 1>  chunks that contain queries are swept again from F_start and emit
+// Row ranges: dir 0 sweeps rows a..b ascending with p_n = P2[n]; dir 1 sweeps b..a descending
+// with p_n = P2[n+1] (1 for the last row of the series).  A query is emitted after row
+// qidx-1 (dir 0) / row qidx (dir 1), as in k_gmm.
+struct GmmChunk {
+    int64_t chunk_len;
+    int nch;
+    double *Floc, *Dloc, *Fstart;   // [B][2][nch][CT*64]
+};
+
+__device__ __forceinline__ int64_t gmm_lower_bound(const int64_t *q, int64_t M, int64_t v) {
+    int64_t lo = 0, hi = M;         // first m with q[m] >= v
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (q[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+template <int CT, int PHASE>
+__global__ void __launch_bounds__(64) k_gmm_chunk(const GmmArgs A, const GmmChunk C) {
+    const int lane = threadIdx.x, b = blockIdx.x, dir = blockIdx.y, ch = blockIdx.z;
+    const int64_t M = A.M, N = A.N;
+    const int ld = A.ld;
+    const int64_t a = (int64_t)ch * C.chunk_len;
+    const int64_t e = (a + C.chunk_len < N) ? (a + C.chunk_len) : N;      // rows [a, e)
+    const double *t1 = A.t1 + (size_t)b * A.t1_bs;
+    const double *t2 = A.t2 + (size_t)b * A.t2_bs;
+    const double *__restrict__ Q1 = (dir == 0 ? A.U1 : A.V1) + (size_t)b * M * ld;
+    const double *__restrict__ G2 = (dir == 0 ? A.V2 : A.U2) + (size_t)b * N * ld;
+    const double *__restrict__ P2 = A.P2 + (size_t)b * N * ld;
+    const double *__restrict__ al = A.alpha + (size_t)b * N;
+    const int64_t *__restrict__ qi = A.qidx + (size_t)b * M;
+    double *out = A.work + ((size_t)b * 2 + dir) * M;
+    const size_t slot = (((size_t)b * 2 + dir) * C.nch + ch) * (CT * 64);
+    bool colok[CT];
+    int col[CT];
+    double F[CT], D[CT], cj[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int j = c * 64 + lane;
+        colok[c] = j < A.W;
+        col[c] = colok[c] ? j : 0;
+        F[c] = (PHASE == 1) ? C.Fstart[slot + c * 64 + lane] : 0.0;
+        D[c] = 1.0;
+        cj[c] = colok[c] ? A.c[(size_t)b * A.W + j] : 0.0;
+    }
+    // queries of this chunk: [m_lo, m_hi)
+    int64_t m_lo = 0, m_hi = 0;
+    if (PHASE == 1) {
+        if (dir == 0) { m_lo = gmm_lower_bound(qi, M, a + 1); m_hi = gmm_lower_bound(qi, M, e + 1); }
+        else          { m_lo = gmm_lower_bound(qi, M, a);     m_hi = gmm_lower_bound(qi, M, e); }
+        // queries before the first / after the last observed row get no contribution
+        if (dir == 0 && ch == 0) for (int64_t m = lane; m < m_lo; m += 64) out[m] = 0.0;
+        if (dir == 1 && ch == C.nch - 1) for (int64_t m = m_hi + lane; m < M; m += 64) out[m] = 0.0;
+        if (m_lo == m_hi) return;
+    }
+    auto emit = [&](int64_t m, double tdata) {
+        const double dt = (dir == 0) ? (tdata - t1[m]) : (t1[m] - tdata);   // <= 0
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+            if (colok[c]) acc = fma(Q1[(size_t)m * ld + col[c]] * exp(cj[c] * dt), F[c], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) out[m] = acc;
+    };
+    constexpr int GB = 8;
+    if (dir == 0) {
+        int64_t m = m_lo;
+        int64_t next = (PHASE == 1) ? qi[m] : (N + 2);                      // emit after row next-1
+        const int64_t last = (PHASE == 1) ? qi[m_hi - 1] : e;               // rows [a, last)
+        for (int64_t n = a; n < last; n += GB) {
+            double pr[GB][CT], gr[GB][CT], an[GB];
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+                const int64_t r = (n + k < last) ? (n + k) : (last - 1);
+                an[k] = al[r];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const size_t o = (size_t)r * ld + col[c];
+                    pr[k][c] = P2[o];
+                    gr[k][c] = G2[o];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+                if (n + k < last) {                                          // wave-uniform
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        F[c] = colok[c] ? fma(pr[k][c], F[c], gr[k][c] * an[k]) : 0.0;
+                        if (PHASE == 0) D[c] *= pr[k][c];
+                    }
+                    if (PHASE == 1) {
+                        while (m < m_hi && next == n + k + 1) {
+                            emit(m, t2[n + k]);
+                            ++m;
+                            next = (m < m_hi) ? qi[m] : (N + 2);
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        int64_t m = m_hi - 1;
+        int64_t next = (PHASE == 1) ? qi[m] : -2;                           // emit after row next
+        const int64_t first = (PHASE == 1) ? qi[m_lo] : a;                  // rows (e-1) .. first
+        for (int64_t n = e - 1; n >= first; n -= GB) {
+            double pr[GB][CT], gr[GB][CT], an[GB];
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+                const int64_t r = (n - k >= first) ? (n - k) : first;
+                an[k] = al[r];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const size_t o = (size_t)r * ld + col[c];
+                    pr[k][c] = (r + 1 < N) ? P2[o + ld] : 1.0;
+                    gr[k][c] = G2[o];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+                if (n - k >= first) {
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        F[c] = colok[c] ? fma(pr[k][c], F[c], gr[k][c] * an[k]) : 0.0;
+                        if (PHASE == 0) D[c] *= pr[k][c];
+                    }
+                    if (PHASE == 1) {
+                        while (m >= m_lo && next == n - k) {
+                            emit(m, t2[n - k]);
+                            --m;
+                            next = (m >= m_lo) ? qi[m] : -2;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (PHASE == 0) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            C.Floc[slot + c * 64 + lane] = F[c];
+            C.Dloc[slot + c * 64 + lane] = colok[c] ? D[c] : 0.0;
+        }
+    }
+}
+
+// F_start of every chunk.  dir 0: F_start[0] = 0, F_start[c+1] = D_c F_start[c] + F_loc[c];
+// dir 1 runs from the last chunk down.
+__global__ void __launch_bounds__(256) k_gmm_scan(const int CTW, const GmmChunk C) {
+    const int b = blockIdx.x, dir = blockIdx.y;
+    const size_t base = ((size_t)b * 2 + dir) * C.nch * CTW;
+    for (int j = threadIdx.x; j < CTW; j += 256) {
+        double F = 0.0;
+        if (dir == 0) {
+            for (int c = 0; c < C.nch; ++c) {
+                const size_t o = base + (size_t)c * CTW + j;
+                C.Fstart[o] = F;
+                F = fma(C.Dloc[o], F, C.Floc[o]);
+            }
+        } else {
+            for (int c = C.nch - 1; c >= 0; --c) {
+                const size_t o = base + (size_t)c * CTW + j;
+                C.Fstart[o] = F;
+                F = fma(C.Dloc[o], F, C.Floc[o]);
+            }
+        }
+    }
+}
+
 // mu[b][m] = work[b][0][m] + work[b][1][m]
 __global__ void k_add2(int64_t M, const double *work, double *mu) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3214,6 +3385,28 @@ int gf_solve(int mode, int B, int64_t N, int W, int ld, int R,
     return check_launch("gf_solve");
 }
 
+// chunking of the conditional-mean sweeps: ~2048 waves over (problem, direction, chunk), chunks of
+// at least 256 rows; one chunk = the sequential k_gmm
+static void gmm_chunking(int B, int64_t N, int *nch, int64_t *chunk_len) {
+    int64_t n = N / 256;
+    const int64_t cap = (1024 / B) > 1 ? (1024 / B) : 1;
+    if (n > cap) n = cap;
+    if (n < 1) n = 1;
+    int64_t len = (N + n - 1) / n;
+    *nch = (int)((N + len - 1) / len);
+    *chunk_len = len;
+}
+
+// doubles of `work` that gf_general_matmul needs
+int64_t gf_general_matmul_work(int B, int64_t M, int64_t N, int W) {
+    int nch;
+    int64_t chunk_len;
+    if (B < 1 || N < 1 || M < 1 || W < 1) return 0;
+    gmm_chunking(B, N, &nch, &chunk_len);
+    const int CT = (W <= 64) ? 1 : (W <= 128) ? 2 : 4;
+    return (int64_t)B * 2 * M + (nch > 1 ? 3 * (int64_t)B * 2 * nch * CT * 64 : 0);
+}
+
 int gf_general_matmul(int B, int64_t M, int64_t N, int W, int ld,
                       const double *c,
                       const double *t1, int64_t t1_bs, const double *U1, const double *V1,
@@ -3231,7 +3424,27 @@ int gf_general_matmul(int B, int64_t M, int64_t N, int W, int ld,
     A.t2 = t2; A.t2_bs = t2_bs; A.U2 = U2; A.V2 = V2; A.P2 = P2; A.alpha = alpha;
     A.qidx = qidx; A.work = work;
     hipStream_t st = (hipStream_t)stream;
-    if (W <= 64)       hipLaunchKernelGGL(k_gmm<1>, dim3(B, 2), dim3(64), 0, st, A);
+    const int CT = (W <= 64) ? 1 : (W <= 128) ? 2 : 4;
+    int nch;
+    int64_t chunk_len;
+    gmm_chunking(B, N, &nch, &chunk_len);
+    if (nch > 1) {                      // long series: chunk-parallel (decayed prefix sums)
+        GmmChunk C;
+        C.chunk_len = chunk_len; C.nch = nch;
+        const size_t per = (size_t)B * 2 * nch * CT * 64;
+        C.Floc = work + (size_t)B * 2 * M;
+        C.Dloc = C.Floc + per;
+        C.Fstart = C.Dloc + per;
+        const dim3 grid(B, 2, nch);
+        if (CT == 1)      hipLaunchKernelGGL((k_gmm_chunk<1, 0>), grid, dim3(64), 0, st, A, C);
+        else if (CT == 2) hipLaunchKernelGGL((k_gmm_chunk<2, 0>), grid, dim3(64), 0, st, A, C);
+        else              hipLaunchKernelGGL((k_gmm_chunk<4, 0>), grid, dim3(64), 0, st, A, C);
+        hipLaunchKernelGGL(k_gmm_scan, dim3(B, 2), dim3(256), 0, st, CT * 64, C);
+        if (CT == 1)      hipLaunchKernelGGL((k_gmm_chunk<1, 1>), grid, dim3(64), 0, st, A, C);
+        else if (CT == 2) hipLaunchKernelGGL((k_gmm_chunk<2, 1>), grid, dim3(64), 0, st, A, C);
+        else              hipLaunchKernelGGL((k_gmm_chunk<4, 1>), grid, dim3(64), 0, st, A, C);
+    }
+    else if (W <= 64)  hipLaunchKernelGGL(k_gmm<1>, dim3(B, 2), dim3(64), 0, st, A);
     else if (W <= 128) hipLaunchKernelGGL(k_gmm<2>, dim3(B, 2), dim3(64), 0, st, A);
     else               hipLaunchKernelGGL(k_gmm<4>, dim3(B, 2), dim3(64), 0, st, A);
     hipLaunchKernelGGL(k_add2, dim3((unsigned)((M + 255) / 256), B), dim3(256), 0, st, M, work, mu);

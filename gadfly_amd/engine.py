@@ -259,7 +259,7 @@ class DeviceBatch:
         B, N = self.B, self.N
         M = int(ts.shape[1])
         f64 = dict(dtype=torch.float64, device=self.device)
-        work = torch.empty((B * 2 * M,), **f64)
+        work = torch.empty((int(self.lib.gf_general_matmul_work(B, M, N, src.W)),), **f64)
         mu = torch.empty((B, M), **f64)
         # number of observed rows at or before each query time (device searchsorted)
         qidx = torch.searchsorted(self.t.expand(B, N).contiguous(),

@@ -270,8 +270,11 @@ int gf_solve(int mode, int B, int64_t N, int W, int ld, int R,
  *         + sum_{t2[n] >  t1[m]} (V1[m] o e^{-c (t2[n]-t1[m])}) . U2[n] alpha[n]
  *   c [B][W]; U1, V1 [B][M][ld]; U2, V2, P2 [B][N][ld]; t1 [B|1][M]; t2 [B|1][N]
  *   qidx [B][M] (int64): number of observed rows with t2 <= t1[m] (searchsorted, side "right");
- *   work: B * 2 * M doubles.
+ *   work: gf_general_matmul_work(B, M, N, W) doubles.
+ * Long series are swept chunk-parallel (the recurrence is a decayed prefix sum: local pass,
+ * scan of the chunk states, second pass over the chunks that contain queries).
  */
+int64_t gf_general_matmul_work(int B, int64_t M, int64_t N, int W);
 int gf_general_matmul(int B, int64_t M, int64_t N, int W, int ld,
                       const double *c,
                       const double *t1, int64_t t1_bs, const double *U1, const double *V1,
