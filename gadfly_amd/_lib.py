@@ -63,6 +63,7 @@ SIGNATURES = {
     "gf_reduce_tile": (_int, [_int, _i64] + [_vp] * 4 + [_int, _vp]),
     "gf_loglike_finish": (_int, [_int, _i64] + [_vp] * 4 + [_vp]),
     "gf_solve": (_int, [_int, _int, _i64, _int, _int, _int] + [_vp] * 6 + [_vp]),
+    "gf_cross_covariance": (_int, [_int, _i64, _int, _int, _int] + [_vp] * 6 + [_vp, _i64, _vp, _i64, _vp, _vp]),
     "gf_general_matmul_work": (_i64, [_int, _i64, _i64, _int]),
     "gf_general_matmul": (_int, [_int, _i64, _i64, _int, _int, _vp,
                                  _vp, _i64, _vp, _vp,

@@ -2949,6 +2949,51 @@ __global__ void __launch_bounds__(256) k_gmm_scan(const int CTW, const GmmChunk 
     }
 }
 
+// ------------------------------------------------------------------------------------
+// k_cross: cross-covariance block K(t_n, t*_r) of the celerite kernel, written in the
+// [B][N][R] layout the multi-RHS sweeps take (conditional variance / covariance:
+// celerite2's ConditionalDistribution builds the same dense block on the host).
+//   K = sum_r a_r e^{-c_r tau} + sum_c (a_c cos d_c tau + b_c sin d_c tau) e^{-c_c tau},
+//   tau = |t_n - t*_r|.  One thread per (n, r); coefficients staged in LDS.
+// The exposure-integrated kernel differs from its coefficient form for tau < delta; the caller
+// patches those (at most a few per query) entries.
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_cross(const int64_t N, const int R, const int Jr, const int Jc,
+        const double *__restrict__ ar_, const double *__restrict__ cr_,
+        const double *__restrict__ ac_, const double *__restrict__ bc_,
+        const double *__restrict__ cc_, const double *__restrict__ dc_,
+        const double *__restrict__ t_, const int64_t t_bs,
+        const double *__restrict__ ts_, const int64_t ts_bs, double *__restrict__ out) {
+    extern __shared__ double lds[];             // [2 Jr + 4 Jc] coefficients, then [R] query times
+    const int b = blockIdx.y;
+    double *co = lds, *tq = lds + 2 * Jr + 4 * Jc;
+    for (int i = threadIdx.x; i < Jr; i += 256) { co[2 * i] = ar_[(size_t)b * Jr + i]; co[2 * i + 1] = cr_[(size_t)b * Jr + i]; }
+    for (int i = threadIdx.x; i < Jc; i += 256) {
+        double *p = co + 2 * Jr + 4 * i;
+        p[0] = ac_[(size_t)b * Jc + i]; p[1] = bc_[(size_t)b * Jc + i];
+        p[2] = cc_[(size_t)b * Jc + i]; p[3] = dc_[(size_t)b * Jc + i];
+    }
+    for (int i = threadIdx.x; i < R; i += 256) tq[i] = ts_[(size_t)b * ts_bs + i];
+    __syncthreads();
+    const int64_t total = N * R;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t n = e / R;
+        const int r = (int)(e - n * R);
+        const double tau = fabs(t_[(size_t)b * t_bs + n] - tq[r]);
+        double k = 0.0;
+        for (int i = 0; i < Jr; ++i) k = fma(co[2 * i], fm_exp(-co[2 * i + 1] * tau), k);
+        for (int i = 0; i < Jc; ++i) {
+            const double *p = co + 2 * Jr + 4 * i;
+            double si, cs;
+            const double x = p[3] * tau;
+            if (fabs(x) < 1.6e6) fm_sincos(x, &si, &cs); else sincos(x, &si, &cs);
+            k = fma(fma(p[0], cs, p[1] * si), fm_exp(-p[2] * tau), k);
+        }
+        out[(size_t)b * total + e] = k;
+    }
+}
+
 // mu[b][m] = work[b][0][m] + work[b][1][m]
 __global__ void k_add2(int64_t M, const double *work, double *mu) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3383,6 +3428,24 @@ int gf_solve(int mode, int B, int64_t N, int W, int ld, int R,
         else                hipLaunchKernelGGL((k_solve_rhs<64, 4>), grid, dim3(256), 0, st, A);
     }
     return check_launch("gf_solve");
+}
+
+// K(t_n, t*_r) for n < N, r < R into out [B][N][R] (row-major; R <= 4096 query times per call).
+int gf_cross_covariance(int B, int64_t N, int R, int Jr, int Jc,
+                        const double *ar, const double *cr, const double *ac,
+                        const double *bc, const double *cc, const double *dc,
+                        const double *t, int64_t t_bs, const double *ts, int64_t ts_bs,
+                        double *out, void *stream) {
+    if (B < 1 || N < 1 || R < 1 || R > 4096) return set_err("gf_cross_covariance: bad shape (N=%s%lld, R=%lld)", "", N, R);
+    if (Jr < 0 || Jc < 0 || Jr + Jc < 1 || Jr + 2 * Jc > GF_MAX_WIDTH) return set_err("gf_cross_covariance: bad term counts%s", "");
+    if (!t || !ts || !out || (Jr && (!ar || !cr)) || (Jc && (!ac || !bc || !cc || !dc)))
+        return set_err("gf_cross_covariance: null pointer%s", "");
+    const size_t lds = sizeof(double) * (size_t)(2 * Jr + 4 * Jc + R);
+    int64_t blocks = (N * R + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_cross, dim3((unsigned)blocks, B), dim3(256), lds, (hipStream_t)stream, N, R, Jr, Jc,
+                       ar, cr, ac, bc, cc, dc, t, t_bs, ts, ts_bs, out);
+    return check_launch("gf_cross_covariance");
 }
 
 // chunking of the conditional-mean sweeps: ~2048 waves over (problem, direction, chunk), chunks of

@@ -36,9 +36,10 @@ class _ConstantMean:
 
 class ConditionalDistribution:
     """Conditional (predictive) distribution (celerite2 ``ConditionalDistribution``;
-    built at /root/reference/gadfly/gp.py:232).  ``mean`` runs on the device; ``variance`` /
-    ``covariance`` use the dense K(t, t*) construction celerite2 uses (O(N M W), small M --
-    the scalable version is SURVEY.md 8f rank 1) with the solves on the device."""
+    built at /root/reference/gadfly/gp.py:232).  Everything runs on the device: ``mean`` through the
+    chunk-parallel conditional-mean sweeps, ``variance`` / ``covariance`` through the K(t, t*)
+    construction celerite2 uses, built by ``gf_cross_covariance`` in blocks of 64 query times and
+    solved with the chunk-parallel multi-right-hand-side sweeps."""
 
     def __init__(self, gp, y, t=None, *, include_mean=True, kernel=None):
         self.gp = gp
@@ -83,23 +84,73 @@ class ConditionalDistribution:
             mu = mu + gp._mean(xs)
         return mu
 
-    def _dense_cross(self):
+    #: query times per cross-covariance block (= right-hand sides per chunk-parallel sweep)
+    _RB = 64
+
+    def _cross_blocks(self):
+        """K(t, t*) and K^-1 K(t, t*) on the device, in blocks of ``_RB`` query columns.
+
+        celerite2 builds the dense N x M block with numpy on the host (O(N M J) transcendentals and
+        an N x M x J temporary); here ``gf_cross_covariance`` writes it straight into the layout the
+        multi-right-hand-side sweeps take.  The few entries closer than the exposure time (where
+        an exposure-integrated kernel departs from its celerite coefficients) are patched from
+        :meth:`Term.get_value`.  Yields (column slice, K block (N, R), K^-1 K block (N, R)).
+        """
+        from . import _lib
         gp = self.gp
         kernel = gp.kernel if self.kernel is None else self.kernel
         xs = gp._t if self.t is None else self.t
-        KxsT = kernel.get_value(xs[None, :] - gp._t[:, None])          # (N, M)
-        sol = gp._engine.apply_inverse(gp._to_device(KxsT)[None, :, :])
-        return kernel, xs, KxsT, sol[0].cpu().numpy()
+        torch = gp._engine.torch
+        lib, p = _lib.load(), _lib.ptr
+        dev = gp._engine.device
+        co = kernel.get_device_coefficients()
+        cod = [torch.as_tensor(np.ascontiguousarray(v, dtype=np.float64), device=dev) for v in co[:6]]
+        Jr, Jc = len(co[0]), len(co[2])
+        t_d = gp._to_device(gp._t)
+        N = gp._size
+        delta = float(getattr(kernel, "delta", 0.0) or 0.0)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        for j0 in range(0, len(xs), self._RB):
+            xb = np.ascontiguousarray(xs[j0:j0 + self._RB])
+            R = len(xb)
+            xb_d = torch.as_tensor(xb, device=dev)
+            K = torch.empty((1, N, R), dtype=torch.float64, device=dev)
+            rc = lib.gf_cross_covariance(1, N, R, Jr, Jc, *[p(v) if v.numel() else None for v in cod],
+                                         p(t_d), 0, p(xb_d), 0, p(K), st)
+            _lib.check(rc, "gf_cross_covariance")
+            if delta > 0.0:
+                lo = np.searchsorted(gp._t, xb - delta, side="right")
+                hi = np.searchsorted(gp._t, xb + delta, side="left")
+                rows = np.concatenate([np.arange(a, b) for a, b in zip(lo, hi)]) if np.any(hi > lo) else np.empty(0, int)
+                if rows.size:
+                    cols = np.concatenate([np.full(b - a, r) for r, (a, b) in enumerate(zip(lo, hi))])
+                    vals = kernel.get_value(gp._t[rows] - xb[cols])
+                    K[0, torch.as_tensor(rows, device=dev), torch.as_tensor(cols, device=dev)] = \
+                        torch.as_tensor(vals, device=dev)
+            sol = gp._engine.apply_inverse(K)
+            yield slice(j0, j0 + R), K[0], sol[0]
 
     @property
     def variance(self):
-        kernel, xs, KxsT, KinvK = self._dense_cross()
-        return kernel.get_value(np.zeros(1))[0] - np.sum(KxsT * KinvK, axis=0)
+        gp = self.gp
+        kernel = gp.kernel if self.kernel is None else self.kernel
+        xs = gp._t if self.t is None else self.t
+        out = np.empty(len(xs))
+        k0 = kernel.get_value(np.zeros(1))[0]
+        for sl, K, sol in self._cross_blocks():
+            out[sl] = k0 - (K * sol).sum(dim=0).cpu().numpy()
+        return out
 
     @property
     def covariance(self):
-        kernel, xs, KxsT, KinvK = self._dense_cross()
-        return kernel.get_value(xs[:, None] - xs[None, :]) - KxsT.T @ KinvK
+        gp = self.gp
+        kernel = gp.kernel if self.kernel is None else self.kernel
+        xs = gp._t if self.t is None else self.t
+        blocks = list(self._cross_blocks())
+        torch = gp._engine.torch
+        Kall = torch.cat([b[1] for b in blocks], dim=1)             # (N, M)
+        Sall = torch.cat([b[2] for b in blocks], dim=1)
+        return kernel.get_value(xs[:, None] - xs[None, :]) - (Kall.T @ Sall).cpu().numpy()
 
     def sample(self, *, size=None, regularize=None):
         mu = self.mean

@@ -264,6 +264,20 @@ int gf_solve(int mode, int B, int64_t N, int W, int ld, int R,
              const double *Y, double *Z, void *stream);
 
 /*
+ * Cross-covariance block for the conditional variance / covariance (celerite2's
+ * ConditionalDistribution.variance builds it densely on the host; gp.py:295-304 is gadfly's use):
+ *   out[b][n][r] = k(|t[n] - ts[r]|) from the celerite coefficients, layout [B][N][R] = the
+ * right-hand-side layout of gf_solve / gf_chunk_linear, so K^-1 K(t, t*) follows without a copy.
+ * t [B|1][N] (stride t_bs), ts [B|1][R] (stride ts_bs), R <= 4096.  For an exposure-integrated kernel
+ * the coefficient form holds for lags >= delta only: the caller patches the few closer entries.
+ */
+int gf_cross_covariance(int B, int64_t N, int R, int Jr, int Jc,
+                        const double *ar, const double *cr, const double *ac,
+                        const double *bc, const double *cc, const double *dc,
+                        const double *t, int64_t t_bs, const double *ts, int64_t ts_bs,
+                        double *out, void *stream);
+
+/*
  * Conditional mean at M new (sorted) times t1 given alpha = K^-1 (y - mean) at the N
  * observed times t2:
  *   mu[m] = sum_{t2[n] <= t1[m]} (U1[m] o e^{-c (t1[m]-t2[n])}) . V2[n] alpha[n]

@@ -143,8 +143,10 @@ def test_gaussian_process_api(hip, case):
     mu = gp.predict(y)
     alpha = dense.apply_inverse(co[:6], t, diag, y - mean)
     assert _relmax(mu, y - prob["diag_user"] * alpha) < TOL_VEC
-    # predict at new times with variance (dense small-M path, celerite2 semantics)
-    ts = np.sort(rng.uniform(t[0], t[-1], 40))
+    # predict at new times with variance (celerite2 semantics; K(t, t*) built on the device in
+    # blocks of 64 query times: 100 queries = two blocks, some of them closer than the exposure
+    # time to an observed point)
+    ts = np.sort(np.concatenate([rng.uniform(t[0], t[-1], 97), t[10:13] + 0.3 * getattr(k, "delta", 0.0)]))
     mu_s, var_s = gp.predict(y, t=ts, return_var=True)
     Ks = k.get_value(ts[:, None] - t[None, :])
     K = dense.dense_K(co[:6], t, diag)
@@ -156,6 +158,10 @@ def test_gaussian_process_api(hip, case):
     co_k = dense.kernel_value(co[:6], ts[:, None] - t[None, :])
     assert _relmax(mu_s, co_k @ np.linalg.solve(K, y - mean) + mean) < TOL_VEC
     assert _relmax(var_s, var_ref) < 1e-5
+    cov = gp.condition(y, ts).covariance
+    cov_ref = k.get_value(ts[:, None] - ts[None, :]) - Ks @ np.linalg.solve(K, Ks.T)
+    assert _relmax(cov, cov_ref) < 1e-5
+    assert _relmax(np.diag(cov), var_s) < 1e-9
     # sample(): gadfly's quirk -- across-realisation mean removed (gp.py:392)
     np.random.seed(42)
     s = gp.sample(size=3)
