@@ -2386,43 +2386,54 @@ __global__ void __launch_bounds__(64) k_linR(const LinArgs A) {
 //   upper  : G_{c-1} = Gbar_c + Phi_c^T G_c          (descending)
 //   matmul : F_{c+1} = Fbar_c + D_c o F_c            (D = product of the chunk's reset decays)
 // One workgroup of 64 x RT threads per (problem, RHS tile); Phi is stored [j][i].
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 k_lincombine(const int nch, const int W, const int mode, const int R,
              const double *__restrict__ Phi_, const double *__restrict__ Dch_,
              double *__restrict__ F_state) {
-    const int pr = blockIdx.x;
-    const int i = threadIdx.x & 63;                 // state row
-    const int rsub = threadIdx.x >> 6;              // 4 RHS columns in flight per pass
+    // one wave per (problem, right-hand side): the scan is sequential over the chunks only.
+    // Lane i owns state row i; the 64 x 64 transition of the chunk sits in registers (row i of
+    // Phi, or of Phi^T for the backward solve), the state is broadcast through LDS.
+    const int pr = blockIdx.x, r = blockIdx.y, i = threadIdx.x;
     const bool up = mode == GF_SOLVE_UPPER, mm = mode == GF_MATMUL_LOWER;
-    extern __shared__ __attribute__((aligned(16))) double lds[];    // cur[64][R]
-    double *cur = lds;
-    for (int e = threadIdx.x; e < 64 * R; e += 256) cur[e] = 0.0;
-    __syncthreads();
+    __shared__ __attribute__((aligned(16))) double s_c[64];
+    double cur = 0.0;
+    double P[64];
+    auto load_phi = [&](int c) {
+        const double *Pg = Phi_ + ((size_t)pr * nch + c) * 4096;
+        if (!up) {
+#pragma unroll
+            for (int j = 0; j < 64; ++j) P[j] = Pg[(size_t)j * 64 + i];     // Phi(i, j), coalesced
+        } else {
+            const double2 *row = reinterpret_cast<const double2 *>(Pg + (size_t)i * 64);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) { const double2 v = row[j]; P[2 * j] = v.x; P[2 * j + 1] = v.y; }  // Phi(j, i)
+        }
+    };
+    if (!mm) load_phi(up ? nch - 1 : 0);
     for (int s = 0; s < nch; ++s) {
         const int c = up ? (nch - 1 - s) : s;
         const size_t slot = (size_t)pr * nch + c;
-        double *Fg = F_state + slot * 64 * R;
-        const double *Pg = Phi_ ? Phi_ + slot * 4096 : nullptr;
-        for (int r0 = 0; r0 < R; r0 += 4) {
-            const int r = r0 + rsub;
-            double nxt = 0.0;
-            if (r < R) {
-                nxt = Fg[(size_t)i * R + r];                        // local end state of chunk c
-                if (mm) {
-                    nxt = fma(Dch_[slot * 64 + i], cur[i * R + r], nxt);
-                } else if (!up) {
-#pragma unroll 8
-                    for (int j = 0; j < 64; ++j) nxt = fma(Pg[(size_t)j * 64 + i], cur[j * R + r], nxt);
-                } else {
-#pragma unroll 8
-                    for (int j = 0; j < 64; ++j) nxt = fma(Pg[(size_t)i * 64 + j], cur[j * R + r], nxt);
-                }
-                Fg[(size_t)i * R + r] = cur[i * R + r];             // publish the true start state
+        double *Fg = F_state + slot * 64 * R + (size_t)i * R + r;
+        double nxt = *Fg;                                   // local end state of chunk c
+        *Fg = cur;                                          // publish the true start state
+        if (mm) {
+            nxt = fma(Dch_[slot * 64 + i], cur, nxt);
+        } else {
+            wave_lds_fence();
+            s_c[i] = cur;
+            wave_lds_fence();
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+            for (int j = 0; j < 64; j += 4) {
+                a0 = fma(P[j], s_c[j], a0);
+                a1 = fma(P[j + 1], s_c[j + 1], a1);
+                a2 = fma(P[j + 2], s_c[j + 2], a2);
+                a3 = fma(P[j + 3], s_c[j + 3], a3);
             }
-            __syncthreads();
-            if (r < R) cur[i * R + r] = nxt;
-            __syncthreads();
+            nxt += (a0 + a1) + (a2 + a3);
+            if (s + 1 < nch) load_phi(up ? c - 1 : c + 1);  // in flight during the next step's head
         }
+        cur = nxt;
     }
 }
 
@@ -3373,9 +3384,7 @@ int gf_chunk_linear_combine(int mode, int B, int64_t N, int64_t chunk_len, int n
     hipStream_t st = (hipStream_t)stream;
     if (mode == GF_MATMUL_LOWER)
         hipLaunchKernelGGL(k_chunk_decay, dim3(B * nch), dim3(64), 0, st, N, chunk_len, nch, W, c, de, D_work);
-    const size_t lds = sizeof(double) * 64 * (size_t)R;
-    if (lds > 64 * 1024) return set_err("gf_chunk_linear_combine: R=%s%lld too large (max 128)", "", R);
-    hipLaunchKernelGGL(k_lincombine, dim3(B), dim3(256), lds, st, nch, W, mode, R, Phi, D_work, F_state);
+    hipLaunchKernelGGL(k_lincombine, dim3(B, R), dim3(64), 0, st, nch, W, mode, R, Phi, D_work, F_state);
     return check_launch("gf_chunk_linear_combine");
 }
 
