@@ -513,7 +513,7 @@ __global__ void __launch_bounds__(256) k_build2(const Build2Args A) {
 // LDS (xa[i], xw[i]), software-pipelined: batches of 4 rows (2 + 2 ds_read_b128), SW_AHEAD
 // batches in flight ahead of the FMAs, so the LDS latency is paid once per sweep and not once
 // per read (hipcc otherwise parks every read right in front of its use).
-constexpr int SW_BR = 4, SW_AHEAD = 2;
+constexpr int SW_BR = 4, SW_AHEAD = 1;
 #ifndef GF_CHAIN_PRIO
 #define GF_CHAIN_PRIO 1
 #endif
