@@ -52,7 +52,8 @@ class DeviceBatch:
         torch = _lib.require_device()
         self.torch = torch
         self.lib = _lib.load()
-        self.device = torch.device(device if device is not None else "cuda:0")
+        self.device = torch.device(device if device is not None
+                                   else f"cuda:{torch.cuda.current_device()}")   # the rank's own GPU
         self.B = len(coeffs_list)
         self.Jr, self.Jc, real, comp, diag_add, c = _coeff_pack(coeffs_list)
         self.W = self.Jr + 2 * self.Jc
@@ -387,7 +388,8 @@ class StreamingBatch:
         torch = _lib.require_device()
         self.torch = torch
         self.lib = _lib.load()
-        self.device = torch.device(device if device is not None else "cuda:0")
+        self.device = torch.device(device if device is not None
+                                   else f"cuda:{torch.cuda.current_device()}")   # the rank's own GPU
         self.B = len(coeffs_list)
         self.Jr, self.Jc, real, comp, diag_add, c = _coeff_pack(coeffs_list)
         self.W = self.Jr + 2 * self.Jc

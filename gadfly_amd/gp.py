@@ -383,7 +383,8 @@ class GaussianProcess:
 
     def _device_of(self):
         import torch
-        return torch.device(self._device if self._device is not None else "cuda:0")
+        return torch.device(self._device if self._device is not None
+                            else f"cuda:{torch.cuda.current_device()}")
 
     # ---- public numerical API (reference gp.py:308-395) ------------------------
     def dot_tril(self, y, *, inplace=False):
