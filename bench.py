@@ -78,7 +78,9 @@ def main():
     dist = None
     # "nccl" is RCCL on ROCm; GADFLY_BENCH_BACKEND=gloo is for rehearsals on a single GPU
     backend = os.environ.get("GADFLY_BENCH_BACKEND", "nccl")
-    if world > 1:
+    # GADFLY_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, barriers, MAX-reduce of
+    # the time) even at world size 1 -- how the N > 1 path is smoke-tested on a one-GPU box
+    if world > 1 or os.environ.get("GADFLY_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -115,6 +117,7 @@ def main():
     elif args.kernel == "blocked" and not eng._blocked_ok():
         raise SystemExit("--kernel blocked: not supported for this term structure / cadence")
     eng.time_factor = True
+    eng.force_streaming = True      # the metric is the streamed sweep of independent evaluations
     torch.cuda.synchronize()
 
     outs = []

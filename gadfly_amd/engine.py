@@ -796,8 +796,9 @@ class StreamingBatch:
         few long series (B * N large per problem, B small) unless told otherwise."""
         if time_parallel is None:
             # chunking costs ~3.5x the flops: it pays while the batch alone fills less than
-            # ~1/8 of the 2048 wave slots
-            time_parallel = self._fused_ok() and self.B <= 256 and self.N >= 8192
+            # ~1/8 of the 2048 wave slots (``force_streaming``: benchmarks of the streamed sweep)
+            time_parallel = (self._fused_ok() and self.B <= 256 and self.N >= 8192
+                             and not getattr(self, "force_streaming", False))
         if time_parallel and self._fused_ok():
             out = self.log_likelihood_time_parallel()
             acc = self._tp["acc"] if getattr(self, "_tp_key", None) and self._tp_used else self.acc
