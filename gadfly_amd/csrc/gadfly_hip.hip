@@ -729,6 +729,9 @@ k_factor2(const int64_t N, const int64_t n_first, const int ld, const int W,
 // slot b, so the same kernel serves the nominal pass (zero start state, r~ rows stored for
 // k_phi) and the final pass (true start states from k_combine).
 // ------------------------------------------------------------------------------------
+#ifndef GF_SUBANCHOR
+#define GF_SUBANCHOR 16
+#endif
 struct RowGen {
     // per-lane column constants: u~ = (k1 cu + k2 su), v~ = own / rho^2 with (cu, su) =
     // rho (cos, sin)(d t); lanes 2k, 2k+1 carry the same (cu, su)
@@ -736,7 +739,7 @@ struct RowGen {
     bool is_sin, colok;
     int block;
     // running state: rho-scaled phasor, 1 / rho^2, cached one-cadence multipliers
-    double cu, su, irho2, Er, Ei, G2, dt_ref, tref, t_m1;
+    double cu, su, irho2, Er, Ei, G2, dt_ref, dt_last, tref, t_m1;
 
     __device__ __forceinline__ void init(int lane, int b, int Jr, int Jc, int block_, double gap_,
                                          const double *ar_, const double *cr_, const double *ac_,
@@ -762,7 +765,7 @@ struct RowGen {
         wmax = read_lane(wave_max(fmax(cj, fabs(dj))), 0);      // uniform: lives in SGPRs
         block = block_;
         gap = gap_;
-        cu = 1.0; su = 0.0; irho2 = 1.0; Er = 1.0; Ei = 0.0; G2 = 1.0; dt_ref = -1.0;
+        cu = 1.0; su = 0.0; irho2 = 1.0; Er = 1.0; Ei = 0.0; G2 = 1.0; dt_ref = -1.0; dt_last = -2.0;
         // reference time of the block that precedes the first row (for its decay); tg points
         // at the first row, earlier rows are at negative indices
         tref = tg[0];
@@ -780,15 +783,30 @@ struct RowGen {
     // advances by the cached one-cadence multiplier exp((-c + i d) dt_ref), corrected to second
     // order for the deviation of this row's spacing from dt_ref (rounding-level jitter of a
     // regular cadence: |(c, d) ddt| < 2e-6 => truncation < 2e-18 per row); any other spacing
-    // refreshes the cache (sincos + exp, as an anchor costs).  Per-row rounding accumulates over
-    // at most 63 rows (~1e-14); scratch/proto_rot.py: log-likelihood to 1e-14, d_n to 4e-11.
+    // recomputes the phasor exactly (and re-caches the multiplier once the new spacing repeats).
+    // Per-row rounding accumulates over at most GF_SUBANCHOR - 1 rows (sub-anchors).
     // The pieces of next(): kind of the row at time tn (0 = plain rotation step, 1 = the cached
     // multipliers must be refreshed first, 2 = reset row / anchor); wave-uniform.
     __device__ __forceinline__ int peek(const double tn, const int64_t g, double &dt, double &ddt) const {
         dt = tn - t_m1;
         ddt = dt - dt_ref;
         if (((g & (block - 1)) == 0) || (cmax * dt > gap)) return 2;
+        if ((g & (GF_SUBANCHOR - 1)) == 0) return 3;            // exact phasor again, same scaling
         return (fabs(ddt) * wmax < 2e-6) ? 0 : 1;
+    }
+    // Sub-anchor: every GF_SUBANCHOR rows inside a scaling block the phasor is recomputed exactly
+    // (theta = d t_n as one rounded multiply, rho = exp(-c (t_n - t_ref))), so the rotation's
+    // rounding accumulates over at most GF_SUBANCHOR - 1 steps.  Without it (63 steps) the
+    // log-likelihood of ill-conditioned problems (pivot/diagonal ~ 1e-6) was off by 1e-8, 20 x the
+    // error of exact generation (tests/test_gpu_random.py, seed 126).
+    __device__ __forceinline__ void subanchor(const double tn) {
+        t_m1 = tn;
+        double si, co;
+        fm_sincos(dj * tn, &si, &co);
+        const double rho = fm_exp(-cj * (tn - tref));
+        cu = rho * co;
+        su = rho * si;
+        irho2 = fast_rcp(rho * rho);
     }
     __device__ __forceinline__ void anchor(const double tn, const int64_t g, double &de) {
         de = (g > 0) ? (tn - tref) : 0.0;
@@ -829,8 +847,18 @@ struct RowGen {
         rst = kind == 2;
         if (kind == 2) {                            // wave-uniform
             anchor(tn, g, de);
+        } else if (kind == 3) {                     // wave-uniform
+            subanchor(tn);
+            de = -1.0;
+        } else if (kind == 1) {                     // wave-uniform: spacing differs from the cached one
+            // exact phasor (an irregular cadence thus never accumulates rotation steps: same cost
+            // as refreshing the multiplier, exact accuracy); the cached multipliers move to the
+            // new spacing only once it repeats (a lasting change of cadence, not a single odd row)
+            subanchor(tn);
+            if (fabs(dt - dt_last) * wmax < 2e-6) refresh(dt);
+            dt_last = read_lane(dt, 0);
+            de = -1.0;
         } else {
-            if (kind == 1) { refresh(dt); ddt = 0.0; }      // wave-uniform: new cadence
             step(tn, ddt);
             de = -1.0;
         }
@@ -1303,7 +1331,8 @@ k_factor5(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
                 // kind of row n+1 (RowGen::peek; g0 is a multiple of block, so the block phase is n's)
                 const double t_next = read_lane(s_in[0][(n + 1) & 63], 0);
                 const double dt = t_next - tm1, ddt = dt - dtr;
-                if ((((n + 1) & bmask) == 0) || (cmx * dt > gp) || !(fabs(ddt) * wmx < 2e-6)) break;
+                if ((((n + 1) & bmask) == 0) || (((n + 1) & (GF_SUBANCHOR - 1)) == 0) || (cmx * dt > gp)
+                    || !(fabs(ddt) * wmx < 2e-6)) break;
                 tm1 = t_next;
                 G.unpark(s_gen, lane);
                 G.step(t_next, ddt);
