@@ -45,6 +45,7 @@ SIGNATURES = {
                          + [_vp] * 5 + [_vp]),
     "gf_loglike_fused": (_int, [_int, _i64, _i64, _int, _int, _int] + [_vp] * 8
                          + [_vp, _i64, _vp, _i64, _vp, _i64] + [_vp] * 5 + [_vp]),
+    "gf_set_generator_period": (_int, [_int]),
     "gf_set_pipelined": (_int, [_int]),
     "gf_blocked_supported": (_int, [_int, _int, _int]),
     "gf_loglike_blocked": (_int, [_int, _i64, _i64, _int, _int, _int] + [_vp] * 8

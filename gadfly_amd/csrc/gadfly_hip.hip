@@ -729,19 +729,16 @@ k_factor2(const int64_t N, const int64_t n_first, const int ld, const int W,
 // slot b, so the same kernel serves the nominal pass (zero start state, r~ rows stored for
 // k_phi) and the final pass (true start states from k_combine).
 // ------------------------------------------------------------------------------------
-#ifndef GF_SUBANCHOR
-#define GF_SUBANCHOR 16
-#endif
 struct RowGen {
     // per-lane column constants: u~ = (k1 cu + k2 su), v~ = own / rho^2 with (cu, su) =
     // rho (cos, sin)(d t); lanes 2k, 2k+1 carry the same (cu, su)
     double cj, dj, k1, k2, cmax, wmax, gap;
     bool is_sin, colok;
-    int block;
+    int block, sub_mask;            // scaling block length; sub-anchor period - 1
     // running state: rho-scaled phasor, 1 / rho^2, cached one-cadence multipliers
     double cu, su, irho2, Er, Ei, G2, dt_ref, dt_last, tref, t_m1;
 
-    __device__ __forceinline__ void init(int lane, int b, int Jr, int Jc, int block_, double gap_,
+    __device__ __forceinline__ void init(int lane, int b, int Jr, int Jc, int block_sub, double gap_,
                                          const double *ar_, const double *cr_, const double *ac_,
                                          const double *bc_, const double *cc_, const double *dc_,
                                          const double *cmax_, const double *tg, int64_t n_first) {
@@ -763,7 +760,8 @@ struct RowGen {
         }
         cmax = cmax_[b];
         wmax = read_lane(wave_max(fmax(cj, fabs(dj))), 0);      // uniform: lives in SGPRs
-        block = block_;
+        block = block_sub & 0xff;           // (block <= 64) | (sub-anchor period << 8)
+        sub_mask = (block_sub >> 8) - 1;
         gap = gap_;
         cu = 1.0; su = 0.0; irho2 = 1.0; Er = 1.0; Ei = 0.0; G2 = 1.0; dt_ref = -1.0; dt_last = -2.0;
         // reference time of the block that precedes the first row (for its decay); tg points
@@ -784,21 +782,22 @@ struct RowGen {
     // order for the deviation of this row's spacing from dt_ref (rounding-level jitter of a
     // regular cadence: |(c, d) ddt| < 2e-6 => truncation < 2e-18 per row); any other spacing
     // recomputes the phasor exactly (and re-caches the multiplier once the new spacing repeats).
-    // Per-row rounding accumulates over at most GF_SUBANCHOR - 1 rows (sub-anchors).
+    // Per-row rounding accumulates over at most period - 1 rows (sub-anchors).
     // The pieces of next(): kind of the row at time tn (0 = plain rotation step, 1 = the cached
     // multipliers must be refreshed first, 2 = reset row / anchor); wave-uniform.
     __device__ __forceinline__ int peek(const double tn, const int64_t g, double &dt, double &ddt) const {
         dt = tn - t_m1;
         ddt = dt - dt_ref;
         if (((g & (block - 1)) == 0) || (cmax * dt > gap)) return 2;
-        if ((g & (GF_SUBANCHOR - 1)) == 0) return 3;            // exact phasor again, same scaling
+        if ((g & sub_mask) == 0) return 3;                      // exact phasor again, same scaling
         return (fabs(ddt) * wmax < 2e-6) ? 0 : 1;
     }
-    // Sub-anchor: every GF_SUBANCHOR rows inside a scaling block the phasor is recomputed exactly
-    // (theta = d t_n as one rounded multiply, rho = exp(-c (t_n - t_ref))), so the rotation's
-    // rounding accumulates over at most GF_SUBANCHOR - 1 steps.  Without it (63 steps) the
-    // log-likelihood of ill-conditioned problems (pivot/diagonal ~ 1e-6) was off by 1e-8, 20 x the
-    // error of exact generation (tests/test_gpu_random.py, seed 126).
+    // Sub-anchor: every `period` rows (gf_set_generator_period: 1, 2, 4, ... 64) the phasor is
+    // recomputed exactly (theta = d t_n as one rounded multiply, rho = exp(-c (t_n - t_ref))), so
+    // the rotation's rounding -- coherent within a segment, the cached multiplier carries one
+    // fixed 0.5-ulp error -- accumulates over at most period - 1 steps.  Measured against the
+    // 80-bit recurrence (tests/test_gpu_random.py seeds, condition 4e5): period 1 = exact
+    // generation every row 2e-10 (the float64 class), 4: 2e-9, 16: 1e-8, 64: several 1e-8.
     __device__ __forceinline__ void subanchor(const double tn) {
         t_m1 = tn;
         double si, co;
@@ -886,7 +885,7 @@ struct RowGen {
 template <int ROWS>
 __global__ void __launch_bounds__(64, 2)
 k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int nch,
-          const int Jr, const int Jc, const int block, const double gap,
+          const int Jr, const int Jc, const int block_sub, const double gap,
           const double *__restrict__ ar_, const double *__restrict__ cr_,
           const double *__restrict__ ac_, const double *__restrict__ bc_,
           const double *__restrict__ cc_, const double *__restrict__ dc_,
@@ -898,6 +897,7 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
           double *__restrict__ Ut_out, double *__restrict__ Wt_out, double *__restrict__ de_out,
           double *__restrict__ S_state, double *__restrict__ F_state,
           int32_t *__restrict__ info) {
+    const int block = block_sub & 0xff;     // | (generator sub-anchor period << 8)
     const int lane = threadIdx.x;
     const int b = blockIdx.x;                       // state slot = problem * nch + chunk
     if (info[b] != 0) return;
@@ -920,7 +920,7 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     const double diag_add = diag_add_[pr];
 
     RowGen G;
-    G.init(lane, pr, Jr, Jc, block, gap, ar_, cr_, ac_, bc_, cc_, dc_, cmax_, tg, g0);
+    G.init(lane, pr, Jr, Jc, block_sub, gap, ar_, cr_, ac_, bc_, cc_, dc_, cmax_, tg, g0);
     const double cj = G.cj;
 
     __shared__ double s_w[64];      // r_{n-1}  (pending rank-1 update, row form)
@@ -1104,7 +1104,7 @@ __device__ __forceinline__ void pipe_preload(double (&ab)[PP_AHEAD + 1][PP_BR],
 template <int ROWS, bool STORES>
 __global__ void __launch_bounds__(64, 2)
 k_factor5(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int nch,
-          const int Jr, const int Jc, const int block, const double gap,
+          const int Jr, const int Jc, const int block_sub, const double gap,
           const double *__restrict__ ar_, const double *__restrict__ cr_,
           const double *__restrict__ ac_, const double *__restrict__ bc_,
           const double *__restrict__ cc_, const double *__restrict__ dc_,
@@ -1116,6 +1116,7 @@ k_factor5(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
           double *__restrict__ Ut_out, double *__restrict__ Wt_out, double *__restrict__ de_out,
           double *__restrict__ S_state, double *__restrict__ F_state,
           int32_t *__restrict__ info) {
+    const int block = block_sub & 0xff;     // | (generator sub-anchor period << 8)
     const int lane = threadIdx.x;
     const int b = blockIdx.x;                       // state slot = problem * nch + chunk
     if (info[b] != 0) return;
@@ -1134,7 +1135,7 @@ k_factor5(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     const double diag_add = diag_add_[pr];
 
     RowGen G;
-    G.init(lane, pr, Jr, Jc, block, gap, ar_, cr_, ac_, bc_, cc_, dc_, cmax_, tg, g0);
+    G.init(lane, pr, Jr, Jc, block_sub, gap, ar_, cr_, ac_, bc_, cc_, dc_, cmax_, tg, g0);
 
     __shared__ double s_gen[10 * 64];   // the generator's per-lane state, parked during the sweeps
     __shared__ __attribute__((aligned(16))) double s_w[2][64];   // r_{n-2} | r_{n-1}  (by parity)
@@ -1331,7 +1332,7 @@ k_factor5(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
                 // kind of row n+1 (RowGen::peek; g0 is a multiple of block, so the block phase is n's)
                 const double t_next = read_lane(s_in[0][(n + 1) & 63], 0);
                 const double dt = t_next - tm1, ddt = dt - dtr;
-                if ((((n + 1) & bmask) == 0) || (((n + 1) & (GF_SUBANCHOR - 1)) == 0) || (cmx * dt > gp)
+                if ((((n + 1) & bmask) == 0) || (((n + 1) & G.sub_mask) == 0) || (cmx * dt > gp)
                     || !(fabs(ddt) * wmx < 2e-6)) break;
                 tm1 = t_next;
                 G.unpark(s_gen, lane);
@@ -1699,7 +1700,7 @@ k_factor4(const int64_t N, const int64_t n_first, const int Jr, const int Jc, co
 template <int ROWS>
 __global__ void __launch_bounds__(64, 2)
 k_phi(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int nch,
-      const int Jr, const int Jc, const int block, const double gap,
+      const int Jr, const int Jc, const int block_sub, const double gap,
       const double *__restrict__ ar_, const double *__restrict__ cr_,
       const double *__restrict__ ac_, const double *__restrict__ bc_,
       const double *__restrict__ cc_, const double *__restrict__ dc_,
@@ -1707,6 +1708,7 @@ k_phi(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int
       const double *__restrict__ t_, const int64_t t_bs,
       const double *__restrict__ dbar_, const double *__restrict__ rbar_,
       double *__restrict__ h_out, double *__restrict__ Phi_out) {
+    const int block = block_sub & 0xff;     // | (generator sub-anchor period << 8)
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     const int pr = b / nch, ch = b - pr * nch;
@@ -1721,7 +1723,7 @@ k_phi(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int
     double *__restrict__ Pg = Phi_out + (size_t)b * (64 * 64) + (size_t)lane * 64;
 
     RowGen G;
-    G.init(lane, pr, Jr, Jc, block, gap, ar_, cr_, ac_, bc_, cc_, dc_, cmax_, tg, g0);
+    G.init(lane, pr, Jr, Jc, block_sub, gap, ar_, cr_, ac_, bc_, cc_, dc_, cmax_, tg, g0);
     const double cj = G.cj;
 
     __shared__ double s_w[64], s_u[64], s_e[64];
@@ -3191,8 +3193,9 @@ int gf_factor_scaled(int B, int64_t N, int64_t n_first, int W, int ld, const dou
     return check_launch("gf_factor_scaled");
 }
 
-#define GF_F3_ARGS dim3(B * nch), dim3(64), 0, st, N, n_first, chunk_len, nch, Jr, Jc, block, gap, ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out, Ut_out, Wt_out, de_out, S_state, F_state, info
+#define GF_F3_ARGS dim3(B * nch), dim3(64), 0, st, N, n_first, chunk_len, nch, Jr, Jc, (block | (g_gen_period << 8)), gap, ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out, Ut_out, Wt_out, de_out, S_state, F_state, info
 #define GF_F3_CASE(R) case R: if (!g_pipelined) hipLaunchKernelGGL((k_factor3<R>), GF_F3_ARGS); else if (r_out || Ut_out || de_out) hipLaunchKernelGGL((k_factor5<R, true>), GF_F3_ARGS); else hipLaunchKernelGGL((k_factor5<R, false>), GF_F3_ARGS); break;
+static int g_gen_period = 16;       // gf_set_generator_period
 static int g_pipelined = 0;         // gf_set_pipelined(1) selects the pipelined k_factor5 (experimental, slower: DESIGN.md 4.2)
 
 
@@ -3228,6 +3231,12 @@ static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int6
         default: return set_err("%s: internal dispatch error", who);
     }
     return check_launch(who);
+}
+
+int gf_set_generator_period(int period) {
+    const int old = g_gen_period;
+    if (period >= 1 && period <= 64 && !(period & (period - 1))) g_gen_period = period;
+    return old;
 }
 
 int gf_set_pipelined(int on) {
@@ -3290,7 +3299,7 @@ int gf_chunk_sweep(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc,
                         Ut_out, Wt_out, de_out, S_state, F_state, info, stream);
 }
 
-#define GF_PHI_CASE(R) case R: hipLaunchKernelGGL((k_phi<R>), dim3(B * nch), dim3(64), 0, st, N, (int64_t)0, chunk_len, nch, Jr, Jc, block, gap, ar, cr, ac, bc, cc, dc, cmax, t, t_bs, dbar, rbar, h_out, Phi_out); break;
+#define GF_PHI_CASE(R) case R: hipLaunchKernelGGL((k_phi<R>), dim3(B * nch), dim3(64), 0, st, N, (int64_t)0, chunk_len, nch, Jr, Jc, (block | (g_gen_period << 8)), gap, ar, cr, ac, bc, cc, dc, cmax, t, t_bs, dbar, rbar, h_out, Phi_out); break;
 
 int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc, int block,
                         const double *ar, const double *cr, const double *ac,

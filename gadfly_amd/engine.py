@@ -447,6 +447,10 @@ class StreamingBatch:
         # on gfx950 FP64 MFMA and vector instructions do not execute concurrently and run at the
         # same FMA rate, so the blocked form is no faster than k_factor3
         self.allow_blocked = bool(allow_blocked)
+        # rows between exact re-anchorings of the in-register generator (gf_set_generator_period):
+        # 16 = throughput setting (log-likelihood within 1e-8 up to conditions ~3e5), 1 = exact
+        # generation every row (float64-class accuracy on ill-conditioned problems, ~12 % slower)
+        self.generator_period = 16
         T = int(min(max(int(tile_rows), 1), self.N))
         if T < self.N:
             T = max(64, T // 64 * 64)         # tiles start on a reset row (any block <= 64)
@@ -616,6 +620,7 @@ class StreamingBatch:
         T, N, B = self.tile_rows, self.N, self.B
         real, comp, diag_add, _, cmax, block, _ = self._pack
         blocked = self._blocked_ok()
+        lib.gf_set_generator_period(int(self.generator_period))
         sweep = lib.gf_loglike_blocked if blocked else lib.gf_loglike_fused
         self.kernel_used = "blocked" if blocked else "fused"
         for k in range((N + T - 1) // T):
@@ -668,6 +673,7 @@ class StreamingBatch:
         N, B = self.N, self.B
         real, comp, diag_add, _, cmax, block, _ = self._pack
         chunk_len, nch = self._tp_chunking(chunk_len)
+        lib.gf_set_generator_period(int(self.generator_period))
         f64 = dict(dtype=torch.float64, device=self.device)
         key = (chunk_len, nch)
         if getattr(self, "_tp_key", None) != key:

@@ -179,6 +179,8 @@ class GaussianProcess:
         self.kernel = kernel
         self.mean = mean
         self._device = device
+        #: rows between exact re-anchorings of the device-side row generator (1 = exact every row)
+        self.generator_period = 1
         self._factor = None
         self._fast = None
         self._t = None
@@ -341,6 +343,11 @@ class GaussianProcess:
                                   device=self._device)
             if not fast._fused_ok():
                 fast = None
+            else:
+                # the drop-in class favours accuracy over the last 10 % of speed: exact generator
+                # rows (float64-class results also for ill-conditioned problems, e.g. yerr = 0);
+                # the batched throughput paths (BatchedLogLikelihood, bench.py) keep period 16
+                fast.generator_period = self.generator_period
         self._fast = fast
         if fast is not None:
             _, logdet = fast.evaluate()

@@ -143,6 +143,17 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
                      int32_t *info, void *stream);
 
 /*
+ * Accuracy / speed of the in-register generator rows of gf_loglike_fused, gf_chunk_sweep and
+ * gf_chunk_transition: between exact anchors the rows advance by a cached complex rotation; every
+ * `period` rows (a power of two, 1..64; default 16) the phasor is recomputed exactly.  period = 1
+ * is exact generation every row: float64-class accuracy even for ill-conditioned problems
+ * (pivot/diagonal ~ 1e-6), ~12 % slower; period = 16 keeps the log-likelihood within 1e-8 up to
+ * conditions of ~3e5 (1e-11 on the benchmark's workload).  Irregular spacings are always generated
+ * exactly.  Process-wide switch, returns the previous setting.
+ */
+int gf_set_generator_period(int period);
+
+/*
  * gf_set_pipelined(1) makes gf_loglike_fused / gf_chunk_sweep run the software-pipelined sweep
  * (k_factor5: the reductions, reciprocal and r, q of row n-1 are issued between the FMA batches of
  * sweep n).  Experimental and currently slower than the default k_factor3 (DESIGN.md 4.2 has the
