@@ -3195,7 +3195,7 @@ int gf_factor_scaled(int B, int64_t N, int64_t n_first, int W, int ld, const dou
 
 #define GF_F3_ARGS dim3(B * nch), dim3(64), 0, st, N, n_first, chunk_len, nch, Jr, Jc, (block | (g_gen_period << 8)), gap, ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out, Ut_out, Wt_out, de_out, S_state, F_state, info
 #define GF_F3_CASE(R) case R: if (!g_pipelined) hipLaunchKernelGGL((k_factor3<R>), GF_F3_ARGS); else if (r_out || Ut_out || de_out) hipLaunchKernelGGL((k_factor5<R, true>), GF_F3_ARGS); else hipLaunchKernelGGL((k_factor5<R, false>), GF_F3_ARGS); break;
-static int g_gen_period = 16;       // gf_set_generator_period
+static int g_gen_period = 4;        // gf_set_generator_period
 static int g_pipelined = 0;         // gf_set_pipelined(1) selects the pipelined k_factor5 (experimental, slower: DESIGN.md 4.2)
 
 

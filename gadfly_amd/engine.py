@@ -448,9 +448,10 @@ class StreamingBatch:
         # same FMA rate, so the blocked form is no faster than k_factor3
         self.allow_blocked = bool(allow_blocked)
         # rows between exact re-anchorings of the in-register generator (gf_set_generator_period):
-        # 16 = throughput setting (log-likelihood within 1e-8 up to conditions ~3e5), 1 = exact
-        # generation every row (float64-class accuracy on ill-conditioned problems, ~12 % slower)
-        self.generator_period = 16
+        # 4 = throughput setting (log-likelihood within ~2e-9 at a condition of 4e5; 3 % slower than
+        # 16, which reaches 1e-8 there), 1 = exact generation every row (float64-class accuracy,
+        # 15 % slower)
+        self.generator_period = 4
         T = int(min(max(int(tile_rows), 1), self.N))
         if T < self.N:
             T = max(64, T // 64 * 64)         # tiles start on a reset row (any block <= 64)
