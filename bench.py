@@ -50,9 +50,11 @@ def parse():
     ap.add_argument("--kernel", choices=["auto", "blocked", "fused", "pipelined"], default="auto",
                     help="sweep kernel: blocked = k_factor4 (FP64 MFMA, rank-16 blocks), "
                          "fused = k_factor3 (vector FMA); auto takes blocked when supported")
-    ap.add_argument("--generator-period", type=int, default=4,
+    ap.add_argument("--generator-period", type=int, default=0,
                     help="rows between exact re-anchorings of the in-kernel row generator "
-                         "(1 = exact rows; 4 = default throughput setting, DESIGN.md 2.1a)")
+                         "(1 = exact rows ... 64 = at the scaling-block resets only); 0 = chosen "
+                         "after the warm-up from the measured conditioning so that the generator's "
+                         "share of the log-likelihood error stays below 1e-9 (DESIGN.md 2.1a)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=0,
                     help="rows of the CPU-baseline sample (0 = full N, one evaluation)")
@@ -121,13 +123,17 @@ def main():
         raise SystemExit("--kernel blocked: not supported for this term structure / cadence")
     eng.time_factor = True
     eng.force_streaming = True      # the metric is the streamed sweep of independent evaluations
-    eng.generator_period = args.generator_period
+    if args.generator_period > 0:
+        eng.generator_period = args.generator_period
     torch.cuda.synchronize()
 
     outs = []
     for s in range(args.warmup):
         outs.append(ev.evaluate_device(packs[s]))
     torch.cuda.synchronize()
+    gen_cond = None
+    if args.generator_period == 0 and args.warmup > 0:
+        gen_cond, _ = ev.calibrate()        # what a sampler does after its first steps
     eng.factor_events = []
     if dist is not None:
         dist.barrier()
@@ -178,7 +184,8 @@ def main():
                         "each = build + factor + solve + reduce; time axis streamed in tiles of "
                         f"{args.tile_rows} rows",
             "N": N, "J": J, "W": W, "evals_per_rank_per_step": E,
-            "tile_rows": args.tile_rows, "generator_period": args.generator_period,
+            "tile_rows": args.tile_rows, "generator_period": int(eng.generator_period),
+            "condition_estimate": gen_cond,
             "parallelism": f"independent evaluations x{world}" if world > 1 else "1 GPU",
         },
     }

@@ -41,6 +41,10 @@ class BatchedLogLikelihood:
         self.engine = StreamingBatch([k.get_device_coefficients() for k in kernels], t,
                                      y - mean, diag=d, tile_rows=tile_rows, device=device,
                                      overlap_build=overlap_build)
+        #: keep the row generator's share of the relative log-likelihood error below this by
+        #: choosing its re-anchoring period from the measured conditioning
+        self.generator_target = 1e-9
+        self.auto_generator_period = True
 
     @property
     def B(self):
@@ -60,7 +64,17 @@ class BatchedLogLikelihood:
 
     def evaluate(self, kernels=None):
         out = self.evaluate_device(None if kernels is None else self.pack(kernels))
-        return out.cpu().numpy()
+        res = out.cpu().numpy()
+        if self.auto_generator_period:
+            # the result copy synchronised anyway: adapt the generator period of the NEXT
+            # evaluation to the conditioning just seen (hyperparameters move slowly in a sampler)
+            self.engine.calibrate_generator(self.generator_target)
+        return res
+
+    def calibrate(self):
+        """After asynchronous evaluations (:meth:`evaluate_device`): set the generator period
+        from the condition estimate of the last one.  Returns (condition, period)."""
+        return self.engine.calibrate_generator(self.generator_target)
 
 
 def log_likelihood_batch(kernels, t, y, yerr=None, diag=None, mean=0.0, device=None):

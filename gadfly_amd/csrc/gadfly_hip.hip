@@ -841,25 +841,26 @@ struct RowGen {
     }
     __device__ __forceinline__ void next(const double tn, const int64_t g, double &ut, double &vt,
                                          bool &rst, double &de) {
-        double dt, ddt;
-        const int kind = peek(tn, g, dt, ddt);
-        rst = kind == 2;
-        if (kind == 2) {                            // wave-uniform
+        // two wave-uniform tests on the common path (reset? plain step?); the rare cases are told
+        // apart inside the rare branch
+        const double dt = tn - t_m1;
+        double ddt = dt - dt_ref;
+        rst = ((g & (block - 1)) == 0) || (cmax * dt > gap);
+        de = -1.0;
+        if (rst) {
             anchor(tn, g, de);
-        } else if (kind == 3) {                     // wave-uniform
-            subanchor(tn);
-            de = -1.0;
-        } else if (kind == 1) {                     // wave-uniform: spacing differs from the cached one
-            // exact phasor (an irregular cadence thus never accumulates rotation steps: same cost
-            // as refreshing the multiplier, exact accuracy); the cached multipliers move to the
-            // new spacing only once it repeats (a lasting change of cadence, not a single odd row)
-            subanchor(tn);
-            if (fabs(dt - dt_last) * wmax < 2e-6) refresh(dt);
-            dt_last = read_lane(dt, 0);
-            de = -1.0;
-        } else {
+        } else if (((g & sub_mask) != 0) && (fabs(ddt) * wmax < 2e-6)) {
             step(tn, ddt);
-            de = -1.0;
+        } else {
+            // sub-anchor row, or a spacing that differs from the cached one: exact phasor (an
+            // irregular cadence thus never accumulates rotation steps: same cost as refreshing
+            // the multiplier, exact accuracy); the cached multipliers move to a new spacing
+            // only once it repeats (a lasting change of cadence, not a single odd row)
+            subanchor(tn);
+            if (!(fabs(ddt) * wmax < 2e-6)) {
+                if (fabs(dt - dt_last) * wmax < 2e-6) refresh(dt);
+                dt_last = read_lane(dt, 0);
+            }
         }
         emit(ut, vt);
     }
@@ -2499,43 +2500,51 @@ __host__ __device__ inline int red_groups(int64_t N) {
     return (int)g;
 }
 
+constexpr int RED_NACC = 3;         // sum log d, sum z^2/d, min d
+
 __global__ void __launch_bounds__(RED_BLOCK) k_reduce1(int64_t N, const double *d, const double *z,
                                                        double *work) {
     const int b = blockIdx.y, g = blockIdx.x, G = gridDim.x;
     const double *dp = d + (size_t)b * N;
     const double *zp = z ? z + (size_t)b * N : nullptr;
-    double s1 = 0.0, s2 = 0.0;
+    double s1 = 0.0, s2 = 0.0, mn = INFINITY;
     for (int64_t n = (int64_t)g * RED_BLOCK + threadIdx.x; n < N; n += (int64_t)G * RED_BLOCK) {
         const double dn = dp[n];
         s1 += log(dn);
+        mn = fmin(mn, dn);
         if (zp) { const double zn = zp[n]; s2 += zn * zn / dn; }
     }
     wave_sum2(s1, s2);
-    __shared__ double sh[2][RED_BLOCK / 64];
+    mn = -wave_max(-mn);
+    __shared__ double sh[RED_NACC][RED_BLOCK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { sh[0][wave] = s1; sh[1][wave] = s2; }
+    if (lane == 0) { sh[0][wave] = s1; sh[1][wave] = s2; sh[2][wave] = mn; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double t1 = 0.0, t2 = 0.0;
-        for (int w = 0; w < RED_BLOCK / 64; ++w) { t1 += sh[0][w]; t2 += sh[1][w]; }
-        work[((size_t)b * G + g) * 2] = t1;
-        work[((size_t)b * G + g) * 2 + 1] = t2;
+        double t1 = 0.0, t2 = 0.0, t3 = INFINITY;
+        for (int w = 0; w < RED_BLOCK / 64; ++w) { t1 += sh[0][w]; t2 += sh[1][w]; t3 = fmin(t3, sh[2][w]); }
+        double *o = work + ((size_t)b * G + g) * RED_NACC;
+        o[0] = t1; o[1] = t2; o[2] = t3;
     }
 }
 
-// acc[b] = {sum log d, sum z^2/d}; init != 0 overwrites, else adds (tile streaming, fixed order)
+// acc[b] = {sum log d, sum z^2/d, min d}; init != 0 overwrites, else accumulates (tile streaming,
+// fixed order)
 __global__ void __launch_bounds__(64) k_reduce2(int G, const double *work, double *acc, int init) {
     const int b = blockIdx.x, lane = threadIdx.x;
-    double s1 = 0.0, s2 = 0.0;
+    double s1 = 0.0, s2 = 0.0, mn = INFINITY;
     for (int g = lane; g < G; g += 64) {
-        s1 += work[((size_t)b * G + g) * 2];
-        s2 += work[((size_t)b * G + g) * 2 + 1];
+        const double *w = work + ((size_t)b * G + g) * RED_NACC;
+        s1 += w[0];
+        s2 += w[1];
+        mn = fmin(mn, w[2]);
     }
     wave_sum2(s1, s2);
+    mn = -wave_max(-mn);
     if (lane == 0) {
-        if (!init) { s1 += acc[2 * b]; s2 += acc[2 * b + 1]; }
-        acc[2 * b] = s1;
-        acc[2 * b + 1] = s2;
+        double *a = acc + (size_t)b * RED_NACC;
+        if (!init) { s1 += a[0]; s2 += a[1]; mn = fmin(mn, a[2]); }
+        a[0] = s1; a[1] = s2; a[2] = mn;
     }
 }
 
@@ -2544,7 +2553,7 @@ __global__ void k_finish(int B, int64_t N, const double *acc, const int32_t *inf
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const bool bad = info && info[b] != 0;
-    const double s1 = acc[2 * b], s2 = acc[2 * b + 1];
+    const double s1 = acc[(size_t)b * RED_NACC], s2 = acc[(size_t)b * RED_NACC + 1];
     if (logdet) logdet[b] = bad ? -INFINITY : s1;
     if (out) out[b] = bad ? -INFINITY : (-0.5 * (s1 + (double)N * 1.8378770664093453) - 0.5 * s2);
 }
@@ -3426,7 +3435,7 @@ int gf_chunk_linear_combine(int mode, int B, int64_t N, int64_t chunk_len, int n
     return check_launch("gf_chunk_linear_combine");
 }
 
-int64_t gf_reduce_work(int64_t N) { return 2 * (int64_t)red_groups(N); }
+int64_t gf_reduce_work(int64_t N) { return RED_NACC * (int64_t)red_groups(N); }
 
 int gf_reduce_tile(int B, int64_t N, const double *d, const double *z,
                    double *work, double *acc, int init, void *stream) {

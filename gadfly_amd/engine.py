@@ -205,7 +205,7 @@ class DeviceBatch:
         B, N = self.B, self.N
         f64 = dict(dtype=torch.float64, device=self.device)
         work = torch.empty((B * int(self.lib.gf_reduce_work(N)),), **f64)
-        acc = torch.empty((B, 2), **f64)
+        acc = torch.empty((B, 3), **f64)
         out = torch.empty((B,), **f64)
         logdet = torch.empty((B,), **f64)
         p = _lib.ptr
@@ -474,7 +474,7 @@ class StreamingBatch:
         nF = 64 if self.scaled else int(self.lib.gf_state_cols(self.W))
         self.S_state = torch.empty((B, nS), **f64)
         self.F_state = torch.empty((B, nF), **f64)
-        self.acc = torch.empty((B, 2), **f64)
+        self.acc = torch.empty((B, 3), **f64)
         self.work = torch.empty((B * int(self.lib.gf_reduce_work(T)),), **f64)
         self.info = torch.zeros((B,), dtype=torch.int32, device=self.device)
         self.out = torch.empty((B,), **f64)
@@ -500,6 +500,32 @@ class StreamingBatch:
     def _fused_ok(self):
         """Phases d*t must stay inside fm_sincos's Cody-Waite range (|x| < 1.6e6)."""
         return self.allow_fused and self._pack[6] * self._tmax < 1.6e6
+
+    # error of the log-likelihood ~ GEN_ERR * period * condition (measured: 1e-8 at period 16 and a
+    # condition of 4e5, DESIGN.md 2.1a)
+    GEN_ERR = 1.6e-15
+
+    def condition_estimate(self):
+        """max(a) / min(d) over all problems of the LAST evaluation (synchronises): the factor by
+        which rounding in the generator rows shows up in the log-likelihood."""
+        acc = self._tp["acc"] if getattr(self, "_tp_used", False) else self.acc
+        dmin = float(acc[:, 2].min().item())
+        amax = float(self._pack[2].max().item())
+        if self.diag is not None:
+            amax += float(self.diag.max().item())
+        return amax / dmin if dmin > 0.0 else float("inf")
+
+    def calibrate_generator(self, target=1e-9):
+        """Choose the generator period (rows between exact re-anchorings, a power of two in 1..64)
+        for the following evaluations from the condition estimate of the last one, so that the
+        generator's contribution to the relative log-likelihood error stays below ``target``.
+        Returns (condition estimate, period)."""
+        cond = self.condition_estimate()
+        period = 1
+        while period < 64 and self.GEN_ERR * (2 * period) * cond <= target:
+            period *= 2
+        self.generator_period = period
+        return cond, period
 
     def _blocked_ok(self):
         return (self.allow_blocked and self._fused_ok()
@@ -686,7 +712,7 @@ class StreamingBatch:
                 r=torch.zeros((B * N + 2, 64), **f64), h=torch.empty((B * N, 64), **f64),
                 info=torch.zeros((B * nch,), dtype=torch.int32, device=self.device),
                 work=torch.empty((B * int(lib.gf_reduce_work(N)),), **f64),
-                acc=torch.empty((B, 2), **f64))
+                acc=torch.empty((B, 3), **f64))
             self._tp_key = key
         w = self._tp
         if store and "Ut" not in w:

@@ -147,9 +147,11 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
  * gf_chunk_transition: between exact anchors the rows advance by a cached complex rotation; every
  * `period` rows (a power of two, 1..64; default 4) the phasor is recomputed exactly.  Measured at a
  * condition (diagonal/pivot) of 4e5 against an 80-bit recurrence, and per 8192-row tile of 2048
- * evaluations: period 1 (exact rows) 2e-10 / 12.1 ms, 4: 2e-9 / 10.6 ms, 16: 1e-8 / 10.3 ms,
- * 64: several 1e-8 / 9.9 ms (1e-11 on the benchmark's workload at any period).  Irregular spacings
- * are always generated exactly.  Process-wide switch, returns the previous setting.
+ * evaluations: period 1 (exact rows) 2e-10 / 12.2 ms, 4: 2e-9 / 10.4 ms, 16: 1e-8 / 10.0 ms,
+ * 64: several 1e-8 / 10.0 ms, i.e. error ~ 1.6e-15 * period * condition (1e-11 on the benchmark's
+ * workload, condition 48, at any period).  Callers pick the period from the condition estimate
+ * max(a) / min(d) that gf_reduce_tile returns.  Irregular spacings are always generated exactly.
+ * Process-wide switch, returns the previous setting.
  */
 int gf_set_generator_period(int period);
 
@@ -248,9 +250,11 @@ int gf_chunk_linear_combine(int mode, int B, int64_t N, int64_t chunk_len, int n
 
 /*
  * Log-likelihood reductions (fixed-shape tree, deterministic):
- *   gf_reduce_tile   : acc[b] = {sum log d, sum z^2/d} over N rows; init != 0 overwrites acc,
- *                      init == 0 adds to it (tiles in order).  z == NULL: second sum is 0.
- *                      work must hold B * gf_reduce_work(N) doubles.
+ *   gf_reduce_tile   : acc[b] = {sum log d, sum z^2/d, min d} (THREE doubles per problem) over N
+ *                      rows; init != 0 overwrites acc, init == 0 accumulates (tiles in order).
+ *                      z == NULL: second sum is 0.  work: B * gf_reduce_work(N) doubles.
+ *                      min d gives the condition estimate max(a) / min(d) that selects the
+ *                      generator period (gf_set_generator_period).
  *   gf_loglike_finish: out[b] = -0.5 (acc0 + Ntot log 2pi) - 0.5 acc1; logdet[b] = acc0
  *                      (either may be NULL); info[b] != 0 -> -inf for both.
  */

@@ -104,3 +104,34 @@ def test_random_problem(hip, seed):
     ll_g = float(gen.log_likelihood(torch.as_tensor(y).cuda(), keep_W=True)[0])
     assert abs(ll_g - ref) <= RTOL_LL * abs(ref), (tag, ll_g, ref)
     assert _relmax(gen.apply_inverse(Yd)[0].cpu().numpy(), ai_ref) < TOL_VEC, tag
+
+
+def test_generator_calibration(hip):
+    """The condition estimate (max a / min d from the reduction kernel) and the period it selects:
+    a well-conditioned solar-like problem gets the longest period, an ill-conditioned one (seed
+    1127: condition 4e5) exact rows; the batched evaluator adapts after its first evaluation."""
+    import gadfly_amd
+    from gadfly_amd.engine import StreamingBatch
+    from gadfly_amd.synth import solar_like_hyperparameters, uniform_times
+    from oracle import cref, seq
+    k = gadfly_amd.StellarOscillatorKernel(solar_like_hyperparameters(12), texp=60.0)
+    t = uniform_times(20000, 60.0)
+    y = np.random.default_rng(1).normal(size=len(t)) * 80.0
+    ev = gadfly_amd.BatchedLogLikelihood([k, k], t, y, yerr=30.0)
+    assert ev.engine.generator_period == 4                  # until something has been measured
+    ev.evaluate()
+    co = k.get_device_coefficients()
+    c, a, U, V = seq.celerite_matrices(co[:6], t, np.full(len(t), 900.0) + co[6])
+    d_ref, _, _ = cref.factor(t, c, a, U, V)
+    cond_ref = float(a.max() / d_ref.min())
+    assert abs(ev.engine.condition_estimate() - cond_ref) <= 1e-6 * cond_ref
+    assert ev.engine.generator_period == 64 and cond_ref < 1e3
+
+    prob = _problem(1127)
+    co = prob["kernel"].get_device_coefficients()
+    eng = StreamingBatch([co], prob["t"], prob["y"], diag=prob["diag_user"])
+    eng.log_likelihood()
+    cond, period = eng.calibrate_generator()
+    assert cond > 1e5 and period == 1
+    ref, _ = cref.loglike(co[:6], prob["t"], prob["diag_user"] + co[6], prob["y"])
+    assert abs(float(eng.log_likelihood()[0]) - ref) <= 2e-9 * abs(ref)
