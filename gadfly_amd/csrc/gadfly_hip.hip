@@ -1780,14 +1780,16 @@ k_phi(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int
 }
 
 // G[i][j] = sum_n h_n[i] h_n[j] / dbar_n ;  m[i] = sum_n h_n[i] zbar_n / dbar_n   per chunk.
-// One workgroup of 256 threads per (problem, chunk); thread (ty, tx) owns a 4x4 block of G.
-// Output layout [j][i] (column-major, = the lane-major layout of the sweep states).
-__global__ void __launch_bounds__(256)
-k_gram(const int64_t N, const int64_t chunk_len, const int nch,
-       const double *__restrict__ h_, const double *__restrict__ dbar_,
-       const double *__restrict__ zbar_, double *__restrict__ G_out, double *__restrict__ m_out) {
-    constexpr int TR = 32;
-    const int b = blockIdx.x;
+// k_gram_mfma: the same sums on the FP64 matrix pipe (a pure rank-k update: 32 FMAs per loaded
+// double instead of 2 with 4x4 register blocks, which ran LDS-bound at 14 TFLOP/s).  One wave per
+// (problem, chunk); four rows per step: A[i][k] = h(row0 + k, 16 it + i) in lane (i, k),
+// B[k][j] = the same register divided by d(row0 + k); G as 10 accumulator tiles (it <= jt, G is
+// symmetric); operands come straight from global memory, prefetched one step ahead.
+__global__ void __launch_bounds__(64)
+k_gram_mfma(const int64_t N, const int64_t chunk_len, const int nch,
+            const double *__restrict__ h_, const double *__restrict__ dbar_,
+            const double *__restrict__ zbar_, double *__restrict__ G_out, double *__restrict__ m_out) {
+    const int lane = threadIdx.x, b = blockIdx.x;
     const int pr = b / nch, ch = b - pr * nch;
     const int64_t c0 = (int64_t)ch * chunk_len;
     const int64_t rows = (N - c0 < chunk_len) ? (N - c0) : chunk_len;
@@ -1795,48 +1797,59 @@ k_gram(const int64_t N, const int64_t chunk_len, const int nch,
     const double *__restrict__ hg = h_ + pb * 64;
     const double *__restrict__ dg = dbar_ + pb;
     const double *__restrict__ zg = zbar_ + pb;
-    __shared__ double sh[TR][64], shd[TR][64], sz[TR];
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    double acc[4][4] = {};
-    double macc[4] = {};
-    for (int64_t r0 = 0; r0 < rows; r0 += TR) {
-        const int nr = (int)((rows - r0 < TR) ? (rows - r0) : TR);
-        for (int e = tid; e < TR * 64; e += 256) {
-            const int r = e >> 6, j = e & 63;
-            double hv = 0.0, dinv = 0.0;
-            if (r < nr) { hv = hg[(size_t)(r0 + r) * 64 + j]; dinv = 1.0 / dg[r0 + r]; }
-            sh[r][j] = hv;
-            shd[r][j] = hv * dinv;
-            if (j == 0) sz[r] = (r < nr) ? zg[r0 + r] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int r = 0; r < TR; ++r) {
-            double hi[4], hj[4];
+    const int i = lane & 15, k = lane >> 4;
+    d4 acc[4][4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) { hi[a] = sh[r][4 * ty + a]; hj[a] = shd[r][4 * tx + a]; }
+    for (int it = 0; it < 4; ++it)
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+        for (int jt = 0; jt < 4; ++jt) acc[it][jt] = d4{0.0, 0.0, 0.0, 0.0};
+    double macc[4] = {0.0, 0.0, 0.0, 0.0};
+    double an[4], dn = 1.0, zn = 0.0;
+    auto fetch = [&](int64_t r0) {                  // row r0 + k of this lane (zeros past the end)
+        const int64_t r = r0 + k;
+        const bool ok = r < rows;
+        const int64_t rr = ok ? r : (rows - 1);
+        dn = dg[rr];
+        zn = ok ? zg[rr] : 0.0;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[a][c] = fma(hi[a], hj[c], acc[a][c]);
-            if (tx == 0) {
-                const double zr = sz[r];
+        for (int it = 0; it < 4; ++it) { const double v = hg[(size_t)rr * 64 + 16 * it + i]; an[it] = ok ? v : 0.0; }
+    };
+    fetch(0);
+    for (int64_t r0 = 0; r0 < rows; r0 += 4) {
+        double a[4], bq[4];
+        const double dinv = fast_rcp(dn), zd = zn * dinv;
 #pragma unroll
-                for (int a = 0; a < 4; ++a) macc[a] = fma(shd[r][4 * ty + a], zr, macc[a]);
-            }
-        }
-        __syncthreads();
+        for (int it = 0; it < 4; ++it) { a[it] = an[it]; bq[it] = a[it] * dinv; macc[it] = fma(a[it], zd, macc[it]); }
+        if (r0 + 4 < rows) fetch(r0 + 4);           // wave-uniform; in flight during the MFMAs
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int jt = it; jt < 4; ++jt) acc[it][jt] = GF_MFMA64(a[it], bq[jt], acc[it][jt]);
     }
+    // tile (it, jt), register r, lane (j, g):  G(16 it + g + 4 r, 16 jt + j); layout [col][row]
     double *Gg = G_out + (size_t)b * (64 * 64);
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int it = 0; it < 4; ++it)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) Gg[(size_t)(4 * tx + c) * 64 + 4 * ty + a] = acc[a][c];
-    if (tx == 0) {
+        for (int jt = it; jt < 4; ++jt)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) m_out[(size_t)b * 64 + 4 * ty + a] = macc[a];
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * it + k + 4 * r, col = 16 * jt + i;
+                const double v = acc[it][jt][r];
+                Gg[(size_t)col * 64 + row] = v;
+                if (jt > it) Gg[(size_t)row * 64 + col] = v;
+            }
+    // m(16 it + i) = sum over the four k-slices
+    __shared__ double sm[4][64];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) sm[it][lane] = macc[it];
+    wave_lds_fence();
+    {
+        const int it = lane >> 4;                   // lane = 16 it + i
+        m_out[(size_t)b * 64 + lane] = (sm[it][i] + sm[it][i + 16]) + (sm[it][i + 32] + sm[it][i + 48]);
     }
 }
+
 
 // ---- dense 64x64 helpers for the chunk combines (one workgroup of 256 threads) ---------------
 // LDS matrices are row-major with leading dimension CB_LD (conflict-free rows); global
@@ -3335,7 +3348,7 @@ int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int Jr, in
         GF_PHI_CASE(52) GF_PHI_CASE(56) GF_PHI_CASE(60) GF_PHI_CASE(64)
         default: return set_err("gf_chunk_transition: internal dispatch error%s", "");
     }
-    hipLaunchKernelGGL(k_gram, dim3(B * nch), dim3(256), 0, st, N, chunk_len, nch, h_out, dbar, zbar, G_out, m_out);
+    hipLaunchKernelGGL(k_gram_mfma, dim3(B * nch), dim3(64), 0, st, N, chunk_len, nch, h_out, dbar, zbar, G_out, m_out);
     return check_launch("gf_chunk_transition");
 }
 
