@@ -1862,29 +1862,45 @@ __device__ __forceinline__ void cb_load(double *dst, const double *__restrict__ 
     for (int e = tid; e < 4096; e += 256) { const int j = e >> 6, i = e & 63; dst[i * ld + j] = src[e]; }
 }
 
-// acc[a][c] (+)= sum_k A[4ty+a][k] * B[k][4tx+c]   (TB: use B^T, i.e. B[4tx+c][k])
+// 64 x 64 x 64 products on v_mfma_f64_16x16x4 (256 threads = 4 waves; wave w owns rows 16w..16w+15
+// of the result as four accumulator tiles): acc[q][r] = element (cb_row(ty, r), cb_col(tx, q)) of
+// A' B' with A'(row, k) = a_of(row, k), B'(k, col) = b_of(k, col) read from LDS -- two LDS reads per
+// 1024 FMAs instead of one per two with 4x4 register blocks (which ran LDS-bound).
+__device__ __forceinline__ int cb_row(int ty, int r) { return 16 * (ty >> 2) + (ty & 3) + 4 * r; }
+__device__ __forceinline__ int cb_col(int tx, int q) { return 16 * q + tx; }
+
+template <class FA, class FB>
+__device__ __forceinline__ void cb_mm(double (&acc)[4][4], FA a_of, FB b_of, int tx, int ty) {
+    const int i = tx, k = ty & 3, w = ty >> 2;          // lane = (i, k) of wave w
+    d4 C[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) C[q] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {
+        const double av = a_of(16 * w + i, 4 * ks + k);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) C[q] = GF_MFMA64(av, b_of(4 * ks + k, 16 * q + i), C[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[q][r] = C[q][r];
+}
+
+// acc = A' B' with A' = A or A^T (TA), B' = B or B^T (TB), row-major LDS matrices
 template <bool TA, bool TB>
 __device__ __forceinline__ void cb_matmul(double (&acc)[4][4], const double *A, int lda,
                                           const double *B, int ldb, int tx, int ty) {
-    for (int k = 0; k < 64; ++k) {
-        double av[4], bv[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            av[a] = TA ? A[k * lda + 4 * ty + a] : A[(4 * ty + a) * lda + k];
-            bv[a] = TB ? B[(4 * tx + a) * ldb + k] : B[k * ldb + 4 * tx + a];
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[a][c] = fma(av[a], bv[c], acc[a][c]);
-    }
+    cb_mm(acc,
+          [&](int row, int k) { return TA ? A[k * lda + row] : A[row * lda + k]; },
+          [&](int k, int col) { return TB ? B[col * ldb + k] : B[k * ldb + col]; }, tx, ty);
 }
 
 __device__ __forceinline__ void cb_store_lds(double *dst, int ld, const double (&acc)[4][4], int tx, int ty) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) dst[(4 * ty + a) * ld + 4 * tx + c] = acc[a][c];
+        for (int r = 0; r < 4; ++r) dst[cb_row(ty, r) * ld + cb_col(tx, q)] = acc[q][r];
 }
 
 // Gauss-Jordan with IMPLICIT partial pivoting on the 64 x 129 augmented system Au = [A | RHS],
@@ -1997,7 +2013,7 @@ __device__ __forceinline__ void cb_apply(double *Xs, double *Au, double *Bs, dou
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
-                const int i = 4 * ty + a, j = 4 * tx + cc;
+                const int i = cb_row(ty, cc), j = cb_col(tx, a);
                 Au[i * LA + j] = ((i == j) ? 1.0 : 0.0) - acc[a][cc];
                 Au[i * LA + 64 + j] = Xs[i * LD + j];
             }
@@ -2015,18 +2031,10 @@ __device__ __forceinline__ void cb_apply(double *Xs, double *Au, double *Bs, dou
     __syncthreads();
     {
         double acc[4][4] = {};
-        for (int k = 0; k < 64; ++k) {
-            double pa[4], kb[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                pa[a] = Bs[(4 * ty + a) * LD + k];
-                kb[a] = 0.5 * (Au[k * LA + 64 + 4 * tx + a] + Au[(4 * tx + a) * LA + 64 + k]);
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) acc[a][cc] = fma(pa[a], kb[cc], acc[a][cc]);
-        }
+        cb_mm(acc,
+              [&](int row, int k) { return Bs[row * LD + k]; },
+              [&](int k, int col) { return 0.5 * (Au[k * LA + 64 + col] + Au[col * LA + 64 + k]); },
+              tx, ty);
         __syncthreads();
         cb_store_lds(Xs, LD, acc, tx, ty);
     }
@@ -2128,7 +2136,7 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int i = 4 * ty + a, j = 4 * tx + c;
+                const int i = cb_row(ty, c), j = cb_col(tx, a);
                 Au[i * LA + j] = ((i == j) ? 1.0 : 0.0) - acc[a][c];
                 Au[i * LA + 64 + j] = (i == j) ? 1.0 : 0.0;
             }
@@ -2204,7 +2212,7 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) Pr[(size_t)(4 * tx + c) * 64 + 4 * ty + a] = acc[a][c];
+            for (int c = 0; c < 4; ++c) Pr[(size_t)cb_col(tx, a) * 64 + cb_row(ty, c)] = acc[a][c];
     }
     __syncthreads();
     // f. M1 <- G2 (D Phi1) ;  G12 = G1 + Phi1^T M1 ;  m12 = m1 + Phi1^T (m2 - G2 v)
