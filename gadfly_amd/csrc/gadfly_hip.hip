@@ -1904,89 +1904,55 @@ __device__ __forceinline__ void cb_store_lds(double *dst, int ld, const double (
 }
 
 // Gauss-Jordan with IMPLICIT partial pivoting on the 64 x 129 augmented system Au = [A | RHS],
-// held in registers: thread (rgp, jj) owns rows rgp*8..+7 x columns {jj, jj+32, jj+64, jj+96}
-// (+ column 128 for jj == 0).  Per step only the pivot column (for the search) and the pivot
-// row travel through LDS (scratch >= 400 doubles); rows are never swapped or normalised,
-// eliminated columns are never revisited.  Every wave repeats the 64-candidate DPP arg-max, so
-// a step needs two barriers.  On exit Au[:, 64:129] = A^-1 RHS.
+// held in registers with lanes = rows: wave w (of 4) owns the columns c = w (mod 4), 33 registers
+// per lane.  Step k: the wave that owns column k searches the pivot among the unused rows (DPP
+// arg-max), forms the row multipliers f_i = a_ik / a_pk (lane form, f_p = 0) and publishes them
+// with the pivot's lane index through LDS; after ONE barrier every wave eliminates its columns,
+// fetching the pivot row's entries with readlane (an SGPR operand of the FMA: no LDS traffic in
+// the update).  Rows are never swapped or normalised, eliminated columns are not revisited
+// (updating them is harmless and keeps the loops compile-time).  The multiplier buffer alternates
+// between two halves so that the next owner may write while slower waves still read.
+// scratch >= 140 doubles.  On exit Au[:, 64:129] = A^-1 RHS.
 __device__ __forceinline__ void cb_gauss_jordan(double *Au, double *scratch, int tid) {
-    constexpr int LA = CB_LA;
-    const int jj = tid & 31, rgp = tid >> 5, lane = tid & 63;
-    double *pcol = scratch;                 // [2][64] candidate column (double-buffered)
-    double *prow = scratch + 128;           // [129]   pivot row
-    double *pinvr = scratch + 128 + 136;    // [64]    1 / pivot of the row
-    int *rowvar = reinterpret_cast<int *>(scratch + 128 + 136 + 64);    // [64] variable solved by row
-    double R[8][5];
+    constexpr int LA = CB_LA, NC = 33;
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *fbuf = scratch;                                     // [2][64] multipliers
+    double *pinvbuf = scratch + 128;                            // [2]
+    int *pvbuf = reinterpret_cast<int *>(scratch + 130);        // [2]
+    double R[NC];
 #pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int cc = 0; cc < 5; ++cc) {
-            const int j = (cc < 4) ? (jj + 32 * cc) : 128;
-            R[a][cc] = (cc < 4 || jj == 0) ? Au[(rgp * 8 + a) * LA + j] : 0.0;
-        }
-    bool used = false;                      // lane-form: row `lane` already served as a pivot
-    __syncthreads();
-    if (jj == 0) {
-#pragma unroll
-        for (int a = 0; a < 8; ++a) pcol[rgp * 8 + a] = R[a][0];
+    for (int lc = 0; lc < NC; ++lc) {
+        const int c = 4 * lc + w;
+        R[lc] = (c <= 128) ? Au[lane * LA + c] : 0.0;
     }
+    bool used = false;                      // row `lane` already served as a pivot
+    int myk = 0;                            // ... of which variable
+    double mypinv = 0.0;                    // ... with which 1 / pivot
     __syncthreads();
-    for (int k = 0; k < 64; ++k) {
-        const double *pc = pcol + 64 * (k & 1);
-        double *pn = pcol + 64 * ((k & 1) ^ 1);
-        const double cval = pc[lane];
-        const double cand = used ? -1.0 : fabs(cval);
-        const double vm = wave_max(cand);
-        const unsigned long long hit = __ballot(cand == vm);
-        const int pv = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)hit) - 1);
-        if (lane == pv) used = true;
-        // every wave knows the pivot value from its own search lanes: reciprocal and the row
-        // multipliers are formed while the owners publish the pivot row
-        const int lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(cval) & 0xffffffffLL), pv);
-        const int hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(cval) >> 32), pv);
-        const double pval = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-        const double pinv = fast_rcp(pval);
-        if ((pv >> 3) == rgp) {             // owners of row pv publish it (pv is wave-uniform)
-#define CB_PUB(a)                                                                        \
-    case a:                                                                              \
-        prow[jj] = R[a][0]; prow[jj + 32] = R[a][1]; prow[jj + 64] = R[a][2];            \
-        prow[jj + 96] = R[a][3]; if (jj == 0) prow[128] = R[a][4];                       \
-        break;
-            switch (pv & 7) { CB_PUB(0) CB_PUB(1) CB_PUB(2) CB_PUB(3) CB_PUB(4) CB_PUB(5) CB_PUB(6) CB_PUB(7) }
-#undef CB_PUB
-        }
-        if (tid == 0) { rowvar[pv] = k; pinvr[pv] = pinv; }
-        double fr[8];
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            const int i = rgp * 8 + a;
-            fr[a] = (i == pv) ? 0.0 : pc[i] * pinv;
+    static_for([&](auto kc) {
+        constexpr int k = decltype(kc)::value, wo = k & 3, lk = k >> 2, buf = k & 1;
+        if (w == wo) {                      // wave-uniform: this wave owns column k
+            const double cval = R[lk];
+            const double cand = used ? -1.0 : fabs(cval);
+            const double vm = wave_max(cand);
+            const unsigned long long hit = __ballot(cand == vm);
+            const int pv = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)hit) - 1);
+            const double pinv = fast_rcp(read_lane(cval, pv));
+            fbuf[buf * 64 + lane] = (lane == pv) ? 0.0 : cval * pinv;
+            if (lane == 0) { pvbuf[buf] = pv; pinvbuf[buf] = pinv; }
         }
         __syncthreads();
-        const int kn = k + 1;
+        const double f = fbuf[buf * 64 + lane];
+        const int pv = __builtin_amdgcn_readfirstlane(pvbuf[buf]);
+        if (lane == pv) { used = true; myk = k; mypinv = pinvbuf[buf]; }
 #pragma unroll
-        for (int cc = 0; cc < 5; ++cc) {
-            const int j = (cc < 4) ? (jj + 32 * cc) : 128;
-            if (j > k && (cc < 4 || jj == 0)) {
-                const double pk = prow[j];
+        for (int lc = lk; lc < NC; ++lc) R[lc] = fma(-f, read_lane(R[lc], pv), R[lc]);
+    }, std::make_integer_sequence<int, 64>{});
+    // row `lane` solved variable myk:  x(myk, :) = (right part of the row) / pivot
 #pragma unroll
-                for (int a = 0; a < 8; ++a) R[a][cc] = fma(-fr[a], pk, R[a][cc]);
-            }
-        }
-        if (kn < 64 && jj == (kn & 31)) {   // next candidate column -> the other buffer
-#pragma unroll
-            for (int a = 0; a < 8; ++a) pn[rgp * 8 + a] = (kn >> 5) ? R[a][1] : R[a][0];
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {           // variable rowvar[i] = (right part of row i) / pivot(i)
-        const int i = rgp * 8 + a;
-        const int kv = rowvar[i];
-        const double sc = pinvr[i];
-        Au[kv * LA + 64 + jj] = R[a][2] * sc;
-        Au[kv * LA + 96 + jj] = R[a][3] * sc;
-        if (jj == 0) Au[kv * LA + 128] = R[a][4] * sc;
+    for (int lc = 16; lc < NC; ++lc) {
+        const int c = 4 * lc + w;
+        if (c <= 128) Au[myk * LA + c] = R[lc] * mypinv;
     }
     __syncthreads();
 }
@@ -3360,6 +3326,17 @@ int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int Jr, in
     return check_launch("gf_chunk_transition");
 }
 
+// the > 64 KB dynamic-LDS opt-in is a per-device function attribute: remember it per device
+// (false the first time kernel group `which` is launched on the current device)
+static bool lds_opted_in(int which) {
+    static bool done[2][64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    const bool was = done[which][dev];
+    done[which][dev] = true;
+    return was;
+}
+
 static size_t cb_lds_bytes(bool with_xn) {
     (void)with_xn;
     return sizeof(double) * (64 * CB_LD + 64 * CB_LA + 64 * CB_LD + 256);
@@ -3370,11 +3347,7 @@ int gf_chunk_combine(int B, int nch, const double *Phi, const double *G, const d
     if (B < 1 || nch < 1) return set_err("gf_chunk_combine: empty problem%s", "");
     if (!Phi || !G || !m || !S_state || !F_state) return set_err("gf_chunk_combine: null pointer%s", "");
     const size_t lds = cb_lds_bytes(true);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_combine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    if (!lds_opted_in(0)) (void)hipFuncSetAttribute((const void *)k_combine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_combine, dim3(B), dim3(256), lds, (hipStream_t)stream, nch, Phi, G, m, S_state, F_state);
     return check_launch("gf_chunk_combine");
 }
@@ -3389,11 +3362,9 @@ int gf_chunk_combine_tree(int B, int P, double *Phi, double *G, double *m, doubl
     if (!Phi || !G || !m || !S || !F || !Xst || !Yst) return set_err("gf_chunk_combine_tree: null pointer%s", "");
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = cb_lds_bytes(false);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!lds_opted_in(1)) {
         (void)hipFuncSetAttribute((const void *)k_tree_compose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void *)k_tree_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     TreeArgs A;
     A.P = P; A.Phi = Phi; A.G = G; A.S = S; A.F = F; A.m = m; A.Xst = Xst; A.Yst = Yst;
