@@ -329,6 +329,41 @@ def test_streaming_irregular_cadence_fused(hip):
         assert info == 0 and abs(ll - ref) <= RTOL_LL * abs(ref), (allow_fused, ll, ref)
 
 
+@pytest.mark.parametrize("case", [STREAM_CASES[0], STREAM_CASES[1], STREAM_CASES[2], STREAM_CASES[6]],
+                         ids=["solar6", "solar20jitter", "solar30gaps", "overdamped"])
+def test_pipelined_variant(hip, case):
+    """The experimental software-pipelined sweep (gf_set_pipelined(1), k_factor5) gives the results
+    of the default kernel: streamed tiles with state hand-off, and the time-parallel evaluation
+    (chunk mode with the extra row stores)."""
+    from gadfly_amd.engine import StreamingBatch
+    from oracle import cref
+    kind, kw, tile = case
+    prob = _make((kind, kw))
+    k, t, y = prob["kernel"], prob["t"], prob["y"]
+    co = k.get_device_coefficients()
+    ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y)
+    assert info == 0
+    lib = hip.load()
+    old = lib.gf_set_pipelined(1)
+    try:
+        eng = StreamingBatch([co], t, y, diag=prob["diag_user"], tile_rows=tile)
+        assert eng._fused_ok()
+        ll = float(eng.log_likelihood()[0])
+        assert abs(ll - ref) <= RTOL_LL * abs(ref), (ll, ref)
+        ll_tp = float(eng.log_likelihood_time_parallel(chunk_len=128)[0])
+        assert abs(ll_tp - ref) <= RTOL_LL * abs(ref), (ll_tp, ref)
+        fac = eng.stored_factor(chunk_len=128)
+    finally:
+        lib.gf_set_pipelined(old)
+    import torch
+    c, a, U, V = util.oracle_matrices(prob, __import__("oracle.seq", fromlist=["seq"]))
+    d_ref, W_ref, _ = cref.factor(t, c, a, U, V)
+    Y = np.random.default_rng(5).normal(size=(len(t), 3))
+    ref_ai = cref.solve_upper(t, c, U, W_ref, cref.solve_lower(t, c, U, W_ref, Y) / d_ref[:, None])
+    got = fac.apply_inverse(torch.as_tensor(Y).cuda().reshape(1, len(t), 3))[0].cpu().numpy()
+    assert _relmax(got, ref_ai) < TOL_VEC
+
+
 TP_CASES = [
     ("solar", dict(J=6, N=3000), 256),
     ("solar", dict(J=30, N=5000), 512),
