@@ -34,6 +34,9 @@ def timeit(fn, reps=3):
 
 dt, ll0 = timeit(eng.log_likelihood, reps=1)
 print(f"N={N} J={J} B={B} sequential streamed sweep: {dt*1e3:9.2f} ms  ll={float(ll0[0]):.12e}")
+dt, ll = timeit(lambda: eng.log_likelihood_time_parallel())
+print(f"  time-parallel, default chunking ({eng._tp_chunking(None)[0]} rows x {eng._tp_chunking(None)[1]}): "
+      f"{dt*1e3:9.2f} ms  ({B/dt:8.1f} evals/s)")
 for L in [int(x) for x in os.environ.get("TP_CHUNKS", "32768,16384,8192,4096,2048,1024,512").split(",")]:
     if L >= N:
         continue
