@@ -66,13 +66,6 @@ __device__ __forceinline__ double read_lane(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
-// Tell the compiler a value is wave-uniform (it then lives in SGPRs and branches on it are scalar)
-__device__ __forceinline__ int64_t uni64(int64_t v) {
-    const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL));
-    const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
-    return ((int64_t)hi << 32) | (unsigned int)lo;
-}
-
 // Fixed-shape tree sum over the 64 lanes, result broadcast to every lane (deterministic).
 __device__ __forceinline__ double wave_sum(double v) {
     v += dpp_get<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
@@ -898,7 +891,6 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
           double *__restrict__ Ut_out, double *__restrict__ Wt_out, double *__restrict__ de_out,
           double *__restrict__ S_state, double *__restrict__ F_state,
           int32_t *__restrict__ info) {
-    const int block = block_sub & 0xff;     // | (generator sub-anchor period << 8)
     const int lane = threadIdx.x;
     const int b = blockIdx.x;                       // state slot = problem * nch + chunk
     if (info[b] != 0) return;
@@ -1117,7 +1109,6 @@ k_factor5(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
           double *__restrict__ Ut_out, double *__restrict__ Wt_out, double *__restrict__ de_out,
           double *__restrict__ S_state, double *__restrict__ F_state,
           int32_t *__restrict__ info) {
-    const int block = block_sub & 0xff;     // | (generator sub-anchor period << 8)
     const int lane = threadIdx.x;
     const int b = blockIdx.x;                       // state slot = problem * nch + chunk
     if (info[b] != 0) return;
@@ -1709,7 +1700,6 @@ k_phi(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int
       const double *__restrict__ t_, const int64_t t_bs,
       const double *__restrict__ dbar_, const double *__restrict__ rbar_,
       double *__restrict__ h_out, double *__restrict__ Phi_out) {
-    const int block = block_sub & 0xff;     // | (generator sub-anchor period << 8)
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     const int pr = b / nch, ch = b - pr * nch;
@@ -2406,7 +2396,7 @@ __global__ void __launch_bounds__(64) k_linR(const LinArgs A) {
 //   matmul : F_{c+1} = Fbar_c + D_c o F_c            (D = product of the chunk's reset decays)
 // One workgroup of 64 x RT threads per (problem, RHS tile); Phi is stored [j][i].
 __global__ void __launch_bounds__(64)
-k_lincombine(const int nch, const int W, const int mode, const int R,
+k_lincombine(const int nch, const int /*W*/, const int mode, const int R,
              const double *__restrict__ Phi_, const double *__restrict__ Dch_,
              double *__restrict__ F_state) {
     // one wave per (problem, right-hand side): the scan is sequential over the chunks only.
