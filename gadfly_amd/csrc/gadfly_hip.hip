@@ -2339,14 +2339,30 @@ __global__ void __launch_bounds__(64) k_linR(const LinArgs A) {
     double carry = 0.0;
     s_a[lane] = 0.0;                                // pending push row (w~_{n-1} or u~_{n+1})
     double de_cross = -1.0;
+    // everything a row needs from memory is fetched three rows ahead (the loads used to sit at
+    // their point of use: one full memory round trip per row, 5 us)
+    struct RowIn { double y, pull, push, e, d; };
+    auto fetch = [&](int64_t s) {
+        if (s > rows - 1) s = rows - 1;
+        const int64_t n = up ? (rows - 1 - s) : s;
+        RowIn q;
+        q.y = rok ? Yg[(size_t)n * R + r] : 0.0;
+        q.pull = up ? Wg[(size_t)n * 64] : Ug[(size_t)n * 64];
+        q.push = up ? Ug[(size_t)n * 64] : Wg[(size_t)n * 64];
+        q.e = eg[n];
+        q.d = A.scale ? dg[n] : 1.0;
+        return q;
+    };
+    RowIn p0 = fetch(0), p1 = fetch(1), p2 = fetch(2);
     for (int64_t s = 0; s < rows; ++s) {
         const int64_t n = up ? (rows - 1 - s) : s;
-        double yn = rok ? Yg[(size_t)n * R + r] : 0.0;
-        if (A.scale) { const double dn = dg[n]; yn = mm ? yn * sqrt(dn) : yn / dn; }
-        const double de = up ? de_cross : eg[n];    // decay to apply before this row's dot
-        const double pullv = up ? Wg[(size_t)n * 64] : Ug[(size_t)n * 64];
+        const RowIn cur = p0;
+        p0 = p1; p1 = p2; p2 = fetch(s + 3);
+        double yn = cur.y;
+        if (A.scale) yn = mm ? yn * sqrt(cur.d) : yn / cur.d;
+        const double de = up ? de_cross : cur.e;    // decay to apply before this row's dot
         wave_lds_fence();
-        s_b[lane] = pullv;
+        s_b[lane] = cur.pull;
         const bool dec = de >= 0.0;
         if (dec) s_e[lane] = fm_exp(-cj * de);
         wave_lds_fence();
@@ -2372,10 +2388,9 @@ __global__ void __launch_bounds__(64) k_linR(const LinArgs A) {
         const double zn = mm ? (yn + dot) : (yn - dot);
         if (A.store && rok) Zg[(size_t)n * R + r] = zn;
         carry = mm ? yn : zn;
-        const double pushv = up ? Ug[(size_t)n * 64] : Wg[(size_t)n * 64];
         wave_lds_fence();
-        s_a[lane] = pushv;
-        if (up) de_cross = eg[n];
+        s_a[lane] = cur.push;
+        if (up) de_cross = cur.e;
     }
     wave_lds_fence();
     const bool dec = up && de_cross >= 0.0;
