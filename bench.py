@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--overlap", action="store_true",
                     help="build tile k+1 on a side stream during the sweep of tile k (slower: "
                          "the build waves displace one of the two sweep waves per SIMD)")
-    ap.add_argument("--kernel", choices=["auto", "blocked", "fused", "pipelined"], default="auto",
+    ap.add_argument("--kernel", choices=["auto", "blocked", "fused", "pipelined", "split"], default="auto",
                     help="sweep kernel: blocked = k_factor4 (FP64 MFMA, rank-16 blocks), "
                          "fused = k_factor3 (vector FMA); auto takes blocked when supported")
     ap.add_argument("--generator-period", type=int, default=0,
@@ -117,7 +117,9 @@ def main():
     eng = ev.engine
     if args.kernel == "pipelined":
         eng.lib.gf_set_pipelined(1)
-    if args.kernel in ("fused", "pipelined"):
+    elif args.kernel == "split":
+        eng.lib.gf_set_pipelined(2)
+    if args.kernel in ("fused", "pipelined", "split"):
         eng.allow_blocked = False
     elif args.kernel == "blocked" and not eng._blocked_ok():
         raise SystemExit("--kernel blocked: not supported for this term structure / cadence")
@@ -211,6 +213,8 @@ def main():
                                   "on v_mfma_f64_16x16x4)",
                        "fused": "k_factor5 (fused build + factor + forward solve, post work of row n-1 "
                                 "interleaved with sweep n)" if args.kernel == "pipelined" else
+                                "k_factor6 (fused build + factor + forward solve, split sweep: the "
+                                "fold runs under the row's chain)" if args.kernel == "split" else
                                 "k_factor3 (fused build + factor + forward solve)"}.get(
                            getattr(eng, "kernel_used", ""), "k_factor"),
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

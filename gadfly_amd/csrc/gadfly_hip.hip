@@ -1005,6 +1005,244 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
 }
 
 // ------------------------------------------------------------------------------------
+// k_factor6: k_factor3 with the sweep SPLIT so that half of it runs under the row's serial chain.
+//
+// k_factor3's sweep of row n folds the update of row n-1 and takes the mat-vec in one pass, so it
+// waits for q_{n-1} and the chain (reduction, reciprocal) waits for it.  Here the two halves are
+// separate passes over T:
+//     A_n :  acc   = T u~_n                      (T still lacks the update of row n-1: no q needed)
+//            tmp_n = acc + q_{n-1} sigma_{n-1} ,  sigma_{n-1} = r_{n-1} . u~_n
+//     B_n :  T    += r_{n-1} q_{n-1}^T           (the fold; nothing in row n's chain reads it)
+// B_n's 64 FMAs are issued with row n's chain (d_n, z_n, 1/d_n, q_n, sigma_n) in stages between
+// its batches; the chain then costs latency only where it is longer than the fold.  Same flops as
+// k_factor3, one more reduction (sigma, interleaved with the first), one live update as before:
+// no parking, no extra LDS state beyond a second r buffer.  Same arguments and results.
+// Measured: 13.3 ms per tile against 10.0 -- k_factor3's chain already hides
+// under the row generator, which is left exposed here, and the kernel is VALU-issue-bound, so the
+// second reduction's ~30 instructions cost more than the overlap returns.  Experimental switch
+// (gf_set_pipelined(2)), parity-tested, not the default.
+// ------------------------------------------------------------------------------------
+constexpr int SP_BR = 4, SP_AHEAD = 1;
+
+template <int ROWS>
+__device__ __forceinline__ void split_preload(double (&rb)[SP_AHEAD + 1][SP_BR], const double *x) {
+#pragma unroll
+    for (int k = 0; k < SP_AHEAD && k < ROWS / SP_BR; ++k) {
+#pragma unroll
+        for (int r = 0; r < SP_BR; ++r) rb[k][r] = x[k * SP_BR + r];
+    }
+}
+
+template <int ROWS>
+__device__ __forceinline__ double split_matvec(const double (&T)[ROWS], double (&rb)[SP_AHEAD + 1][SP_BR],
+                                               const double *xa) {
+    constexpr int BR = SP_BR, NB = ROWS / BR, AHEAD = SP_AHEAD;
+    static_assert(ROWS % BR == 0, "ROWS must be a multiple of 4");
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        if (k + AHEAD < NB) {
+#pragma unroll
+            for (int r = 0; r < BR; ++r) rb[(k + AHEAD) % (AHEAD + 1)][r] = xa[(k + AHEAD) * BR + r];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int c = k % (AHEAD + 1);
+        acc0 = fma(rb[c][0], T[k * BR + 0], acc0);
+        acc1 = fma(rb[c][1], T[k * BR + 1], acc1);
+        acc2 = fma(rb[c][2], T[k * BR + 2], acc2);
+        acc3 = fma(rb[c][3], T[k * BR + 3], acc3);
+        asm volatile("" : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return (acc0 + acc2) + (acc1 + acc3);
+}
+
+template <class F, int... K>
+__device__ __forceinline__ void static_for(F &&f, std::integer_sequence<int, K...>) {
+    (f(std::integral_constant<int, K>{}), ...);
+}
+
+// T_i += xw_i q, hook(k) issued after batch k (the row's chain, one stage per batch)
+template <int ROWS, class Hook>
+__device__ __forceinline__ void split_fold(double (&T)[ROWS], double (&rb)[SP_AHEAD + 1][SP_BR],
+                                           const double *xw, const double q, Hook &&hook) {
+    constexpr int BR = SP_BR, NB = ROWS / BR, AHEAD = SP_AHEAD;
+    static_for([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k + AHEAD < NB) {
+#pragma unroll
+            for (int r = 0; r < BR; ++r) rb[(k + AHEAD) % (AHEAD + 1)][r] = xw[(k + AHEAD) * BR + r];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int c = k % (AHEAD + 1);
+#pragma unroll
+        for (int r = 0; r < BR; ++r) T[k * BR + r] = fma(rb[c][r], q, T[k * BR + r]);
+        // pin the batch here: LLVM otherwise sinks the whole fold below the pivot test that follows
+        // the sweep (T is dead on the failure path) and keeps all 64 row operands alive
+        asm volatile("" : "+v"(T[k * BR + 0]), "+v"(T[k * BR + 1]), "+v"(T[k * BR + 2]), "+v"(T[k * BR + 3]));
+        hook(kc);
+        __builtin_amdgcn_sched_barrier(0);
+    }, std::make_integer_sequence<int, NB>{});
+}
+
+template <int ROWS>
+__global__ void __launch_bounds__(64, 2)
+k_factor6(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int nch,
+          const int Jr, const int Jc, const int block_sub, const double gap,
+          const double *__restrict__ ar_, const double *__restrict__ cr_,
+          const double *__restrict__ ac_, const double *__restrict__ bc_,
+          const double *__restrict__ cc_, const double *__restrict__ dc_,
+          const double *__restrict__ diag_add_, const double *__restrict__ cmax_,
+          const double *__restrict__ t_, const int64_t t_bs,
+          const double *__restrict__ diag_, const int64_t diag_bs,
+          const double *__restrict__ y_, const int64_t y_bs,
+          double *__restrict__ d_, double *__restrict__ z_, double *__restrict__ r_out,
+          double *__restrict__ Ut_out, double *__restrict__ Wt_out, double *__restrict__ de_out,
+          double *__restrict__ S_state, double *__restrict__ F_state,
+          int32_t *__restrict__ info) {
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;                       // state slot = problem * nch + chunk
+    if (info[b] != 0) return;
+    const int pr = b / nch, ch = b - pr * nch;
+    const int64_t c0 = (int64_t)ch * chunk_len;     // first row of the chunk within this call
+    const int64_t rows = (N - c0 < chunk_len) ? (N - c0) : chunk_len;
+    const int64_t g0 = n_first + c0;                // global index of the chunk's first row
+    const size_t pb = (size_t)pr * N + c0;
+    const double *__restrict__ tg = t_ + (size_t)pr * t_bs + g0;
+    const double *__restrict__ yg = y_ + (size_t)pr * y_bs + g0;
+    const double *__restrict__ gg = diag_ ? diag_ + (size_t)pr * diag_bs + g0 : nullptr;
+    double *__restrict__ dg = d_ + pb;
+    double *__restrict__ zg = z_ + pb;
+    double *__restrict__ rg = r_out ? r_out + pb * 64 + lane : nullptr;
+    double *__restrict__ ug = Ut_out ? Ut_out + pb * 64 + lane : nullptr;   // stored factor:
+    double *__restrict__ wg = Wt_out ? Wt_out + pb * 64 + lane : nullptr;   // u~, w~ = r/d rows
+    double *__restrict__ eg = de_out ? de_out + pb : nullptr;               // reset spans (-1: none)
+    double *__restrict__ Sg = S_state + (size_t)b * (64 * 64) + (size_t)lane * 64;
+    double *__restrict__ Fg = F_state + (size_t)b * 64;
+    const double diag_add = diag_add_[pr];
+
+    RowGen G;
+    G.init(lane, pr, Jr, Jc, block_sub, gap, ar_, cr_, ac_, bc_, cc_, dc_, cmax_, tg, g0);
+    const double cj = G.cj;
+
+    __shared__ __attribute__((aligned(16))) double s_w[2][64];   // r_{n-1} | r_n (pending update, row form)
+    __shared__ __attribute__((aligned(16))) double s_u[64];      // u~_n
+    __shared__ __attribute__((aligned(16))) double s_e[64];      // block decay E at reset rows
+    const bool fl = lane == 63;     // pad lane carrying the forward solve (W < 64)
+
+    double T[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) T[i] = fl ? Fg[i] : Sg[i];
+    double q = 0.0, sg = 0.0;       // q_{n-1} (lane form; lane 63: z/d), sigma_{n-1}
+    int32_t fail = 0;
+
+    double t_n1 = tg[1], t_n2 = tg[2];
+    double y_n = yg[0], y_n1 = yg[1], y_n2 = yg[2];
+    double g_n = gg ? gg[0] : 0.0, g_n1 = gg ? gg[1] : 0.0, g_n2 = gg ? gg[2] : 0.0;
+    double ut, vt, de;
+    bool rst;
+    G.next(tg[0], g0, ut, vt, rst, de);
+
+    double rb[SP_AHEAD + 1][SP_BR];
+    double *swc = s_w[0], *swn = s_w[1];    // r of the pending update | r of this row
+    swc[lane] = 0.0;
+    s_u[lane] = ut;
+    wave_lds_fence();
+    split_preload<ROWS>(rb, s_u);
+
+    for (int64_t n = 0; n < rows; ++n) {
+        const double a_n = g_n + diag_add, yy = y_n;
+        const double ut_c = ut, vt_c = vt;
+        if (eg && lane == 0) eg[n] = rst ? de : -1.0;
+        if (rst) {                          // wave-uniform: fold the pending update, then decay
+            const double el = fm_exp(-cj * de);     // pad lanes: cj = 0 -> 1
+            s_e[lane] = el;
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < ROWS / 4; ++k) {
+                double w4[4], e4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { w4[r] = swc[4 * k + r]; e4[r] = s_e[4 * k + r]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T[4 * k + r] = fma(w4[r], q, T[4 * k + r]) * (e4[r] * el);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            q = 0.0;
+            sg = 0.0;
+        }
+        __builtin_amdgcn_s_setprio(0);
+        const double acc = split_matvec<ROWS>(T, rb, s_u);
+        __builtin_amdgcn_s_setprio(GF_CHAIN_PRIO);
+        const double tmp = fma(q, sg, acc);
+        const double r = fl ? 0.0 : (vt_c - tmp);
+        G.next(t_n1, g0 + n + 1, ut, vt, rst, de);
+        t_n1 = t_n2; y_n = y_n1; y_n1 = y_n2; g_n = g_n1; g_n1 = g_n2;
+        t_n2 = tg[n + 3];
+        y_n2 = yg[n + 3];
+        g_n2 = gg ? gg[n + 3] : 0.0;
+        wave_lds_fence();
+        swn[lane] = r;
+        s_u[lane] = ut;
+        wave_lds_fence();
+        split_preload<ROWS>(rb, swc);
+        // row n's chain, one stage per batch of the fold (everything the fold does not need is
+        // finished or stored before it: the fold block is the register-pressure peak)
+        double x = ut_c * tmp, y = r * ut, dn = 1.0, inv = 1.0, qn = 0.0, sgn = 0.0;
+        const double zn = yy - read_lane(tmp, 63);
+        const double rz = fl ? zn : r;
+        if (rg) rg[(size_t)n * 64] = r;             // r~ rows for k_phi (chunk mode)
+        if (ug) ug[(size_t)n * 64] = ut_c;
+        constexpr int NS = 11, NB = ROWS / SP_BR;
+        auto chain = [&](auto sc) {
+            constexpr int st = decltype(sc)::value;
+            if constexpr (st == 0) { x += dpp_get<0xB1, 0xf>(x); y += dpp_get<0xB1, 0xf>(y); }
+            else if constexpr (st == 1) { x += dpp_get<0x4E, 0xf>(x); y += dpp_get<0x4E, 0xf>(y); }
+            else if constexpr (st == 2) { x += dpp_get<0x141, 0xf>(x); y += dpp_get<0x141, 0xf>(y); }
+            else if constexpr (st == 3) { x += dpp_get<0x140, 0xf>(x); y += dpp_get<0x140, 0xf>(y); }
+            else if constexpr (st == 4) { x += dpp_get<0x142, 0xa>(x); y += dpp_get<0x142, 0xa>(y); }
+            else if constexpr (st == 5) { x += dpp_get<0x143, 0xc>(x); y += dpp_get<0x143, 0xc>(y); }
+            else if constexpr (st == 6) { dn = a_n - read_lane(x, 63); sgn = read_lane(y, 63); }
+            // (pinned like the fold's batches: these would otherwise sink below the pivot test)
+            else if constexpr (st == 7) { inv = __builtin_amdgcn_rcp(dn); asm volatile("" : "+v"(inv)); }
+            else if constexpr (st == 8) { inv = fma(fma(-dn, inv, 1.0), inv, inv); asm volatile("" : "+v"(inv)); }
+            else if constexpr (st == 9) { inv = fma(fma(-dn, inv, 1.0), inv, inv); asm volatile("" : "+v"(inv)); }
+            else if constexpr (st == 10) { qn = rz * inv; asm volatile("" : "+v"(qn)); }
+        };
+        split_fold<ROWS>(T, rb, swc, q, [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            // one stage per batch from the first batch on; narrow problems (fewer batches than
+            // stages) spread the stages evenly
+            constexpr int lo = (NB >= NS) ? (k < NS ? k : NS) : k * NS / NB;
+            constexpr int hi = (NB >= NS) ? (k < NS ? k + 1 : NS) : (k + 1) * NS / NB;
+            static_for([&](auto jc) { chain(std::integral_constant<int, lo + decltype(jc)::value>{}); },
+                       std::make_integer_sequence<int, hi - lo>{});
+        });
+        split_preload<ROWS>(rb, s_u);
+        if (!(dn > 0.0)) {
+            const int64_t gf = g0 + n + 1;
+            fail = (int32_t)(gf > 0x7fffffff ? 0x7fffffff : gf);
+            break;
+        }
+        q = qn;
+        sg = sgn;
+        { double *t = swc; swc = swn; swn = t; }
+        if (wg) wg[(size_t)n * 64] = fl ? 0.0 : qn;
+        if (lane == 0) { dg[n] = dn; zg[n] = zn; }
+    }
+    if (fail) {
+        if (lane == 0) info[b] = fail;
+        return;
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        const double v = fma(swc[i], q, T[i]);
+        if (fl) Fg[i] = v; else Sg[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // k_factor5: k_factor3 with the per-row serial chain taken off the sweep's critical path.
 //
 // In k_factor3 the sweep of row n+1 folds the rank-1 update of row n, so it cannot start before
@@ -1024,11 +1262,6 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
 // both pending updates, decay) and restart it.  Same arguments, state hand-off and results as
 // k_factor3, chunk mode included.
 // ------------------------------------------------------------------------------------
-template <class F, int... K>
-__device__ __forceinline__ void static_for(F &&f, std::integer_sequence<int, K...>) {
-    (f(std::integral_constant<int, K>{}), ...);
-}
-
 //   MODE 0:  T_i += xw_i q ;  acc += xa_i T_i     (fold + mat-vec; hook(k) after batch k)
 //   MODE 1:  T_i  = (T_i + xw_i q) (xa_i el)      (fold + decay)
 //   MODE 2:  T_i += xw_i q                         (fold only)
@@ -3220,7 +3453,7 @@ int gf_factor_scaled(int B, int64_t N, int64_t n_first, int W, int ld, const dou
 }
 
 #define GF_F3_ARGS dim3(B * nch), dim3(64), 0, st, N, n_first, chunk_len, nch, Jr, Jc, (block | (g_gen_period << 8)), gap, ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out, Ut_out, Wt_out, de_out, S_state, F_state, info
-#define GF_F3_CASE(R) case R: if (!g_pipelined) hipLaunchKernelGGL((k_factor3<R>), GF_F3_ARGS); else if (r_out || Ut_out || de_out) hipLaunchKernelGGL((k_factor5<R, true>), GF_F3_ARGS); else hipLaunchKernelGGL((k_factor5<R, false>), GF_F3_ARGS); break;
+#define GF_F3_CASE(R) case R: if (!g_pipelined) hipLaunchKernelGGL((k_factor3<R>), GF_F3_ARGS); else if (g_pipelined == 2) hipLaunchKernelGGL((k_factor6<R>), GF_F3_ARGS); else if (r_out || Ut_out || de_out) hipLaunchKernelGGL((k_factor5<R, true>), GF_F3_ARGS); else hipLaunchKernelGGL((k_factor5<R, false>), GF_F3_ARGS); break;
 static int g_gen_period = 4;        // gf_set_generator_period
 static int g_pipelined = 0;         // gf_set_pipelined(1) selects the pipelined k_factor5 (experimental, slower: DESIGN.md 4.2)
 
@@ -3267,7 +3500,7 @@ int gf_set_generator_period(int period) {
 
 int gf_set_pipelined(int on) {
     const int old = g_pipelined;
-    g_pipelined = on ? 1 : 0;
+    g_pipelined = (on == 2) ? 2 : (on ? 1 : 0);
     return old;
 }
 

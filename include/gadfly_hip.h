@@ -158,9 +158,11 @@ int gf_set_generator_period(int period);
 /*
  * gf_set_pipelined(1) makes gf_loglike_fused / gf_chunk_sweep run the software-pipelined sweep
  * (k_factor5: the reductions, reciprocal and r, q of row n-1 are issued between the FMA batches of
- * sweep n).  Experimental and currently slower than the default k_factor3 (DESIGN.md 4.2 has the
- * counters); kept, parity-tested, for A/B measurements.  Process-wide switch, returns the
- * previous setting; results agree to rounding.
+ * sweep n); gf_set_pipelined(2) the split sweep (k_factor6: mat-vec with the not-yet-updated T,
+ * then the fold with the row's reduction / reciprocal chain issued between its batches).  Both are
+ * experimental and slower than the default k_factor3 (DESIGN.md 2.1b has the measurements); kept,
+ * parity-tested, for A/B measurements.  Process-wide switch (0 = default), returns the previous
+ * setting; results agree to rounding.
  */
 int gf_set_pipelined(int on);
 

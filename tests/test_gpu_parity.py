@@ -331,9 +331,10 @@ def test_streaming_irregular_cadence_fused(hip):
 
 @pytest.mark.parametrize("case", [STREAM_CASES[0], STREAM_CASES[1], STREAM_CASES[2], STREAM_CASES[6]],
                          ids=["solar6", "solar20jitter", "solar30gaps", "overdamped"])
-def test_pipelined_variant(hip, case):
-    """The experimental software-pipelined sweep (gf_set_pipelined(1), k_factor5) gives the results
-    of the default kernel: streamed tiles with state hand-off, and the time-parallel evaluation
+@pytest.mark.parametrize("mode", [1, 2], ids=["pipelined", "split"])
+def test_pipelined_variant(hip, case, mode):
+    """The experimental sweeps (gf_set_pipelined(1): software-pipelined k_factor5; (2): split-sweep
+    k_factor6) give the results of the default kernel: streamed tiles with state hand-off, and the time-parallel evaluation
     (chunk mode with the extra row stores)."""
     from gadfly_amd.engine import StreamingBatch
     from oracle import cref
@@ -344,7 +345,7 @@ def test_pipelined_variant(hip, case):
     ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y)
     assert info == 0
     lib = hip.load()
-    old = lib.gf_set_pipelined(1)
+    old = lib.gf_set_pipelined(mode)
     try:
         eng = StreamingBatch([co], t, y, diag=prob["diag_user"], tile_rows=tile)
         assert eng._fused_ok()
