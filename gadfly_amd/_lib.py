@@ -26,6 +26,7 @@ _lib = None
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
 _int = ctypes.c_int
+_dbl = ctypes.c_double
 
 # name -> (restype, argtypes); must list every symbol include/gadfly_hip.h declares
 SIGNATURES = {
@@ -65,6 +66,8 @@ SIGNATURES = {
     "gf_loglike_finish": (_int, [_int, _i64] + [_vp] * 4 + [_vp]),
     "gf_solve": (_int, [_int, _int, _i64, _int, _int, _int] + [_vp] * 6 + [_vp]),
     "gf_cross_covariance": (_int, [_int, _i64, _int, _int, _int] + [_vp] * 6 + [_vp, _i64, _vp, _i64, _vp, _vp]),
+    "gf_psd_power": (_int, [_int, _i64, _i64, _dbl, _vp, _vp, _vp]),
+    "gf_psd_bin": (_int, [_int, _i64, _int, _vp, _vp, _vp, _dbl, _vp, _vp, _vp]),
     "gf_general_matmul_work": (_i64, [_int, _i64, _i64, _int]),
     "gf_general_matmul": (_int, [_int, _i64, _i64, _int, _int, _vp,
                                  _vp, _i64, _vp, _vp,

@@ -3303,6 +3303,82 @@ __global__ void k_add2(int64_t M, const double *work, double *mu) {
 }
 
 // ------------------------------------------------------------------------------------
+// Power spectra of light curves / prior draws and their binning: the step
+// after `sample` in the reference's own hot-path test (gadfly/tests/test_core.py:29-34).  The
+// transform itself is hipFFT's (a plain library FFT); these two kernels are what the reference
+// does around it in numpy / scipy.binned_statistic.
+// ------------------------------------------------------------------------------------
+// power[r][k] = |X[r][first + k]|^2 * norm      (PowerSpectrum._fft, psd.py:566-587)
+// X interleaved complex [R][M]; re*re + im*im without contraction, as numpy forms it.
+__global__ void __launch_bounds__(256)
+k_psd_power(const int64_t M, const int64_t Mout, const int64_t first, const double norm,
+            const double2 *__restrict__ spec, double *__restrict__ power) {
+    const size_t r = blockIdx.y;
+    const double2 *X = spec + r * (size_t)M + first;
+    double *P = power + r * (size_t)Mout;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < Mout; k += (int64_t)gridDim.x * 256) {
+        const double2 v = X[k];
+        P[k] = __dadd_rn(__dmul_rn(v.x, v.x), __dmul_rn(v.y, v.y)) * norm;
+    }
+}
+
+// sum over the 256 threads of a workgroup, result in every thread (fixed shape: deterministic)
+__device__ __forceinline__ double wg_sum256(double v, double *red) {
+    v = wave_sum(v);
+    __syncthreads();                                // red may still be read from the last call
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// One workgroup per (bin, series): the bin's points are the contiguous range [start[b], start[b+1])
+// of the ascending frequency axis x.  bin_power_spectrum's two statistics (psd.py:186-227):
+//   stat = trapz(y, x) / (x_last - x_first)                          (one point: y itself)
+//   err  = std(y) / sqrt(n) * mean(x) / (x_last - x_first) / constant (one point: y itself)
+// and NaN for an empty bin (scipy.stats.binned_statistic's value for a failing statistic).
+__global__ void __launch_bounds__(256)
+k_psd_bin(const int64_t M, const int nb, const double *__restrict__ x,
+          const double *__restrict__ power, const int64_t *__restrict__ start,
+          const double constant, double *__restrict__ stat, double *__restrict__ err) {
+    __shared__ double red[4];
+    const int b = blockIdx.x;
+    const size_t r = blockIdx.y;
+    const int64_t s = start[b], e = start[b + 1], n = e - s;
+    const double *y = power + r * (size_t)M;
+    double *st = stat + r * (size_t)nb + b, *er = err + r * (size_t)nb + b;
+    if (n <= 0) {
+        if (threadIdx.x == 0) { *st = __builtin_nan(""); *er = __builtin_nan(""); }
+        return;
+    }
+    const double span = x[e - 1] - x[s];
+    if (n == 1 || !(span > 0.0)) {
+        if (threadIdx.x == 0) { *st = y[s]; *er = y[s]; }
+        return;
+    }
+    double tz = 0.0, sy = 0.0, sx = 0.0;
+    for (int64_t i = s + threadIdx.x; i < e; i += 256) {
+        const double yi = y[i], xi = x[i];
+        sy += yi;
+        sx += xi;
+        if (i + 1 < e) tz += (x[i + 1] - xi) * (yi + y[i + 1]) * 0.5;
+    }
+    tz = wg_sum256(tz, red);
+    sy = wg_sum256(sy, red);
+    sx = wg_sum256(sx, red);
+    const double mean = sy / (double)n;
+    double ss = 0.0;
+    for (int64_t i = s + threadIdx.x; i < e; i += 256) {
+        const double dv = y[i] - mean;
+        ss = fma(dv, dv, ss);
+    }
+    ss = wg_sum256(ss, red);
+    if (threadIdx.x == 0) {
+        *st = tz / span;
+        *er = sqrt(ss / (double)n) / sqrt((double)n) * (sx / (double)n) / span / constant;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // dispatch helpers
 // ------------------------------------------------------------------------------------
 template <int RB, int CT, int NW>
@@ -3757,6 +3833,29 @@ int gf_cross_covariance(int B, int64_t N, int R, int Jr, int Jc,
     hipLaunchKernelGGL(k_cross, dim3((unsigned)blocks, B), dim3(256), lds, (hipStream_t)stream, N, R, Jr, Jc,
                        ar, cr, ac, bc, cc, dc, t, t_bs, ts, ts_bs, out);
     return check_launch("gf_cross_covariance");
+}
+
+int gf_psd_power(int R, int64_t M, int64_t first, double norm, const double *spec,
+                 double *power, void *stream) {
+    if (R < 1 || M < 1 || first < 0 || first >= M) return set_err("gf_psd_power: bad shape (M=%s%lld, first=%lld)", "", M, first);
+    if (!spec || !power) return set_err("gf_psd_power: null pointer%s", "");
+    if (R > 65535) return set_err("gf_psd_power: more than 65535 series%s", "");
+    const int64_t Mout = M - first;
+    int64_t blocks = (Mout + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_psd_power, dim3((unsigned)blocks, R), dim3(256), 0, (hipStream_t)stream, M, Mout,
+                       first, norm, (const double2 *)spec, power);
+    return check_launch("gf_psd_power");
+}
+
+int gf_psd_bin(int R, int64_t M, int nb, const double *x, const double *power,
+               const int64_t *start, double constant, double *stat, double *err, void *stream) {
+    if (R < 1 || M < 1 || nb < 1) return set_err("gf_psd_bin: bad shape (M=%s%lld, bins=%lld)", "", M, (int64_t)nb);
+    if (!x || !power || !start || !stat || !err) return set_err("gf_psd_bin: null pointer%s", "");
+    if (R > 65535) return set_err("gf_psd_bin: more than 65535 series%s", "");
+    hipLaunchKernelGGL(k_psd_bin, dim3(nb, R), dim3(256), 0, (hipStream_t)stream, M, nb, x, power, start,
+                       constant, stat, err);
+    return check_launch("gf_psd_bin");
 }
 
 // chunking of the conditional-mean sweeps: ~2048 waves over (problem, direction, chunk), chunks of

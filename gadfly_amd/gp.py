@@ -450,6 +450,20 @@ class GaussianProcess:
             return self._ppm_to_flux(result)
         return result
 
+    def sample_device(self, *, size=None, include_mean=True):
+        """:meth:`sample` with the draws left on the GPU: a float64 tensor of shape (N,) or
+        (size, N) [ppm], same normal vectors (numpy's legacy global RNG), same arithmetic and
+        mean-subtraction quirk -- for pipelines that continue on the device
+        (:meth:`gadfly_amd.PowerSpectrum.from_flux`).  Extension; not in the reference."""
+        if self._t is None:
+            raise RuntimeError("The process must be initialized with compute")
+        n = np.random.randn(self._size) if size is None else np.random.randn(self._size, size)
+        Z = self._engine.dot_tril(self._to_device(n).reshape(1, self._size, -1))
+        result = Z.reshape(n.shape).T.contiguous() if n.ndim == 2 else Z.reshape(-1)
+        if include_mean:
+            result = result + self._to_device(np.broadcast_to(self._mean_value, (self._size,)).copy())
+        return result - (result.mean(dim=0) if result.ndim == 2 else result.mean())
+
     def condition(self, y, t=None, include_mean=True, kernel=None,
                   return_quantity=False):
         """Condition the GP on observations ``y`` (reference gp.py:206-239)."""

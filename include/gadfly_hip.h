@@ -295,6 +295,29 @@ int gf_cross_covariance(int B, int64_t N, int R, int Jr, int Jc,
                         double *out, void *stream);
 
 /*
+ * Power spectral density of R evenly sampled series from their one-sided FFT (hipFFT's rfft,
+ * interleaved complex [R][M], M = N/2 + 1): replaces the numpy expression of
+ * PowerSpectrum._fft (gadfly/psd.py:566-587),
+ *   power[r][k] = (re^2 + im^2)(spec[r][first + k]) * norm,   norm = d / sqrt(2 pi) / N,
+ * power is [R][M - first]; first = 1 drops the zero frequency (include_zero_freq=False, psd.py:559-561).
+ */
+int gf_psd_power(int R, int64_t M, int64_t first, double norm, const double *spec,
+                 double *power, void *stream);
+
+/*
+ * Binned power spectrum: replaces the two scipy.stats.binned_statistic passes of
+ * bin_power_spectrum (gadfly/psd.py:229-300) with spectral_binning / spectral_binning_err
+ * (psd.py:186-227) as statistics.  x [M] is the ascending frequency axis the bins were drawn on
+ * (log10 frequency by default), power [R][M]; bin b holds the points start[b] <= i < start[b+1]
+ * (start [nb+1], int64, ascending: the host applies binned_statistic's edge rules).  Per bin and
+ * series: stat = trapz(power, x) / span, err = std(power) / sqrt(n) * mean(x) / span / constant,
+ * span = x_last - x_first; a one-point (or zero-span) bin gives the point itself for both, an
+ * empty bin NaN.  stat, err are [R][nb].
+ */
+int gf_psd_bin(int R, int64_t M, int nb, const double *x, const double *power,
+               const int64_t *start, double constant, double *stat, double *err, void *stream);
+
+/*
  * Conditional mean at M new (sorted) times t1 given alpha = K^-1 (y - mean) at the N
  * observed times t2:
  *   mu[m] = sum_{t2[n] <= t1[m]} (U1[m] o e^{-c (t1[m]-t2[n])}) . V2[n] alpha[n]

@@ -1,0 +1,81 @@
+"""
+CPU tests of the power-spectrum restatement (oracle/psd_ref.py) and of the host-side bin logic of
+gadfly_amd.psd: the reference formulation (value look-ups inside scipy.stats.binned_statistic
+callables, /root/reference/gadfly/psd.py:186-300) against the index-range formulation the device
+kernel implements, including binned_statistic's edge rules.
+"""
+import numpy as np
+import pytest
+
+from oracle import psd_ref
+
+
+def _series(n, seed):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) * 60e-6
+    return (300 * np.sin(2 * np.pi * 3000.0 * t) + 50 * rng.normal(size=n)
+            + np.cumsum(rng.normal(size=n))), 60e-6
+
+
+def test_fft_norm_matches_parseval():
+    """sum(power) d_freq-free check of the normalisation d / sqrt(2 pi) / N (psd.py:578-580)."""
+    flux, d = _series(4096, 1)
+    freq, power, norm = psd_ref.fft_power(flux, d, include_zero_freq=True)
+    assert norm == d / (2 * np.pi) ** 0.5 / len(flux)
+    # Parseval for the one-sided spectrum of an even-length real series
+    two_sided = 2 * power.sum() - power[0] - power[-1]
+    assert np.isclose(two_sided / norm, len(flux) * np.sum(flux ** 2), rtol=1e-12)
+    f1, p1, _ = psd_ref.fft_power(flux, d)
+    assert len(f1) == len(freq) - 1 and np.array_equal(p1, power[1:])
+
+
+@pytest.mark.parametrize("n,bins,log", [(20000, 15, True), (20000, 7, False), (5001, 40, True),
+                                         (3000, 1, True), (1 << 14, 200, True)])
+def test_range_form_equals_lookup_form(n, bins, log):
+    flux, d = _series(n, n + bins)
+    freq, power, _ = psd_ref.fft_power(flux, d)
+    c0, s0, e0 = psd_ref.bin_power_lookup(freq, power, bins=bins, log=log, constant=3)
+    c1, s1, e1 = psd_ref.bin_power_ranges(freq, power, bins=bins, log=log, constant=3)
+    np.testing.assert_allclose(c1, c0, rtol=1e-15)
+    np.testing.assert_allclose(s1, s0, rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(e1, e0, rtol=1e-12, equal_nan=True)
+    # many narrow log bins: some are empty (NaN), some hold a single point (the point itself)
+    if bins == 200:
+        assert np.isnan(s0).any() and np.isfinite(s0).any()
+
+
+def test_explicit_edges_and_outliers():
+    flux, d = _series(8000, 5)
+    freq, power, _ = psd_ref.fft_power(flux, d)
+    edges = np.array([0.5, 1.0, 2.0, 2.0 + 1e-9, 3.5])          # drops both tails, one empty bin
+    c0, s0, e0 = psd_ref.bin_power_lookup(freq, power, bins=edges)
+    c1, s1, e1 = psd_ref.bin_power_ranges(freq, power, bins=edges)
+    np.testing.assert_allclose(s1, s0, rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(e1, e0, rtol=1e-12, equal_nan=True)
+
+
+def test_bin_starts_match_scipy_binnumbers():
+    from scipy.stats import binned_statistic
+    from gadfly_amd.psd import _bin_starts
+    rng = np.random.default_rng(0)
+    for bins in (3, 15, 64, np.array([-1.0, 0.0, 0.25, 0.25 + 1e-7, 2.0])):
+        axis = np.sort(rng.uniform(-0.5, 1.5, 2000))
+        axis[-3:] = axis[-1]                                     # several points on the last edge
+        bs = binned_statistic(axis, axis, statistic="count", bins=bins)
+        for fn in (_bin_starts, psd_ref.bin_starts):
+            edges, start = fn(axis, bins)
+            np.testing.assert_array_equal(edges, bs.bin_edges)
+            np.testing.assert_array_equal(np.diff(start), bs.statistic.astype(int))
+            inside = (bs.binnumber >= 1) & (bs.binnumber <= len(edges) - 1)
+            assert start[0] == np.argmax(inside) and start[-1] - start[0] == inside.sum()
+
+
+def test_batch_of_series():
+    flux = np.stack([_series(6000, s)[0] for s in range(3)])
+    freq, power, _ = psd_ref.fft_power(flux, 60e-6)
+    assert power.shape == (3, 3000)
+    c, s, e = psd_ref.bin_power_ranges(freq, power, bins=12)
+    for r in range(3):
+        _, s1, e1 = psd_ref.bin_power_lookup(freq, power[r], bins=12)
+        np.testing.assert_allclose(s[r], s1, rtol=1e-12)
+        np.testing.assert_allclose(e[r], e1, rtol=1e-12)

@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Power spectra of prior draws at cfg5's size (64 draws of N = 5e5, J = 30): sample -> FFT power ->
+log bins, draws left on the GPU, next to the numpy/scipy formulation of the reference
+(gadfly/psd.py:186-300, :566-587) on the host.  Usage: python tools/psd_latency.py [N] [R] [bins]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import gadfly_amd  # noqa: E402
+from gadfly_amd.synth import solar_like_hyperparameters, uniform_times  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000
+R = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+NB = int(sys.argv[3]) if len(sys.argv) > 3 else 25
+k = gadfly_amd.StellarOscillatorKernel(solar_like_hyperparameters(30), texp=60.0)
+t = uniform_times(N, 60.0)
+gp = gadfly_amd.GaussianProcess(k, t=t, yerr=30.0)
+np.random.seed(1)
+
+
+def timed(fn, reps=3):
+    best, out = 1e30, None
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+    return best * 1e3, out
+
+
+ms_draw, draws = timed(lambda: gp.sample_device(size=R), reps=2)
+ms_psd, ps = timed(lambda: gadfly_amd.PowerSpectrum.from_flux(draws, 60e-6))
+ms_bin, binned = timed(lambda: ps.bin(NB))
+
+# kernel-only durations with HIP events on the current stream
+lib, p = gadfly_amd._lib.load(), gadfly_amd._lib.ptr
+spec = torch.view_as_real(torch.fft.rfft(draws, dim=-1)).contiguous()
+M = spec.shape[1]
+power = torch.empty((R, M - 1), dtype=torch.float64, device=draws.device)
+st = torch.cuda.current_stream().cuda_stream
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+k_ms = {}
+for name, call in (
+        ("rfft (hipFFT)", lambda: torch.fft.rfft(draws, dim=-1)),
+        ("k_psd_power", lambda: lib.gf_psd_power(R, M, 1, ps.norm, p(spec), p(power), st))):
+    call(); torch.cuda.synchronize()
+    ev[0].record(); [call() for _ in range(10)]; ev[1].record(); torch.cuda.synchronize()
+    k_ms[name] = ev[0].elapsed_time(ev[1]) / 10
+alg = 24.0 * R * (M - 1)            # read one complex, write one double per frequency and series
+
+# host formulation (one series, scaled): numpy FFT + scipy.binned_statistic with the callables
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import psd_ref  # noqa: E402  (tools/ is measurement scaffolding, like bench.py's cpu leg)
+one = draws[0].cpu().numpy()
+t0 = time.perf_counter(); f, pw, _ = psd_ref.fft_power(one, 60e-6); h_fft = time.perf_counter() - t0
+t0 = time.perf_counter(); c, s, e = psd_ref.bin_power_lookup(f, pw, bins=NB); h_bin = time.perf_counter() - t0
+dev = float(np.nanmax(np.abs(binned.power[0] - s) / np.abs(s)))
+
+print(json.dumps({
+    "workload": f"{R} draws x N={N}, J=30, {NB} log bins",
+    "sample_device_ms": ms_draw, "from_flux_ms": ms_psd, "bin_ms": ms_bin,
+    "kernel_ms": k_ms,
+    "k_psd_power_GBps": alg / (k_ms["k_psd_power"] * 1e-3) / 1e9,
+    "host_numpy_ms_per_series": {"fft_power": h_fft * 1e3, "binned_statistic": h_bin * 1e3},
+    "host_numpy_ms_all_series": (h_fft + h_bin) * 1e3 * R,
+    "binned_power_rel_dev_vs_host": dev,
+}))
