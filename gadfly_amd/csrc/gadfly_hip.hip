@@ -66,14 +66,27 @@ __device__ __forceinline__ double read_lane(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
+// A wave-uniform index made opaque to the optimiser (it stays in SGPRs, at no cost): `p[opaque(i)]`
+// with a loop-invariant per-lane pointer p is then addressed as p + i inside the branch that uses
+// it, instead of becoming one more per-lane 64-bit pointer that loop strength reduction advances
+// with a vector add on EVERY iteration, taken or not.
+__device__ __forceinline__ size_t opaque_uniform(size_t i) {
+    asm volatile("" : "+s"(i));
+    return i;
+}
+
 // Fixed-shape tree sum over the 64 lanes, result broadcast to every lane (deterministic).
 __device__ __forceinline__ double wave_sum(double v) {
     v += dpp_get<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
     v += dpp_get<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
     v += dpp_get<0x141, 0xf>(v);   // row_half_mirror
     v += dpp_get<0x140, 0xf>(v);   // row_mirror       -> every lane holds its 16-lane row sum
-    v += dpp_get<0x142, 0xa>(v);   // row_bcast15 into rows 1, 3
-    v += dpp_get<0x143, 0xc>(v);   // row_bcast31 into rows 2, 3 -> lane 63 holds the total
+    // the two broadcasts only matter for row 3 (rows 1, 3 and rows 2, 3 are what LLVM's own
+    // reductions enable with row_mask 0xa / 0xc); with all rows enabled and bound_ctrl every lane is
+    // written, so no zero-initialised destination (2 v_mov + s_nop per stage) is needed.  The other
+    // rows end up with sums nobody reads.
+    v += dpp_get<0x142, 0xf>(v);   // row_bcast15: rows 1, 3 += total of rows 0, 2
+    v += dpp_get<0x143, 0xf>(v);   // row_bcast31: row 3 += total of rows 0 + 1 -> lane 63 holds the sum
     return read_lane(v, 63);
 }
 
@@ -83,8 +96,8 @@ __device__ __forceinline__ void wave_sum2(double &a, double &b) {
     a += dpp_get<0x4E, 0xf>(a);   b += dpp_get<0x4E, 0xf>(b);
     a += dpp_get<0x141, 0xf>(a);  b += dpp_get<0x141, 0xf>(b);
     a += dpp_get<0x140, 0xf>(a);  b += dpp_get<0x140, 0xf>(b);
-    a += dpp_get<0x142, 0xa>(a);  b += dpp_get<0x142, 0xa>(b);
-    a += dpp_get<0x143, 0xc>(a);  b += dpp_get<0x143, 0xc>(b);
+    a += dpp_get<0x142, 0xf>(a);  b += dpp_get<0x142, 0xf>(b);
+    a += dpp_get<0x143, 0xf>(a);  b += dpp_get<0x143, 0xf>(b);
     a = read_lane(a, 63);
     b = read_lane(b, 63);
 }
@@ -725,8 +738,13 @@ k_factor2(const int64_t N, const int64_t n_first, const int ld, const int W,
 struct RowGen {
     // per-lane column constants: u~ = (k1 cu + k2 su), v~ = own / rho^2 with (cu, su) =
     // rho (cos, sin)(d t); lanes 2k, 2k+1 carry the same (cu, su)
-    double cj, dj, k1, k2, cmax, wmax, gap;
-    bool is_sin, colok;
+    double cj, dj, k1, k2;
+    // own-component selectors of v~ as exact 0/1 factors (pad lanes: both 0): two FMAs-worth of
+    // VALU work instead of two 64-bit selects, and no lane masks held in SGPRs
+    double sel_c, sel_s;
+    // wave-uniform thresholds of the row tests, divided out once: a row is a reset of its own when
+    // dt > gthr (= gap / cmax), its spacing counts as the cached one when |ddt| < jthr (= 2e-6 / wmax)
+    double gthr, jthr;
     int block, sub_mask;            // scaling block length; sub-anchor period - 1
     // running state: rho-scaled phasor, 1 / rho^2, cached one-cadence multipliers
     double cu, su, irho2, Er, Ei, G2, dt_ref, dt_last, tref, t_m1;
@@ -736,8 +754,9 @@ struct RowGen {
                                          const double *bc_, const double *cc_, const double *dc_,
                                          const double *cmax_, const double *tg, int64_t n_first) {
         const int W = Jr + 2 * Jc;
-        colok = lane < W;
-        cj = 0.0; dj = 0.0; k1 = 0.0; k2 = 0.0; is_sin = false;
+        const bool colok = lane < W;
+        bool is_sin = false;
+        cj = 0.0; dj = 0.0; k1 = 0.0; k2 = 0.0;
         if (lane < Jr) {
             cj = cr_[(size_t)b * Jr + lane];
             k1 = ar_[(size_t)b * Jr + lane];
@@ -751,18 +770,21 @@ struct RowGen {
             k1 = is_sin ? -bc_[ck] : ac_[ck];
             k2 = is_sin ? ac_[ck] : bc_[ck];
         }
-        cmax = cmax_[b];
-        wmax = read_lane(wave_max(fmax(cj, fabs(dj))), 0);      // uniform: lives in SGPRs
+        sel_c = (colok && !is_sin) ? 1.0 : 0.0;
+        sel_s = (colok && is_sin) ? 1.0 : 0.0;
+        const double cmax = cmax_[b];
+        const double wmax = read_lane(wave_max(fmax(cj, fabs(dj))), 0);
+        gthr = read_lane(gap_ / cmax, 0);                       // uniform: live in SGPRs
+        jthr = read_lane(2e-6 / wmax, 0);
         block = block_sub & 0xff;           // (block <= 64) | (sub-anchor period << 8)
         sub_mask = (block_sub >> 8) - 1;
-        gap = gap_;
         cu = 1.0; su = 0.0; irho2 = 1.0; Er = 1.0; Ei = 0.0; G2 = 1.0; dt_ref = -1.0; dt_last = -2.0;
         // reference time of the block that precedes the first row (for its decay); tg points
         // at the first row, earlier rows are at negative indices
         tref = tg[0];
         if (n_first > 0) {
             int64_t g = -1;
-            while (!(((n_first + g) & (block - 1)) == 0 || cmax * (tg[g] - tg[g - 1]) > gap)) --g;
+            while (!(((n_first + g) & (block - 1)) == 0 || (tg[g] - tg[g - 1]) > gthr)) --g;
             tref = tg[g];
         }
         t_m1 = (n_first > 0) ? tg[-1] : tg[0];
@@ -781,9 +803,9 @@ struct RowGen {
     __device__ __forceinline__ int peek(const double tn, const int64_t g, double &dt, double &ddt) const {
         dt = tn - t_m1;
         ddt = dt - dt_ref;
-        if (((g & (block - 1)) == 0) || (cmax * dt > gap)) return 2;
+        if (((g & (block - 1)) == 0) || (dt > gthr)) return 2;
         if ((g & sub_mask) == 0) return 3;                      // exact phasor again, same scaling
-        return (fabs(ddt) * wmax < 2e-6) ? 0 : 1;
+        return (fabs(ddt) < jthr) ? 0 : 1;
     }
     // Sub-anchor: every `period` rows (gf_set_generator_period: 1, 2, 4, ... 64) the phasor is
     // recomputed exactly (theta = d t_n as one rounded multiply, rho = exp(-c (t_n - t_ref))), so
@@ -830,7 +852,7 @@ struct RowGen {
     }
     __device__ __forceinline__ void emit(double &ut, double &vt) const {
         ut = fma(k1, cu, k2 * su);                  // pad lanes: k1 = k2 = 0
-        vt = colok ? (is_sin ? su : cu) * irho2 : 0.0;
+        vt = fma(sel_s, su, sel_c * cu) * irho2;
     }
     __device__ __forceinline__ void next(const double tn, const int64_t g, double &ut, double &vt,
                                          bool &rst, double &de) {
@@ -838,11 +860,11 @@ struct RowGen {
         // apart inside the rare branch
         const double dt = tn - t_m1;
         double ddt = dt - dt_ref;
-        rst = ((g & (block - 1)) == 0) || (cmax * dt > gap);
+        rst = ((g & (block - 1)) == 0) || (dt > gthr);
         de = -1.0;
-        if (rst) {
+        if (__builtin_expect(rst, 0)) {
             anchor(tn, g, de);
-        } else if (((g & sub_mask) != 0) && (fabs(ddt) * wmax < 2e-6)) {
+        } else if (__builtin_expect(((g & sub_mask) != 0) && (fabs(ddt) < jthr), 1)) {
             step(tn, ddt);
         } else {
             // sub-anchor row, or a spacing that differs from the cached one: exact phasor (an
@@ -850,8 +872,8 @@ struct RowGen {
             // the multiplier, exact accuracy); the cached multipliers move to a new spacing
             // only once it repeats (a lasting change of cadence, not a single odd row)
             subanchor(tn);
-            if (!(fabs(ddt) * wmax < 2e-6)) {
-                if (fabs(dt - dt_last) * wmax < 2e-6) refresh(dt);
+            if (!(fabs(ddt) < jthr)) {
+                if (fabs(dt - dt_last) < jthr) refresh(dt);
                 dt_last = read_lane(dt, 0);
             }
         }
@@ -901,9 +923,13 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     const size_t pb = (size_t)pr * N + c0;
     const double *__restrict__ tg = t_ + (size_t)pr * t_bs + g0;
     const double *__restrict__ yg = y_ + (size_t)pr * y_bs + g0;
-    const double *__restrict__ gg = diag_ ? diag_ + (size_t)pr * diag_bs + g0 : nullptr;
+    // per-row diagonal: always read (through an address that is valid either way, so the loads stay
+    // unconditional scalar loads) and dropped by a scalar select when there is none
+    const bool has_g = diag_ != nullptr;
+    const double *__restrict__ gg = has_g ? diag_ + (size_t)pr * diag_bs + g0 : yg;
     double *__restrict__ dg = d_ + pb;
     double *__restrict__ zg = z_ + pb;
+    // chunk-mode row stores: loop-invariant per-lane pointers, indexed with opaque_uniform(row)
     double *__restrict__ rg = r_out ? r_out + pb * 64 + lane : nullptr;
     double *__restrict__ ug = Ut_out ? Ut_out + pb * 64 + lane : nullptr;   // stored factor:
     double *__restrict__ wg = Wt_out ? Wt_out + pb * 64 + lane : nullptr;   // u~, w~ = r/d rows
@@ -920,18 +946,21 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     __shared__ double s_u[64];      // u~_n
     __shared__ double s_e[64];      // block decay E at reset rows
     const bool fl = lane == 63;     // pad lane carrying the forward solve (W < 64)
+    // exact 0/1 factors for "every lane but 63" / "lane 63 only": one multiply (FMA) where a
+    // 64-bit select costs two instructions on the row's serial chain
+    const double not63 = fl ? 0.0 : 1.0, is63 = fl ? 1.0 : 0.0;
 
     double T[ROWS];
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) T[i] = fl ? Fg[i] : Sg[i];
-    double q = 0.0, zq = 0.0;
+    double q = 0.0;
     int32_t fail = 0;
 
-    // rows are generated one row ahead of their sweep; t, y, diag are prefetched two further
-    // rows ahead (the caller pads t, y, diag by three elements)
+    // rows are generated one row ahead of their sweep; t is prefetched two further rows ahead, y and
+    // diag one (the caller pads t, y, diag by three elements; a row takes far longer than a scalar load)
     double t_n1 = tg[1], t_n2 = tg[2];
-    double y_n = yg[0], y_n1 = yg[1], y_n2 = yg[2];
-    double g_n = gg ? gg[0] : 0.0, g_n1 = gg ? gg[1] : 0.0, g_n2 = gg ? gg[2] : 0.0;
+    double y_n = yg[0], y_n1 = yg[1];
+    double g_n = gg[0], g_n1 = gg[1];
     double ut, vt, de;
     bool rst;
     G.next(tg[0], g0, ut, vt, rst, de);
@@ -943,7 +972,7 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     sweep_preload<ROWS>(ab, wb, s_u, s_w);
 
     for (int64_t n = 0; n < rows; ++n) {
-        const double a_n = g_n + diag_add, yy = y_n;
+        const double a_n = (has_g ? g_n : 0.0) + diag_add, yy = y_n;
         const double ut_c = ut, vt_c = vt;
         if (eg && lane == 0) eg[n] = rst ? de : -1.0;
         if (rst) {                          // wave-uniform: fold the pending update, then decay
@@ -956,7 +985,6 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
             (void)sweep_run<ROWS, true>(T, ab, wb, s_e, s_w, q, el);
             sweep_preload<ROWS>(ab, wb, s_u, s_w);
             q = 0.0;
-            zq = 0.0;
         }
         __builtin_amdgcn_s_setprio(0);
         const double tmp = sweep_run<ROWS, false>(T, ab, wb, s_u, s_w, q, 0.0);
@@ -964,13 +992,13 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
         // arbitration against the partner wave's FMA stream: its instructions are dependent and
         // each lost slot lengthens the chain, the partner's are not
         __builtin_amdgcn_s_setprio(GF_CHAIN_PRIO);
-        const double r = fl ? 0.0 : (vt_c - tmp);
+        const double r = (vt_c - tmp) * not63;
         // next row's operands: generated here, where the operand ring is dead (register budget)
         G.next(t_n1, g0 + n + 1, ut, vt, rst, de);
-        t_n1 = t_n2; y_n = y_n1; y_n1 = y_n2; g_n = g_n1; g_n1 = g_n2;
+        t_n1 = t_n2; y_n = y_n1; g_n = g_n1;
         t_n2 = tg[n + 3];
-        y_n2 = yg[n + 3];
-        g_n2 = gg ? gg[n + 3] : 0.0;
+        y_n1 = yg[n + 2];
+        g_n1 = gg[n + 2];
         wave_lds_fence();
         s_w[lane] = r;
         s_u[lane] = ut;
@@ -986,10 +1014,10 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
             break;
         }
         const double inv = fast_rcp(dn);
-        zq = zn * inv;
-        q = fl ? zq : r * inv;
-        if (rg) rg[(size_t)n * 64] = r;             // r~ rows for k_phi (chunk mode)
-        if (ug) { ug[(size_t)n * 64] = ut_c; wg[(size_t)n * 64] = fl ? 0.0 : q; }
+        q = fma(zn, is63, r) * inv;                 // lane 63: z / d (r is 0 there)
+        const size_t ro = opaque_uniform((size_t)n * 64);
+        if (rg) rg[ro] = r;                         // r~ rows for k_phi (chunk mode)
+        if (ug) { ug[ro] = ut_c; wg[ro] = fl ? 0.0 : q; }
         if (lane == 0) { dg[n] = dn; zg[n] = zn; }
     }
     if (fail) {
@@ -1113,6 +1141,7 @@ k_factor6(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     const double *__restrict__ gg = diag_ ? diag_ + (size_t)pr * diag_bs + g0 : nullptr;
     double *__restrict__ dg = d_ + pb;
     double *__restrict__ zg = z_ + pb;
+    // chunk-mode row stores: loop-invariant per-lane pointers, indexed with opaque_uniform(row)
     double *__restrict__ rg = r_out ? r_out + pb * 64 + lane : nullptr;
     double *__restrict__ ug = Ut_out ? Ut_out + pb * 64 + lane : nullptr;   // stored factor:
     double *__restrict__ wg = Wt_out ? Wt_out + pb * 64 + lane : nullptr;   // u~, w~ = r/d rows
@@ -1191,8 +1220,9 @@ k_factor6(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
         double x = ut_c * tmp, y = r * ut, dn = 1.0, inv = 1.0, qn = 0.0, sgn = 0.0;
         const double zn = yy - read_lane(tmp, 63);
         const double rz = fl ? zn : r;
-        if (rg) rg[(size_t)n * 64] = r;             // r~ rows for k_phi (chunk mode)
-        if (ug) ug[(size_t)n * 64] = ut_c;
+        const size_t ro = opaque_uniform((size_t)n * 64);
+        if (rg) rg[ro] = r;                         // r~ rows for k_phi (chunk mode)
+        if (ug) ug[ro] = ut_c;
         constexpr int NS = 11, NB = ROWS / SP_BR;
         auto chain = [&](auto sc) {
             constexpr int st = decltype(sc)::value;
@@ -1200,8 +1230,8 @@ k_factor6(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
             else if constexpr (st == 1) { x += dpp_get<0x4E, 0xf>(x); y += dpp_get<0x4E, 0xf>(y); }
             else if constexpr (st == 2) { x += dpp_get<0x141, 0xf>(x); y += dpp_get<0x141, 0xf>(y); }
             else if constexpr (st == 3) { x += dpp_get<0x140, 0xf>(x); y += dpp_get<0x140, 0xf>(y); }
-            else if constexpr (st == 4) { x += dpp_get<0x142, 0xa>(x); y += dpp_get<0x142, 0xa>(y); }
-            else if constexpr (st == 5) { x += dpp_get<0x143, 0xc>(x); y += dpp_get<0x143, 0xc>(y); }
+            else if constexpr (st == 4) { x += dpp_get<0x142, 0xf>(x); y += dpp_get<0x142, 0xf>(y); }
+            else if constexpr (st == 5) { x += dpp_get<0x143, 0xf>(x); y += dpp_get<0x143, 0xf>(y); }
             else if constexpr (st == 6) { dn = a_n - read_lane(x, 63); sgn = read_lane(y, 63); }
             // (pinned like the fold's batches: these would otherwise sink below the pivot test)
             else if constexpr (st == 7) { inv = __builtin_amdgcn_rcp(dn); asm volatile("" : "+v"(inv)); }
@@ -1227,7 +1257,7 @@ k_factor6(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
         q = qn;
         sg = sgn;
         { double *t = swc; swc = swn; swn = t; }
-        if (wg) wg[(size_t)n * 64] = fl ? 0.0 : qn;
+        if (wg) wg[ro] = fl ? 0.0 : qn;
         if (lane == 0) { dg[n] = dn; zg[n] = zn; }
     }
     if (fail) {
@@ -1428,8 +1458,8 @@ k_factor5(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
         else if constexpr (st == 2) x += dpp_get<0x4E, 0xf>(x);
         else if constexpr (st == 3) x += dpp_get<0x141, 0xf>(x);
         else if constexpr (st == 4) x += dpp_get<0x140, 0xf>(x);
-        else if constexpr (st == 5) x += dpp_get<0x142, 0xa>(x);
-        else if constexpr (st == 6) x += dpp_get<0x143, 0xc>(x);
+        else if constexpr (st == 5) x += dpp_get<0x142, 0xf>(x);
+        else if constexpr (st == 6) x += dpp_get<0x143, 0xf>(x);
         else if constexpr (st == 7) {
             const double sp = read_lane(x, 63), t63 = read_lane(tm, 63);
             const int mm = n - 1;
@@ -1446,8 +1476,8 @@ k_factor5(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
         else if constexpr (st == 13) xs += dpp_get<0x4E, 0xf>(xs);
         else if constexpr (st == 14) xs += dpp_get<0x141, 0xf>(xs);
         else if constexpr (st == 15) xs += dpp_get<0x140, 0xf>(xs);
-        else if constexpr (st == 16) xs += dpp_get<0x142, 0xa>(xs);
-        else if constexpr (st == 17) xs += dpp_get<0x143, 0xc>(xs);
+        else if constexpr (st == 16) xs += dpp_get<0x142, 0xf>(xs);
+        else if constexpr (st == 17) xs += dpp_get<0x143, 0xf>(xs);
         else if constexpr (st == 18) sg_m = read_lane(xs, 63);
     };      // (no branches in the stages: a branch would cut the sweep's basic block in two)
 
@@ -1534,8 +1564,8 @@ k_factor5(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
         {
             // loop-invariant, wave-uniform scalars of the generator's row test (peek), held in
             // SGPRs explicitly: the inner loop never refreshes the cadence or re-anchors
-            const double dtr = read_lane(G.dt_ref, 0), cmx = read_lane(G.cmax, 0);
-            const double wmx = read_lane(G.wmax, 0), gp = read_lane(G.gap, 0);
+            const double dtr = read_lane(G.dt_ref, 0);
+            const double gth = read_lane(G.gthr, 0), jth = read_lane(G.jthr, 0);
             const int bmask = __builtin_amdgcn_readfirstlane(G.block - 1);
             const int nrows = __builtin_amdgcn_readfirstlane(rows);
             double tm1 = read_lane(G.t_m1, 0);
@@ -1557,8 +1587,8 @@ k_factor5(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
                 // kind of row n+1 (RowGen::peek; g0 is a multiple of block, so the block phase is n's)
                 const double t_next = read_lane(s_in[0][(n + 1) & 63], 0);
                 const double dt = t_next - tm1, ddt = dt - dtr;
-                if ((((n + 1) & bmask) == 0) || (((n + 1) & G.sub_mask) == 0) || (cmx * dt > gp)
-                    || !(fabs(ddt) * wmx < 2e-6)) break;
+                if ((((n + 1) & bmask) == 0) || (((n + 1) & G.sub_mask) == 0) || (dt > gth)
+                    || !(fabs(ddt) < jth)) break;
                 tm1 = t_next;
                 G.unpark(s_gen, lane);
                 G.step(t_next, ddt);
