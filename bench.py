@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--overlap", action="store_true",
                     help="build tile k+1 on a side stream during the sweep of tile k (slower: "
                          "the build waves displace one of the two sweep waves per SIMD)")
-    ap.add_argument("--kernel", choices=["auto", "blocked", "fused", "pipelined", "split"], default="auto",
+    ap.add_argument("--kernel", choices=["auto", "blocked", "fused", "pipelined", "split", "tiled"], default="auto",
                     help="sweep kernel: blocked = k_factor4 (FP64 MFMA, rank-16 blocks), "
                          "fused = k_factor3 (vector FMA); auto takes blocked when supported")
     ap.add_argument("--generator-period", type=int, default=0,
@@ -115,11 +115,15 @@ def main():
                                          overlap_build=args.overlap)
     packs = [ev.pack(walkers(s)) for s in range(nsteps)]
     eng = ev.engine
-    if args.kernel == "pipelined":
+    if args.kernel == "fused":
+        eng.lib.gf_set_pipelined(4)
+    elif args.kernel == "pipelined":
         eng.lib.gf_set_pipelined(1)
     elif args.kernel == "split":
         eng.lib.gf_set_pipelined(2)
-    if args.kernel in ("fused", "pipelined", "split"):
+    elif args.kernel == "tiled":
+        eng.lib.gf_set_pipelined(3)
+    if args.kernel in ("fused", "pipelined", "split", "tiled"):
         eng.allow_blocked = False
     elif args.kernel == "blocked" and not eng._blocked_ok():
         raise SystemExit("--kernel blocked: not supported for this term structure / cadence")
@@ -207,15 +211,21 @@ def main():
                 traffic = tr["hbm_bytes_per_row_eval"] * fac_avg_rows * E
         except (OSError, ValueError, KeyError):
             pass
+        co0 = walkers(0)[0].get_device_coefficients()    # term structure (real / complex counts)
         result["roofline"] = {
             "bound": "hbm",
             "kernel": {"blocked": "k_factor4 (fused build + factor + forward solve, rank-16 blocks "
                                   "on v_mfma_f64_16x16x4)",
-                       "fused": "k_factor5 (fused build + factor + forward solve, post work of row n-1 "
-                                "interleaved with sweep n)" if args.kernel == "pipelined" else
-                                "k_factor6 (fused build + factor + forward solve, split sweep: the "
-                                "fold runs under the row's chain)" if args.kernel == "split" else
-                                "k_factor3 (fused build + factor + forward solve)"}.get(
+                       "fused": {"pipelined": "k_factor5 (fused build + factor + forward solve, post work "
+                                              "of row n-1 interleaved with sweep n)",
+                                 "split": "k_factor6 (fused build + factor + forward solve, split sweep: "
+                                          "the fold runs under the row's chain)",
+                                 "fused": "k_factor3 (fused build + factor + forward solve, one column "
+                                          "per lane)"}.get(
+                                     args.kernel,
+                                     "k_factor7 (fused build + factor + forward solve, 2 x 32 lane tiling)"
+                                     if len(co0[0]) == 0 and len(co0[2]) <= 31 else
+                                     "k_factor3 (fused build + factor + forward solve, one column per lane)")}.get(
                            getattr(eng, "kernel_used", ""), "k_factor"),
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": traffic,

@@ -854,8 +854,21 @@ struct RowGen {
         ut = fma(k1, cu, k2 * su);                  // pad lanes: k1 = k2 = 0
         vt = fma(sel_s, su, sel_c * cu) * irho2;
     }
+    // both columns of a complex term from the lane that carries its cos column (k1 = a, k2 = b):
+    // u~ = (a cu + b su, a su - b cu), v~ = (cu, su) / rho^2          (k_factor7's lane tiling)
+    __device__ __forceinline__ void emit2(double &u0, double &u1, double &v0, double &v1) const {
+        u0 = fma(k1, cu, k2 * su);
+        u1 = fma(k1, su, -(k2 * cu));
+        const double w = sel_c * irho2;             // pad lanes: 0
+        v0 = cu * w;
+        v1 = su * w;
+    }
     __device__ __forceinline__ void next(const double tn, const int64_t g, double &ut, double &vt,
                                          bool &rst, double &de) {
+        advance(tn, g, rst, de);
+        emit(ut, vt);
+    }
+    __device__ __forceinline__ void advance(const double tn, const int64_t g, bool &rst, double &de) {
         // two wave-uniform tests on the common path (reset? plain step?); the rare cases are told
         // apart inside the rare branch
         const double dt = tn - t_m1;
@@ -877,7 +890,6 @@ struct RowGen {
                 dt_last = read_lane(dt, 0);
             }
         }
-        emit(ut, vt);
     }
 
     // Park / restore the ten per-lane doubles in LDS (buf[10][64]): a kernel that needs its
@@ -1029,6 +1041,232 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     for (int i = 0; i < ROWS; ++i) {
         const double v = fma(s_w[i], q, T[i]);
         if (fl) Fg[i] = v; else Sg[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_factor7: the fused sweep with a 2 x 32 lane tiling (half the LDS operand traffic).
+//
+// k_factor3 gives every lane one column of T and all ROWS rows, so each FMA needs a wave-uniform row
+// operand that reaches the lanes as an LDS broadcast: 1 KiB through the LDS array for 16 useful
+// bytes, 60 ds_read_b128 per row.  With two waves on each of the four SIMDs that is 81 % of the
+// CU's LDS-array cycles (SQ_LDS_IDX_ACTIVE) -- the resource the kernel actually saturates, ahead of
+// vector issue (69 %).  Here lane = (g, c) = (lane >> 5, lane & 31) holds the TWO columns 2c, 2c+1
+// (the cos and sin columns of complex term c: one phasor per lane instead of the same phasor in two
+// lanes) of HALF the rows (pairs of rows 4k + 2g, 4k + 2g + 1): a ds_read_b128 then delivers a
+// different operand pair to each half-wave and feeds 8 FMAs, 30 reads per row instead of 60.  The
+// price: the mat-vec's partial sums of the two halves are added with v_permlane32_swap (12
+// vector instructions), and the row vectors are written to LDS by one half-wave.  Same arguments,
+// state layout in memory and results as k_factor3; needs Jr = 0 (every gadfly kernel with
+// Q > 1/2) and Jc <= 31 (block 31 carries the pad column 62 and the forward solve in column 63).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double xhalf_sum(const double a) {      // a(lane) + a(lane ^ 32), in every lane
+    const int lo = __double2loint(a), hi = __double2hiint(a);
+    const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+}
+
+constexpr int S7_AHEAD = 1;         // batches (one row pair = 8 FMAs + 2 reads) of LDS look-ahead
+
+template <int ROWS>
+__device__ __forceinline__ void sweep7_preload(double2 (&ub)[S7_AHEAD + 1], double2 (&wb)[S7_AHEAD + 1],
+                                               const double2 *pu, const double2 *pw) {
+#pragma unroll
+    for (int k = 0; k < S7_AHEAD && k < ROWS / 4; ++k) { ub[k] = pu[2 * k]; wb[k] = pw[2 * k]; }
+}
+
+// T[2k + s][e] is row 4k + 2g + s, column 2c + e.  pu / pw point at this half-wave's first row pair.
+//   RESET = false:  T += w q^T ;  acc += u^T T         (update + mat-vec, acc[e][s])
+//   RESET = true :  T  = (T + w q^T) * (e_row el_col)  (fold pending, decay; pu = the row decays)
+template <int ROWS, bool RESET>
+__device__ __forceinline__ void sweep7_run(double (&T)[ROWS / 2][2], double2 (&ub)[S7_AHEAD + 1],
+                                           double2 (&wb)[S7_AHEAD + 1], const double2 *pu,
+                                           const double2 *pw, const double q0, const double q1,
+                                           const double el0, const double el1, double &o0, double &o1) {
+    constexpr int NK = ROWS / 4, AHEAD = S7_AHEAD;
+    static_assert(ROWS % 4 == 0, "ROWS must be a multiple of 4");
+    double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        if (k + AHEAD < NK) {
+            ub[(k + AHEAD) % (AHEAD + 1)] = pu[2 * (k + AHEAD)];
+            wb[(k + AHEAD) % (AHEAD + 1)] = pw[2 * (k + AHEAD)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const double2 u = ub[k % (AHEAD + 1)], w = wb[k % (AHEAD + 1)];
+        if constexpr (RESET) {
+            T[2 * k][0] = fma(w.x, q0, T[2 * k][0]) * (u.x * el0);
+            T[2 * k][1] = fma(w.x, q1, T[2 * k][1]) * (u.x * el1);
+            T[2 * k + 1][0] = fma(w.y, q0, T[2 * k + 1][0]) * (u.y * el0);
+            T[2 * k + 1][1] = fma(w.y, q1, T[2 * k + 1][1]) * (u.y * el1);
+        } else {
+            T[2 * k][0] = fma(w.x, q0, T[2 * k][0]);
+            T[2 * k][1] = fma(w.x, q1, T[2 * k][1]);
+            T[2 * k + 1][0] = fma(w.y, q0, T[2 * k + 1][0]);
+            T[2 * k + 1][1] = fma(w.y, q1, T[2 * k + 1][1]);
+            a00 = fma(u.x, T[2 * k][0], a00);
+            a01 = fma(u.x, T[2 * k][1], a01);
+            a10 = fma(u.y, T[2 * k + 1][0], a10);
+            a11 = fma(u.y, T[2 * k + 1][1], a11);
+            asm volatile("" : "+v"(a00), "+v"(a01), "+v"(a10), "+v"(a11));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    o0 = a00 + a10;
+    o1 = a01 + a11;
+}
+
+template <int ROWS>
+__global__ void __launch_bounds__(64, 2)
+k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int nch,
+          const int Jr, const int Jc, const int block_sub, const double gap,
+          const double *__restrict__ ar_, const double *__restrict__ cr_,
+          const double *__restrict__ ac_, const double *__restrict__ bc_,
+          const double *__restrict__ cc_, const double *__restrict__ dc_,
+          const double *__restrict__ diag_add_, const double *__restrict__ cmax_,
+          const double *__restrict__ t_, const int64_t t_bs,
+          const double *__restrict__ diag_, const int64_t diag_bs,
+          const double *__restrict__ y_, const int64_t y_bs,
+          double *__restrict__ d_, double *__restrict__ z_, double *__restrict__ r_out,
+          double *__restrict__ Ut_out, double *__restrict__ Wt_out, double *__restrict__ de_out,
+          double *__restrict__ S_state, double *__restrict__ F_state,
+          int32_t *__restrict__ info) {
+    const int lane = threadIdx.x;
+    const int g = lane >> 5, c = lane & 31;         // row group, column block (columns 2c, 2c + 1)
+    const int b = blockIdx.x;                       // state slot = problem * nch + chunk
+    if (info[b] != 0) return;
+    const int pr = b / nch, ch = b - pr * nch;
+    const int64_t c0 = (int64_t)ch * chunk_len;
+    const int64_t rows = (N - c0 < chunk_len) ? (N - c0) : chunk_len;
+    const int64_t g0 = n_first + c0;
+    const size_t pb = (size_t)pr * N + c0;
+    const double *__restrict__ tg = t_ + (size_t)pr * t_bs + g0;
+    const double *__restrict__ yg = y_ + (size_t)pr * y_bs + g0;
+    const bool has_g = diag_ != nullptr;
+    const double *__restrict__ gg = has_g ? diag_ + (size_t)pr * diag_bs + g0 : yg;
+    double *__restrict__ dg = d_ + pb;
+    double *__restrict__ zg = z_ + pb;
+    // chunk-mode row stores (row vectors of 64, columns 2c, 2c + 1 from the lanes of half-wave 0)
+    double2 *__restrict__ rg = r_out ? (double2 *)(r_out + pb * 64) + c : nullptr;
+    double2 *__restrict__ ug = Ut_out ? (double2 *)(Ut_out + pb * 64) + c : nullptr;
+    double2 *__restrict__ wg = Wt_out ? (double2 *)(Wt_out + pb * 64) + c : nullptr;
+    double *__restrict__ eg = de_out ? de_out + pb : nullptr;
+    double *__restrict__ Sg = S_state + (size_t)b * (64 * 64);     // [column][row]
+    double *__restrict__ Fg = F_state + (size_t)b * 64;
+    const double diag_add = diag_add_[pr];
+
+    RowGen G;                                       // this lane generates term c (its cos column's lane)
+    G.init(2 * c, pr, Jr, Jc, block_sub, gap, ar_, cr_, ac_, bc_, cc_, dc_, cmax_, tg, g0);
+    const double cj = G.cj;
+
+    __shared__ __attribute__((aligned(16))) double s_w[64];     // r_{n-1}  (pending update, row form)
+    __shared__ __attribute__((aligned(16))) double s_u[64];     // u~_n
+    __shared__ __attribute__((aligned(16))) double s_e[64];     // block decay at reset rows
+    const double2 *pw = (const double2 *)s_w + g, *pu = (const double2 *)s_u + g;
+    const double2 *pe = (const double2 *)s_e + g;
+    const bool f31 = c == 31;                       // block 31: pad column 62, forward solve in 63
+    const double not31 = f31 ? 0.0 : 1.0, is31 = f31 ? 1.0 : 0.0;
+
+    // this lane's two columns in memory, from its first row on (column 63 lives in F_state)
+    double *__restrict__ col0 = Sg + (size_t)(2 * c) * 64 + 2 * g;
+    double *__restrict__ col1 = (f31 ? Fg : Sg + (size_t)(2 * c + 1) * 64) + 2 * g;
+    double T[ROWS / 2][2];
+#pragma unroll
+    for (int m = 0; m < ROWS / 2; ++m) {
+        T[m][0] = col0[4 * (m >> 1) + (m & 1)];
+        T[m][1] = col1[4 * (m >> 1) + (m & 1)];
+    }
+    double q0 = 0.0, q1 = 0.0;
+    int32_t fail = 0;
+
+    double t_n1 = tg[1], t_n2 = tg[2];
+    double y_n = yg[0], y_n1 = yg[1];
+    double g_n = gg[0], g_n1 = gg[1];
+    double u0, u1, v0, v1, de;
+    bool rst;
+    G.advance(tg[0], g0, rst, de);
+    G.emit2(u0, u1, v0, v1);
+
+    double2 ub[S7_AHEAD + 1], wb[S7_AHEAD + 1];
+    if (g == 0) {
+        ((double2 *)s_w)[c] = make_double2(0.0, 0.0);
+        ((double2 *)s_u)[c] = make_double2(u0, u1);
+    }
+    wave_lds_fence();
+    sweep7_preload<ROWS>(ub, wb, pu, pw);
+
+    for (int64_t n = 0; n < rows; ++n) {
+        const double a_n = (has_g ? g_n : 0.0) + diag_add, yy = y_n;
+        const double u0c = u0, u1c = u1, v0c = v0, v1c = v1;
+        if (eg && lane == 0) eg[n] = rst ? de : -1.0;
+        if (rst) {                          // wave-uniform: fold the pending update, then decay
+            const double el = fm_exp(-cj * de);     // pad block: cj = 0 -> 1 (both columns)
+            if (g == 0) ((double2 *)s_e)[c] = make_double2(el, el);
+            wave_lds_fence();
+            double d0, d1;
+            sweep7_preload<ROWS>(ub, wb, pe, pw);
+            sweep7_run<ROWS, true>(T, ub, wb, pe, pw, q0, q1, el, el, d0, d1);
+            sweep7_preload<ROWS>(ub, wb, pu, pw);
+            q0 = 0.0;
+            q1 = 0.0;
+        }
+        __builtin_amdgcn_s_setprio(0);
+        double acc0, acc1;
+        sweep7_run<ROWS, false>(T, ub, wb, pu, pw, q0, q1, 0.0, 0.0, acc0, acc1);
+        __builtin_amdgcn_s_setprio(GF_CHAIN_PRIO);
+        const double tmp0 = xhalf_sum(acc0), tmp1 = xhalf_sum(acc1);
+        const double r0 = v0c - tmp0, r1 = (v1c - tmp1) * not31;
+        G.advance(t_n1, g0 + n + 1, rst, de);
+        G.emit2(u0, u1, v0, v1);
+        t_n1 = t_n2; y_n = y_n1; g_n = g_n1;
+        t_n2 = tg[n + 3];
+        y_n1 = yg[n + 2];
+        g_n1 = gg[n + 2];
+        wave_lds_fence();
+        if (g == 0) {
+            ((double2 *)s_w)[c] = make_double2(r0, r1);
+            ((double2 *)s_u)[c] = make_double2(u0, u1);
+        }
+        wave_lds_fence();
+        sweep7_preload<ROWS>(ub, wb, pu, pw);
+        // u~ . tmp over the 32 column blocks (both half-waves hold the same values): 16-lane row
+        // sums, then row 1 += row 0 -> lane 31 holds the total
+        double x = fma(u0c, tmp0, u1c * tmp1);      // u~ = 0 in the pad / forward-solve columns
+        x += dpp_get<0xB1, 0xf>(x);
+        x += dpp_get<0x4E, 0xf>(x);
+        x += dpp_get<0x141, 0xf>(x);
+        x += dpp_get<0x140, 0xf>(x);
+        x += dpp_get<0x142, 0xf>(x);
+        const double s1 = read_lane(x, 31);
+        const double s2 = read_lane(tmp1, 31);      // u~ . F~ (column 63)
+        const double dn = a_n - s1;
+        const double zn = yy - s2;
+        if (!(dn > 0.0)) {
+            const int64_t gf = g0 + n + 1;
+            fail = (int32_t)(gf > 0x7fffffff ? 0x7fffffff : gf);
+            break;
+        }
+        const double inv = fast_rcp(dn);
+        q0 = r0 * inv;
+        q1 = fma(zn, is31, r1) * inv;               // column 63: z / d (r is 0 there)
+        if (g == 0) {
+            const size_t ro = opaque_uniform((size_t)n * 32);
+            if (rg) rg[ro] = make_double2(r0, r1);  // r~ rows for k_phi (chunk mode)
+            if (ug) { ug[ro] = make_double2(u0c, u1c); wg[ro] = make_double2(q0, f31 ? 0.0 : q1); }
+        }
+        if (lane == 0) { dg[n] = dn; zg[n] = zn; }
+    }
+    if (fail) {
+        if (lane == 0) info[b] = fail;
+        return;
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int m = 0; m < ROWS / 2; ++m) {
+        const double w = s_w[2 * g + 4 * (m >> 1) + (m & 1)];
+        col0[4 * (m >> 1) + (m & 1)] = fma(w, q0, T[m][0]);
+        col1[4 * (m >> 1) + (m & 1)] = fma(w, q1, T[m][1]);
     }
 }
 
@@ -3559,9 +3797,9 @@ int gf_factor_scaled(int B, int64_t N, int64_t n_first, int W, int ld, const dou
 }
 
 #define GF_F3_ARGS dim3(B * nch), dim3(64), 0, st, N, n_first, chunk_len, nch, Jr, Jc, (block | (g_gen_period << 8)), gap, ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out, Ut_out, Wt_out, de_out, S_state, F_state, info
-#define GF_F3_CASE(R) case R: if (!g_pipelined) hipLaunchKernelGGL((k_factor3<R>), GF_F3_ARGS); else if (g_pipelined == 2) hipLaunchKernelGGL((k_factor6<R>), GF_F3_ARGS); else if (r_out || Ut_out || de_out) hipLaunchKernelGGL((k_factor5<R, true>), GF_F3_ARGS); else hipLaunchKernelGGL((k_factor5<R, false>), GF_F3_ARGS); break;
+#define GF_F3_CASE(R) case R: if ((g_pipelined == 0 || g_pipelined == 3) && Jr == 0 && Jc <= 31) hipLaunchKernelGGL((k_factor7<R>), GF_F3_ARGS); else if (g_pipelined == 0 || g_pipelined >= 3) hipLaunchKernelGGL((k_factor3<R>), GF_F3_ARGS); else if (g_pipelined == 2) hipLaunchKernelGGL((k_factor6<R>), GF_F3_ARGS); else if (r_out || Ut_out || de_out) hipLaunchKernelGGL((k_factor5<R, true>), GF_F3_ARGS); else hipLaunchKernelGGL((k_factor5<R, false>), GF_F3_ARGS); break;
 static int g_gen_period = 4;        // gf_set_generator_period
-static int g_pipelined = 0;         // gf_set_pipelined(1) selects the pipelined k_factor5 (experimental, slower: DESIGN.md 4.2)
+static int g_pipelined = 0;         // gf_set_pipelined: 0 auto (k_factor7 where it applies, else k_factor3), 1 k_factor5, 2 k_factor6, 3 k_factor7, 4 k_factor3
 
 
 static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int64_t chunk_len, int nch,
@@ -3606,7 +3844,7 @@ int gf_set_generator_period(int period) {
 
 int gf_set_pipelined(int on) {
     const int old = g_pipelined;
-    g_pipelined = (on == 2) ? 2 : (on ? 1 : 0);
+    g_pipelined = (on >= 0 && on <= 4) ? on : 0;
     return old;
 }
 

@@ -156,13 +156,15 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
 int gf_set_generator_period(int period);
 
 /*
- * gf_set_pipelined(1) makes gf_loglike_fused / gf_chunk_sweep run the software-pipelined sweep
- * (k_factor5: the reductions, reciprocal and r, q of row n-1 are issued between the FMA batches of
- * sweep n); gf_set_pipelined(2) the split sweep (k_factor6: mat-vec with the not-yet-updated T,
- * then the fold with the row's reduction / reciprocal chain issued between its batches).  Both are
- * experimental and slower than the default k_factor3 (DESIGN.md 2.1b has the measurements); kept,
- * parity-tested, for A/B measurements.  Process-wide switch (0 = default), returns the previous
- * setting; results agree to rounding.
+ * Which fused sweep gf_loglike_fused / gf_chunk_sweep run (process-wide, returns the previous
+ * setting; all variants agree to rounding and are parity-tested):
+ *   0  automatic (default): k_factor7 -- 2 x 32 lane tiling, half the LDS operand traffic -- for
+ *      kernels made of complex terms only (Jr = 0, Jc <= 31: every SHO term with Q > 1/2),
+ *      k_factor3 (one column per lane) otherwise;
+ *   3 / 4  the same two kernels by name (4 = k_factor3 everywhere), for A/B measurements;
+ *   1  k_factor5, software-pipelined (the reductions, reciprocal and r, q of row n-1 issued between
+ *      the FMA batches of sweep n);  2  k_factor6, split sweep (mat-vec with the not-yet-updated T,
+ *      then the fold under the row's chain).  Both experimental and slower.
  */
 int gf_set_pipelined(int on);
 

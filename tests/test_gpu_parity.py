@@ -331,10 +331,11 @@ def test_streaming_irregular_cadence_fused(hip):
 
 @pytest.mark.parametrize("case", [STREAM_CASES[0], STREAM_CASES[1], STREAM_CASES[2], STREAM_CASES[6]],
                          ids=["solar6", "solar20jitter", "solar30gaps", "overdamped"])
-@pytest.mark.parametrize("mode", [1, 2], ids=["pipelined", "split"])
+@pytest.mark.parametrize("mode", [1, 2, 3], ids=["pipelined", "split", "tiled"])
 def test_pipelined_variant(hip, case, mode):
-    """The experimental sweeps (gf_set_pipelined(1): software-pipelined k_factor5; (2): split-sweep
-    k_factor6) give the results of the default kernel: streamed tiles with state hand-off, and the time-parallel evaluation
+    """The alternative sweeps (gf_set_pipelined(1): software-pipelined k_factor5; (2): split-sweep
+    k_factor6; (3): 2 x 32 lane tiling k_factor7, complex terms only, others fall back) give the
+    results of the default kernel: streamed tiles with state hand-off, and the time-parallel evaluation
     (chunk mode with the extra row stores)."""
     from gadfly_amd.engine import StreamingBatch
     from oracle import cref
