@@ -744,7 +744,7 @@ struct RowGen {
     double sel_c, sel_s;
     // wave-uniform thresholds of the row tests, divided out once: a row is a reset of its own when
     // dt > gthr (= gap / cmax), its spacing counts as the cached one when |ddt| < jthr (= 2e-6 / wmax)
-    double gthr, jthr;
+    double gthr, jthr, jthr1;       // jthr1 = 1.4e-9 / wmax: below it the step's correction is first order
     int block, sub_mask;            // scaling block length; sub-anchor period - 1
     // running state: rho-scaled phasor, 1 / rho^2, cached one-cadence multipliers
     double cu, su, irho2, Er, Ei, G2, dt_ref, dt_last, tref, t_m1;
@@ -776,6 +776,7 @@ struct RowGen {
         const double wmax = read_lane(wave_max(fmax(cj, fabs(dj))), 0);
         gthr = read_lane(gap_ / cmax, 0);                       // uniform: live in SGPRs
         jthr = read_lane(2e-6 / wmax, 0);
+        jthr1 = read_lane(1.4e-9 / wmax, 0);
         block = block_sub & 0xff;           // (block <= 64) | (sub-anchor period << 8)
         sub_mask = (block_sub >> 8) - 1;
         cu = 1.0; su = 0.0; irho2 = 1.0; Er = 1.0; Ei = 0.0; G2 = 1.0; dt_ref = -1.0; dt_last = -2.0;
@@ -841,14 +842,24 @@ struct RowGen {
     __device__ __forceinline__ void step(const double tn, const double ddt) {
         t_m1 = tn;
         const double xr = -cj * ddt, xi = dj * ddt;
-        const double qr = 1.0 + fma(0.5, fma(xr, xr, -xi * xi), xr);    // exp(xr + i xi)
-        const double qi = fma(xr, xi, xi);
-        const double Mr = fma(Er, qr, -Ei * qi), Mi = fma(Er, qi, Ei * qr);
+        double Mr, Mi, g2;
+        if (fabs(ddt) < jthr1) {
+            // |x| < 1.4e-9 (the rounding jitter of a regular cadence): exp(x) = 1 + x to 1e-18
+            Mr = fma(-Ei, xi, fma(Er, xr, Er));                     // E (1 + x)
+            Mi = fma(Ei, xr, fma(Er, xi, Ei));
+            g2 = fma(G2 * -2.0, xr, G2);                            // G2 (1 - 2 xr)
+        } else {
+            const double qr = 1.0 + fma(0.5, fma(xr, xr, -xi * xi), xr);    // exp(xr + i xi), 2nd order
+            const double qi = fma(xr, xi, xi);
+            Mr = fma(Er, qr, -Ei * qi);
+            Mi = fma(Er, qi, Ei * qr);
+            const double x2 = -2.0 * xr;
+            g2 = G2 * (1.0 + fma(0.5 * x2, x2, x2));
+        }
         const double c2 = fma(cu, Mr, -su * Mi);
         su = fma(cu, Mi, su * Mr);
         cu = c2;
-        const double x2 = -2.0 * xr;
-        irho2 *= G2 * (1.0 + fma(0.5 * x2, x2, x2));
+        irho2 *= g2;
     }
     __device__ __forceinline__ void emit(double &ut, double &vt) const {
         ut = fma(k1, cu, k2 * su);                  // pad lanes: k1 = k2 = 0
