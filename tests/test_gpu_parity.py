@@ -366,6 +366,46 @@ def test_pipelined_variant(hip, case, mode):
     assert _relmax(got, ref_ai) < TOL_VEC
 
 
+@pytest.mark.parametrize("J,N,tile", [(1, 700, 128), (6, 1500, 256), (30, 2500, 512), (31, 2000, 320)],
+                         ids=["W2", "W12", "W60", "W62"])
+def test_fused_kernels_by_name(hip, J, N, tile):
+    """Both fused kernels by name -- the 2 x 32 lane tiling (k_factor7, what `auto` picks for these
+    complex-only kernels; W = 62 fills its 31 term blocks) and one column per lane (k_factor3) --
+    against the oracle, streamed over several tiles and in chunk mode (row stores for the stored
+    factor)."""
+    import torch
+    from gadfly_amd.engine import StreamingBatch
+    from oracle import cref
+    prob = util.solar_problem(J, N, gaps=(J == 30))
+    k, t, y = prob["kernel"], prob["t"], prob["y"]
+    co = k.get_device_coefficients()
+    assert len(co[0]) == 0 and len(co[2]) == J
+    ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y)
+    assert info == 0
+    c, a, U, V = util.oracle_matrices(prob, __import__("oracle.seq", fromlist=["seq"]))
+    d_ref, W_ref, _ = cref.factor(t, c, a, U, V)
+    Y = np.random.default_rng(J).normal(size=(len(t), 2))
+    ref_ai = cref.solve_upper(t, c, U, W_ref, cref.solve_lower(t, c, U, W_ref, Y) / d_ref[:, None])
+    lib = hip.load()
+    got = {}
+    for mode in (3, 4):
+        old = lib.gf_set_pipelined(mode)
+        try:
+            eng = StreamingBatch([co], t, y, diag=prob["diag_user"], tile_rows=tile)
+            assert eng._fused_ok()
+            ll = float(eng.log_likelihood()[0])
+            ll_tp = float(eng.log_likelihood_time_parallel(chunk_len=128)[0])
+            fac = eng.stored_factor(chunk_len=128)
+        finally:
+            lib.gf_set_pipelined(old)
+        assert abs(ll - ref) <= RTOL_LL * abs(ref), (mode, ll, ref)
+        assert abs(ll_tp - ref) <= RTOL_LL * abs(ref), (mode, ll_tp, ref)
+        ai = fac.apply_inverse(torch.as_tensor(Y).cuda().reshape(1, len(t), 2))[0].cpu().numpy()
+        assert _relmax(ai, ref_ai) < TOL_VEC, mode
+        got[mode] = ll
+    assert abs(got[3] - got[4]) <= 1e-11 * abs(ref)
+
+
 TP_CASES = [
     ("solar", dict(J=6, N=3000), 256),
     ("solar", dict(J=30, N=5000), 512),
