@@ -66,6 +66,9 @@ SIGNATURES = {
     "gf_loglike_finish": (_int, [_int, _i64] + [_vp] * 4 + [_vp]),
     "gf_solve": (_int, [_int, _int, _i64, _int, _int, _int] + [_vp] * 6 + [_vp]),
     "gf_cross_covariance": (_int, [_int, _i64, _int, _int, _int] + [_vp] * 6 + [_vp, _i64, _vp, _i64, _vp, _vp]),
+    "gf_interp_work": (_i64, [_i64]),
+    "gf_interp_plan": (_int, [_i64, _vp, _vp, _dbl, _vp, _vp, _vp]),
+    "gf_interp_fill": (_int, [_i64, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, _vp]),
     "gf_psd_power": (_int, [_int, _i64, _i64, _dbl, _vp, _vp, _vp]),
     "gf_psd_bin": (_int, [_int, _i64, _int, _vp, _vp, _vp, _dbl, _vp, _vp, _vp]),
     "gf_general_matmul_work": (_i64, [_int, _i64, _i64, _int]),

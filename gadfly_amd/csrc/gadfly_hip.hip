@@ -3592,12 +3592,13 @@ __global__ void k_add2(int64_t M, const double *work, double *mu) {
 __global__ void __launch_bounds__(256)
 k_psd_power(const int64_t M, const int64_t Mout, const int64_t first, const double norm,
             const double2 *__restrict__ spec, double *__restrict__ power) {
+#pragma clang fp contract(off)      // plain operators under this pragma: HIP's __dmul_rn / __dadd_rn wrappers still contract
     const size_t r = blockIdx.y;
     const double2 *X = spec + r * (size_t)M + first;
     double *P = power + r * (size_t)Mout;
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < Mout; k += (int64_t)gridDim.x * 256) {
         const double2 v = X[k];
-        P[k] = __dadd_rn(__dmul_rn(v.x, v.x), __dmul_rn(v.y, v.y)) * norm;
+        P[k] = (v.x * v.x + v.y * v.y) * norm;
     }
 }
 
@@ -3654,6 +3655,170 @@ k_psd_bin(const int64_t M, const int nb, const double *__restrict__ x,
     if (threadIdx.x == 0) {
         *st = tz / span;
         *er = sqrt(ss / (double)n) / sqrt((double)n) * (sx / (double)n) / span / constant;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Light-curve ingestion: fill the missing cadences of an otherwise evenly
+// sampled series by linear interpolation -- interpolate_missing_data (gadfly/interp.py:6-60), what
+// the reference runs before every FFT power spectrum (psd.py:495, :531).  Times ascending.
+//   cadence index c_i = rint((t_i - t_0) / dt)  (or the given cadence numbers, minus the first);
+//   after point i the indices c_i + 1 .. c_{i+1} - 1 are missing: grid time x = t_0 + index * dt,
+//   flux np.interp(x, t, f) = slope * (x - t_j) + f_j on the interval that holds x,
+// each product and sum rounded on its own, as numpy forms them (bit-identical results).
+// Steps: counts (1 + gap) per point, an exclusive scan, then the merge by time (below).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t cadence_index(const double *t, const int64_t *cad, int64_t i,
+                                                 double t0, double dt) {
+#pragma clang fp contract(off)
+    return cad ? (cad[i] - cad[0]) : (int64_t)rint((t[i] - t0) / dt);
+}
+
+constexpr int SCAN_PER_WG = 2048;       // elements per 256-thread workgroup (8 per thread)
+
+// counts[i] = 1 + number of cadences missing after point i; block_sums[wg] = sum over the workgroup's
+// SCAN_PER_WG elements; offsets[i] = exclusive scan of counts WITHIN the workgroup
+__global__ void __launch_bounds__(256)
+k_interp_count(const int64_t N, const double *__restrict__ t, const int64_t *__restrict__ cad,
+               const double t0, const double dt, int64_t *__restrict__ offsets,
+               int64_t *__restrict__ block_sums) {
+    __shared__ int64_t part[256];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_PER_WG + (int64_t)threadIdx.x * 8;
+    int64_t loc[8], run = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int64_t i = base + k;
+        int64_t cnt = 0;
+        if (i < N) {
+            cnt = 1;
+            if (i + 1 < N) {
+                const int64_t gap = cadence_index(t, cad, i + 1, t0, dt) - cadence_index(t, cad, i, t0, dt) - 1;
+                if (gap > 0) cnt += gap;
+            }
+        }
+        loc[k] = run;
+        run += cnt;
+    }
+    part[threadIdx.x] = run;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {           // Hillis-Steele inclusive scan of the 256 partials
+        const int64_t v = (threadIdx.x >= (unsigned)off) ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const int64_t before = part[threadIdx.x] - run;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (base + k < N) offsets[base + k] = before + loc[k];
+    if (threadIdx.x == 255) block_sums[blockIdx.x] = part[255];
+}
+
+// exclusive scan of the block sums in place (one workgroup, any count); total -> offsets[N]
+__global__ void __launch_bounds__(256)
+k_interp_scan_top(const int64_t nblocks, const int64_t N, int64_t *__restrict__ block_sums,
+                  int64_t *__restrict__ offsets) {
+    __shared__ int64_t part[256];
+    __shared__ int64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < nblocks; b0 += 256) {
+        const int64_t i = b0 + threadIdx.x;
+        const int64_t v = (i < nblocks) ? block_sums[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int64_t u = (threadIdx.x >= (unsigned)off) ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += u;
+            __syncthreads();
+        }
+        if (i < nblocks) block_sums[i] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += part[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[N] = carry;
+}
+
+__global__ void __launch_bounds__(256)
+k_interp_offsets(const int64_t N, const int64_t *__restrict__ block_sums, int64_t *__restrict__ offsets) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) offsets[i] += block_sums[i / SCAN_PER_WG];
+}
+
+// The filled series is the reference's merge BY TIME of the input points and the missing cadences'
+// grid times t_0 + m dt (interp.py:56-59).  With cadence numbers given, dt is a median and the grid
+// drifts against the (e.g. barycentric) time stamps, so a missing cadence's grid time need not lie
+// between its neighbours' time stamps: positions come from ranks, not from the gap a cadence sits in.
+//   input point i   -> i + #{missing m : x_m <  t_i}
+//   missing cadence -> (its rank among the missing) + #{i : t_i <= x_m}      (ties: input points first)
+__device__ __forceinline__ double grid_time(const double t0, const int64_t m, const double dt) {
+#pragma clang fp contract(off)
+    return t0 + (double)m * dt;
+}
+
+// G[i] = offsets[i] - i = number of missing cadences before point i's gap
+__global__ void __launch_bounds__(256)
+k_interp_points(const int64_t N, const double *__restrict__ t, const double *__restrict__ f,
+                const int64_t *__restrict__ cad, const double t0, const double dt,
+                const int64_t *__restrict__ offsets, double *__restrict__ t_out, double *__restrict__ f_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const double ti = t[i];
+    // M = smallest cadence index whose grid time is >= t_i (monotone in m: settle it exactly)
+    int64_t M = (int64_t)floor((ti - t0) / dt) - 1;
+    while (grid_time(t0, M, dt) >= ti) --M;
+    while (grid_time(t0, M, dt) < ti) ++M;
+    // j = last input point with cadence index < M; missing below M = G[j] + those of j's gap below M
+    int64_t lo = 0, hi = N;                         // first point with index >= M
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (cadence_index(t, cad, mid, t0, dt) < M) lo = mid + 1; else hi = mid;
+    }
+    int64_t before = 0;
+    if (lo > 0) {
+        const int64_t j = lo - 1;
+        const int64_t gap = offsets[j + 1] - offsets[j] - 1;
+        int64_t part = M - cadence_index(t, cad, j, t0, dt) - 1;
+        part = part < 0 ? 0 : (part > gap ? gap : part);
+        before = (offsets[j] - j) + part;
+    }
+    t_out[i + before] = ti;
+    f_out[i + before] = f[i];
+}
+
+__global__ void __launch_bounds__(256)
+k_interp_missing(const int64_t N, const double *__restrict__ t, const double *__restrict__ f,
+                 const int64_t *__restrict__ cad, const double t0, const double dt,
+                 const int64_t *__restrict__ offsets, double *__restrict__ t_out, double *__restrict__ f_out) {
+#pragma clang fp contract(off)      // numpy rounds the product and the sum separately (no FMA)
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int64_t G = offsets[i] - i, gap = offsets[i + 1] - offsets[i] - 1;
+    if (gap <= 0) return;
+    const int64_t ci = cadence_index(t, cad, i, t0, dt);
+    int64_t p = i + 1;                              // #{points with t <= x}: grows with k, starts near i
+    for (int64_t k = 1; k <= gap; ++k) {
+        const double x = grid_time(t0, ci + k, dt);
+        if (p > 0 && t[p - 1] > x) {                // the grid has drifted back past point p-1: search below
+            int64_t lo = 0, hi = p - 1;
+            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (t[mid] <= x) lo = mid + 1; else hi = mid; }
+            p = lo;
+        }
+        while (p < N && t[p] <= x) ++p;
+        // np.interp: clamped outside the series, the sample itself on a knot, else the chord
+        double v;
+        if (p == 0) v = f[0];
+        else if (p == N) v = f[N - 1];
+        else {
+            const int64_t j = p - 1;
+            const double slope = (f[j + 1] - f[j]) / (t[j + 1] - t[j]);
+            v = slope * (x - t[j]) + f[j];
+        }
+        const int64_t o = (G + k - 1) + p;
+        t_out[o] = x;
+        f_out[o] = v;
     }
 }
 
@@ -4112,6 +4277,43 @@ int gf_cross_covariance(int B, int64_t N, int R, int Jr, int Jc,
     hipLaunchKernelGGL(k_cross, dim3((unsigned)blocks, B), dim3(256), lds, (hipStream_t)stream, N, R, Jr, Jc,
                        ar, cr, ac, bc, cc, dc, t, t_bs, ts, ts_bs, out);
     return check_launch("gf_cross_covariance");
+}
+
+int64_t gf_interp_work(int64_t N) {
+    return (N < 1) ? 0 : (N + SCAN_PER_WG - 1) / SCAN_PER_WG;
+}
+
+int gf_interp_plan(int64_t N, const double *t, const int64_t *cadences, double dt,
+                   int64_t *offsets, int64_t *work, void *stream) {
+    if (N < 1) return set_err("gf_interp_plan: empty series (N=%s%lld)", "", N);
+    if (!t || !offsets || !work) return set_err("gf_interp_plan: null pointer%s", "");
+    if (!(dt > 0.0)) return set_err("gf_interp_plan: the cadence must be positive%s", "");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nb = gf_interp_work(N);
+    double t0;
+    if (hipMemcpyAsync(&t0, t, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return set_err("gf_interp_plan: cannot read the first time%s", "");
+    hipLaunchKernelGGL(k_interp_count, dim3((unsigned)nb), dim3(256), 0, st, N, t, cadences, t0, dt, offsets, work);
+    hipLaunchKernelGGL(k_interp_scan_top, dim3(1), dim3(256), 0, st, nb, N, work, offsets);
+    hipLaunchKernelGGL(k_interp_offsets, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, work, offsets);
+    return check_launch("gf_interp_plan");
+}
+
+int gf_interp_fill(int64_t N, const double *t, const double *f, const int64_t *cadences, double dt,
+                   const int64_t *offsets, double *t_out, double *f_out, void *stream) {
+    if (N < 1) return set_err("gf_interp_fill: empty series (N=%s%lld)", "", N);
+    if (!t || !f || !offsets || !t_out || !f_out) return set_err("gf_interp_fill: null pointer%s", "");
+    hipStream_t st = (hipStream_t)stream;
+    double t0;
+    if (hipMemcpyAsync(&t0, t, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return set_err("gf_interp_fill: cannot read the first time%s", "");
+    hipLaunchKernelGGL(k_interp_points, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, t, f, cadences,
+                       t0, dt, offsets, t_out, f_out);
+    hipLaunchKernelGGL(k_interp_missing, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, t, f, cadences,
+                       t0, dt, offsets, t_out, f_out);
+    return check_launch("gf_interp_fill");
 }
 
 int gf_psd_power(int R, int64_t M, int64_t first, double norm, const double *spec,

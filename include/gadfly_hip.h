@@ -320,6 +320,27 @@ int gf_psd_bin(int R, int64_t M, int nb, const double *x, const double *power,
                const int64_t *start, double constant, double *stat, double *err, void *stream);
 
 /*
+ * Missing cadences of an evenly sampled light curve filled by linear interpolation: replaces
+ * interpolate_missing_data (gadfly/interp.py:6-60; called at psd.py:495, :531 before every FFT).
+ * t, f [N] ascending times and fluxes; cadences [N] int64 or NULL (then the cadence index of a
+ * point is rint((t - t[0]) / dt), interp.py:41-44); dt = the median spacing per cadence
+ * (interp.py:36, :40), computed by the caller.
+ *   gf_interp_plan: offsets [N + 1] <- i + (number of cadences missing before point i),
+ *     offsets[N] = length of the filled series; work = gf_interp_work(N) int64 words of scratch.
+ *   gf_interp_fill: t_out, f_out [offsets[N]] <- the input points and the missing cadences at their
+ *     grid times t[0] + index * dt (interp.py:51) with flux np.interp(x, t, f) (interp.py:54: the
+ *     chord of the interval that holds x, each operation rounded on its own -- bit-identical to the
+ *     numpy result), merged in time order (the reference's argsort, interp.py:57-59; with cadence
+ *     numbers given the grid may drift past neighbouring time stamps, so positions are ranks).
+ * Both read t[0] back to the host (one 8-byte copy, a stream synchronisation).
+ */
+int64_t gf_interp_work(int64_t N);
+int gf_interp_plan(int64_t N, const double *t, const int64_t *cadences, double dt,
+                   int64_t *offsets, int64_t *work, void *stream);
+int gf_interp_fill(int64_t N, const double *t, const double *f, const int64_t *cadences, double dt,
+                   const int64_t *offsets, double *t_out, double *f_out, void *stream);
+
+/*
  * Conditional mean at M new (sorted) times t1 given alpha = K^-1 (y - mean) at the N
  * observed times t2:
  *   mu[m] = sum_{t2[n] <= t1[m]} (U1[m] o e^{-c (t1[m]-t2[n])}) . V2[n] alpha[n]
