@@ -351,9 +351,10 @@ __global__ void __launch_bounds__(64 * NW) k_factor(const FactorArgs A) {
             fail = (int32_t)(ng > 0x7fffffff ? 0x7fffffff : ng);
             break;
         }
+        const double inv_dn = fast_rcp(dn);     // one reciprocal (<= 1 ulp) instead of CT IEEE divisions
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-            wv[c] = (v[c] - tmp[c]) / dn;
+            wv[c] = (v[c] - tmp[c]) * inv_dn;
             sv_w[c * 64 + lane] = wv[c];
         }
         if (wave == 0) {
@@ -3110,39 +3111,86 @@ __global__ void __launch_bounds__(64) k_solve_vec(const SolveArgs A) {
     const double *__restrict__ push = (up ? A.U : A.Wm) + pb * ld;
     const double *__restrict__ pull = (up ? A.Wm : A.U) + pb * ld;
     const double *__restrict__ Pg = A.P + pb * ld;
-    const double *__restrict__ Y = A.Y + pb;
+    const double *Y = A.Y + pb;         // (Z may alias Y: rows are read ahead of, never behind, the writes)
     const double *__restrict__ sc = A.scale ? A.scale + pb : nullptr;
     double *Z = A.Z + pb;
-    bool colok[CT];
-    double F[CT];
+    // The sweep is one dependent chain per row (two FMAs, a 64-lane reduction: a few hundred cycles),
+    // so a row's operands -- three generator rows, y, the scale -- must already be in registers when
+    // the chain reaches it.  They are fetched DEPTH rows ahead into a register ring, by plain
+    // unconditional vector loads that nothing touches until the row is processed: pad lanes read a
+    // clamped column and are switched off by a 0/1 factor on P, the per-row scalars go through the
+    // same (in-order) vector-load queue via an opaque zero lane offset instead of scalar loads the
+    // wave would have to wait for on the spot.  Without the ring every row waited for its own HBM
+    // round trip: 1.6 us per row.
+    constexpr int DEPTH = 8;
+    const int vz = __builtin_amdgcn_mbcnt_lo(0u, 0u);      // 0 in every lane, not known to be uniform
+    int col[CT];
+    double okf[CT], F[CT];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) { colok[c] = (c * 64 + lane) < ld; F[c] = 0.0; }
+    for (int c = 0; c < CT; ++c) {
+        const int j = c * 64 + lane;
+        col[c] = j < ld ? j : ld - 1;
+        okf[c] = j < ld ? 1.0 : 0.0;
+        F[c] = 0.0;
+    }
+    auto row_of = [&](const int64_t s) { return up ? (N - 1 - s) : s; };
+    auto scaled = [&](const double yv, const double sv) {
+        return sc ? (mm ? yv * sqrt(sv) : yv / sv) : yv;
+    };
 
-    double carry = 0.0;                 // z_{prev} (solves) or y_{prev} (matmul)
-    for (int64_t s = 0; s < N; ++s) {
-        const int64_t n = up ? (N - 1 - s) : s;
+    // row 0 of the sweep: nothing carried yet
+    double carry;
+    {
+        const int64_t n = row_of(0);
+        const double yn = scaled(Y[n], sc ? sc[n] : 1.0);
+        if (lane == 0) Z[n] = yn;
+        carry = yn;
+    }
+    double rp[DEPTH][CT], ra[DEPTH][CT], rb[DEPTH][CT], ry[DEPTH], rs[DEPTH];
+    auto fetch = [&](const int slot, int64_t s) {
+        s = s < N ? s : N - 1;                      // past the end: re-read the last row, never used
+        const int64_t n = row_of(s);
         const int64_t prev = up ? (n + 1) : (n - 1);
         const int64_t prow = up ? (n + 1) : n;
-        double yn = Y[n];
-        if (sc) yn = mm ? yn * sqrt(sc[n]) : yn / sc[n];
-        double dot = 0.0;
-        if (s > 0) {
+        ry[slot] = Y[n + vz];
+        rs[slot] = sc ? sc[n + vz] : 1.0;
 #pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                if (colok[c]) {
-                    const int j = c * 64 + lane;
-                    const double pj = Pg[(size_t)prow * ld + j];
-                    const double aj = push[(size_t)prev * ld + j];
-                    const double bj = pull[(size_t)n * ld + j];
-                    F[c] = pj * fma(aj, carry, F[c]);
-                    dot = fma(bj, F[c], dot);
-                }
-            }
-            dot = wave_sum(dot);
+        for (int c = 0; c < CT; ++c) {
+            rp[slot][c] = Pg[(size_t)prow * ld + col[c]];
+            ra[slot][c] = push[(size_t)prev * ld + col[c]];
+            rb[slot][c] = pull[(size_t)n * ld + col[c]];
         }
+    };
+    auto process = [&](const int64_t s, const double (&p)[CT], const double (&a)[CT],
+                       const double (&q)[CT], const double yv, const double sv) {
+        const int64_t n = row_of(s);
+        const double yn = scaled(yv, sv);
+        double dot = 0.0;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            F[c] = (p[c] * okf[c]) * fma(a[c], carry, F[c]);
+            dot = fma(q[c], F[c], dot);
+        }
+        dot = wave_sum(dot);
         const double zn = mm ? (yn + dot) : (yn - dot);
         if (lane == 0) Z[n] = zn;
         carry = mm ? yn : zn;
+    };
+    int64_t s0 = 1;
+    if (N - 1 >= DEPTH) {
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) fetch(k, 1 + k);
+        for (; s0 + DEPTH <= N; s0 += DEPTH) {
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) {
+                process(s0 + k, rp[k], ra[k], rb[k], ry[k], rs[k]);
+                fetch(k, s0 + k + DEPTH);
+            }
+        }
+    }
+    for (; s0 < N; ++s0) {                          // fewer than DEPTH rows left
+        fetch(0, s0);
+        process(s0, rp[0], ra[0], rb[0], ry[0], rs[0]);
     }
 }
 
