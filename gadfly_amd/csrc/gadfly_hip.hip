@@ -3099,20 +3099,22 @@ struct SolveArgs {
     double *Z;
 };
 
-template <int CT>
+// MODE and SCALED are compile-time (the three sweeps x with / without the per-row scale): no
+// branches on the chain.  CT = 3 covers the full solar kernel (W = 172, ld = 176).
+template <int CT, int MODE, bool SCALED>
 __global__ void __launch_bounds__(64) k_solve_vec(const SolveArgs A) {
     const int lane = threadIdx.x, b = blockIdx.x;
     const int64_t N = A.N;
     const int ld = A.ld;
     const size_t pb = (size_t)b * N;
-    const bool up = (A.mode == GF_SOLVE_UPPER);
-    const bool mm = (A.mode == GF_MATMUL_LOWER);
+    constexpr bool up = (MODE == GF_SOLVE_UPPER);
+    constexpr bool mm = (MODE == GF_MATMUL_LOWER);
     // "push" rows multiply the carried value into F; "pull" rows are dotted with F
     const double *__restrict__ push = (up ? A.U : A.Wm) + pb * ld;
     const double *__restrict__ pull = (up ? A.Wm : A.U) + pb * ld;
     const double *__restrict__ Pg = A.P + pb * ld;
     const double *Y = A.Y + pb;         // (Z may alias Y: rows are read ahead of, never behind, the writes)
-    const double *__restrict__ sc = A.scale ? A.scale + pb : nullptr;
+    const double *__restrict__ sc = SCALED ? A.scale + pb : nullptr;
     double *Z = A.Z + pb;
     // The sweep is one dependent chain per row (two FMAs, a 64-lane reduction: a few hundred cycles),
     // so a row's operands -- three generator rows, y, the scale -- must already be in registers when
@@ -3135,14 +3137,15 @@ __global__ void __launch_bounds__(64) k_solve_vec(const SolveArgs A) {
     }
     auto row_of = [&](const int64_t s) { return up ? (N - 1 - s) : s; };
     auto scaled = [&](const double yv, const double sv) {
-        return sc ? (mm ? yv * sqrt(sv) : yv / sv) : yv;
+        if constexpr (SCALED) return mm ? yv * sqrt(sv) : yv / sv;
+        else return yv;
     };
 
     // row 0 of the sweep: nothing carried yet
     double carry;
     {
         const int64_t n = row_of(0);
-        const double yn = scaled(Y[n], sc ? sc[n] : 1.0);
+        const double yn = scaled(Y[n], SCALED ? sc[n] : 1.0);
         if (lane == 0) Z[n] = yn;
         carry = yn;
     }
@@ -3153,7 +3156,7 @@ __global__ void __launch_bounds__(64) k_solve_vec(const SolveArgs A) {
         const int64_t prev = up ? (n + 1) : (n - 1);
         const int64_t prow = up ? (n + 1) : n;
         ry[slot] = Y[n + vz];
-        rs[slot] = sc ? sc[n + vz] : 1.0;
+        rs[slot] = SCALED ? sc[n + vz] : 1.0;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             rp[slot][c] = Pg[(size_t)prow * ld + col[c]];
@@ -4292,9 +4295,17 @@ int gf_solve(int mode, int B, int64_t N, int W, int ld, int R,
     A.U = U; A.Wm = Wm; A.P = P; A.scale = scale; A.Y = Y; A.Z = Z;
     hipStream_t st = (hipStream_t)stream;
     if (R == 1) {
-        if (ld <= 64)       hipLaunchKernelGGL(k_solve_vec<1>, dim3(B), dim3(64), 0, st, A);
-        else if (ld <= 128) hipLaunchKernelGGL(k_solve_vec<2>, dim3(B), dim3(64), 0, st, A);
-        else                hipLaunchKernelGGL(k_solve_vec<4>, dim3(B), dim3(64), 0, st, A);
+#define GF_SV(CT, M, S) hipLaunchKernelGGL((k_solve_vec<CT, M, S>), dim3(B), dim3(64), 0, st, A)
+#define GF_SV_MODE(CT) do { const bool sd = scale != nullptr; \
+        if (mode == GF_SOLVE_LOWER) { if (sd) GF_SV(CT, GF_SOLVE_LOWER, true); else GF_SV(CT, GF_SOLVE_LOWER, false); } \
+        else if (mode == GF_SOLVE_UPPER) { if (sd) GF_SV(CT, GF_SOLVE_UPPER, true); else GF_SV(CT, GF_SOLVE_UPPER, false); } \
+        else { if (sd) GF_SV(CT, GF_MATMUL_LOWER, true); else GF_SV(CT, GF_MATMUL_LOWER, false); } } while (0)
+        if (ld <= 64)       GF_SV_MODE(1);
+        else if (ld <= 128) GF_SV_MODE(2);
+        else if (ld <= 192) GF_SV_MODE(3);
+        else                GF_SV_MODE(4);
+#undef GF_SV_MODE
+#undef GF_SV
     } else {
         const dim3 grid((R + 63) / 64, B);
         if (ld <= 16)       hipLaunchKernelGGL((k_solve_rhs<16, 1>), grid, dim3(64), 0, st, A);
