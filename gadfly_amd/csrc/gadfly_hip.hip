@@ -121,6 +121,16 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return r;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// queue (s_waitcnt vmcnt(0) before s_barrier), which turns a software prefetch issued before the
+// barrier into a wait for HBM at the barrier; kernels whose waves exchange data through LDS alone use
+// this instead and keep their global loads in flight.
+__device__ __forceinline__ void wg_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Order LDS traffic of ONE wave: lane-form writes before uniform (broadcast) reads.
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS operations of one wave execute in issue order, so wavefront scope (a pure
@@ -237,9 +247,11 @@ __global__ void __launch_bounds__(64 * NW) k_factor(const FactorArgs A) {
     double S[RB][CT];
     double Fv[CT], wv[CT];
     bool colok[CT];
+    int colc[CT];                       // pad lanes read a clamped (valid) column and are masked at use
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         colok[c] = (c * 64 + lane) < ld;
+        colc[c] = colok[c] ? (c * 64 + lane) : (ld - 1);
         wv[c] = 0.0;
         Fv[c] = 0.0;
     }
@@ -267,24 +279,29 @@ __global__ void __launch_bounds__(64 * NW) k_factor(const FactorArgs A) {
     double dprev = 0.0, zprev = 0.0;
     int32_t fail = 0;
 
-    // software prefetch of row n0
+    // software prefetch of row n0: plain unconditional loads that nothing touches before the row
+    // is processed (a `colok ? load : 0` here makes the wave wait for HBM right where it issued the load)
     double un[CT], vn[CT], pn[CT], an, yn;
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-        const size_t o = (size_t)n0 * ld + c * 64 + lane;
-        un[c] = colok[c] ? Ug[o] : 0.0;
-        vn[c] = colok[c] ? Vg[o] : 0.0;
-        pn[c] = colok[c] ? Pg[o] : 1.0;
+        const size_t o = (size_t)n0 * ld + colc[c];
+        un[c] = Ug[o];
+        vn[c] = Vg[o];
+        pn[c] = Pg[o];
     }
-    an = ag[n0];
-    yn = yg ? yg[n0] : 0.0;
+    // the per-row scalars travel in the vector-load queue too (opaque zero lane offset): a scalar load
+    // would be waited for at the next LDS access, which shares its counter
+    const int vz = __builtin_amdgcn_mbcnt_lo(0u, 0u);
+    const double *__restrict__ ys = yg ? yg : ag;          // always a valid address; dropped below
+    an = ag[n0 + vz];
+    yn = ys[n0 + vz];
 
     for (int64_t n = n0; n < n1; ++n) {
         double u[CT], v[CT], p[CT];
-        const double a_n = an, y_n = yn;
+        const double a_n = an, y_n = yg ? yn : 0.0;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-            u[c] = un[c]; v[c] = vn[c]; p[c] = pn[c];
+            u[c] = colok[c] ? un[c] : 0.0; v[c] = colok[c] ? vn[c] : 0.0; p[c] = colok[c] ? pn[c] : 1.0;
             sv_u[c * 64 + lane] = u[c];
             sv_p[c * 64 + lane] = p[c];
         }
@@ -292,13 +309,13 @@ __global__ void __launch_bounds__(64 * NW) k_factor(const FactorArgs A) {
         const int64_t nn = (n + 1 < n1) ? (n + 1) : n;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-            const size_t o = (size_t)nn * ld + c * 64 + lane;
-            un[c] = colok[c] ? Ug[o] : 0.0;
-            vn[c] = colok[c] ? Vg[o] : 0.0;
-            pn[c] = colok[c] ? Pg[o] : 1.0;
+            const size_t o = (size_t)nn * ld + colc[c];
+            un[c] = Ug[o];
+            vn[c] = Vg[o];
+            pn[c] = Pg[o];
         }
-        an = ag[nn];
-        yn = yg ? yg[nn] : 0.0;
+        an = ag[nn + vz];
+        yn = ys[nn + vz];
 
         wave_lds_fence();
 
@@ -323,7 +340,7 @@ __global__ void __launch_bounds__(64 * NW) k_factor(const FactorArgs A) {
             const int buf = (int)(n & 1);
 #pragma unroll
             for (int c = 0; c < CT; ++c) s_part[buf][wave][c * 64 + lane] = acc[c];
-            __syncthreads();
+            wg_lds_barrier();           // (not __syncthreads: the next row's prefetch stays in flight)
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 double s = s_part[buf][0][c * 64 + lane];
@@ -3254,7 +3271,7 @@ __global__ void __launch_bounds__(64 * NWV) k_solve_rhs(const SolveArgs A) {
             if constexpr (NWV > 1) {
                 const int buf = (int)(s & 1);
                 s_dot[buf][wave][lane] = dot;
-                __syncthreads();
+                wg_lds_barrier();
                 dot = s_dot[buf][0][lane];
 #pragma unroll
                 for (int w2 = 1; w2 < NWV; ++w2) dot += s_dot[buf][w2][lane];
