@@ -40,6 +40,7 @@ SIGNATURES = {
     "gf_factor": (_int, [_int, _i64, _i64, _int, _int] + [_vp] * 4 + [_vp, _i64]
                   + [_vp] * 6 + [_vp]),
     "gf_scaled_supported": (_int, [_int]),
+    "gf_scaled_wide_supported": (_int, [_int]),
     "gf_build_scaled": (_int, [_int, _i64, _i64, _int, _int, _int] + [_vp] * 8 + [_int]
                         + [_vp, _i64, _vp, _i64] + [_vp] * 4 + [_vp]),
     "gf_factor_scaled": (_int, [_int, _i64, _i64, _int, _int] + [_vp] * 5 + [_vp, _i64]

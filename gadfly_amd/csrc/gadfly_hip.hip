@@ -3891,6 +3891,196 @@ k_interp_missing(const int64_t N, const double *__restrict__ t, const double *__
 }
 
 // ------------------------------------------------------------------------------------
+// k_factor2w: the block-scaled recurrence of k_factor2 for widths beyond one wave (64 < W <= 256),
+// in k_factor's multi-wave mapping.  Scaled coordinates turn the per-row decay
+// S <- P (S + ...) P (two multiplies per element and row) into a rescaling at reset rows only:
+// per element and row one FMA for the pending rank-1 update and one for the mat-vec, instead of
+// the four operations of k_factor.  Inputs are gf_build_scaled's rows (U~, V~, a, de); the state
+// handed from tile to tile is k_factor's layout [RT rows][CT * 64 columns] with the pending
+// update folded in, F~ in column form.  Log-likelihood path only (no factor rows are stored).
+// ------------------------------------------------------------------------------------
+struct Factor2wArgs {
+    int64_t N, n_first;
+    int W, ld;
+    const double *c, *a, *Ut, *Vt, *de, *y;
+    int64_t y_bs;
+    double *d, *z, *S_state, *F_state;
+    int32_t *info;
+};
+
+template <int RB, int CT, int NW>
+__global__ void __launch_bounds__(64 * NW, 2) k_factor2w(const Factor2wArgs A) {     // 2 waves per SIMD
+    static_assert(RB % 4 == 0, "rows per wave must be a multiple of 4");
+    constexpr int WPC = CT * 64;
+    constexpr int RT = RB * NW;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x;
+    if (A.info[b] != 0) return;         // an earlier tile of this problem already failed
+    const int ld = A.ld;
+    const size_t pb = (size_t)b * A.N;
+    const double *__restrict__ ag = A.a + pb;
+    const double *__restrict__ Ug = A.Ut + pb * ld;
+    const double *__restrict__ Vg = A.Vt + pb * ld;
+    const double *__restrict__ eg = A.de + pb;
+    const double *__restrict__ yg = A.y + (size_t)b * A.y_bs;
+    double *__restrict__ Sg = A.S_state + (size_t)b * RT * WPC;
+    double *__restrict__ Fg = A.F_state + (size_t)b * WPC;
+
+    __shared__ double s_part[2][NW][WPC];
+    __shared__ double s_vec[NW][3][WPC];
+    double *sv_u = s_vec[wave][0], *sv_w = s_vec[wave][1], *sv_e = s_vec[wave][2];
+
+    double S[RB][CT], Fv[CT], q[CT];         // pending update: S += w q^T, F~ += q z (q = r / d)
+    bool colok[CT];
+    int colc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int j = c * 64 + lane;
+        colok[c] = j < ld;
+        colc[c] = colok[c] ? j : (ld - 1);
+        Fv[c] = Fg[j];
+        q[c] = 0.0;
+        sv_w[j] = 0.0;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) S[r][c] = Sg[(size_t)(wave * RB + r) * WPC + j];
+    }
+    double zp = 0.0;                    // z of the pending row
+    int32_t fail = 0;
+
+    // row operands one row ahead: plain unconditional loads (clamped pad columns, masked at use; the
+    // per-row scalars through the vector-load queue): the caller pads every buffer by two rows
+    const int vz = __builtin_amdgcn_mbcnt_lo(0u, 0u);
+    double un[CT], vn[CT], an, yn, en;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) { un[c] = Ug[colc[c]]; vn[c] = Vg[colc[c]]; }
+    an = ag[vz]; yn = yg[vz]; en = eg[vz];
+
+    for (int64_t n = 0; n < A.N; ++n) {
+        double u[CT], v[CT];
+        const double a_n = an, y_n = yn;
+        const double e_n = read_lane(en, 0);    // wave-uniform: say so
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            u[c] = colok[c] ? un[c] : 0.0;
+            v[c] = colok[c] ? vn[c] : 0.0;
+            sv_u[c * 64 + lane] = u[c];
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const size_t o = (size_t)(n + 1) * ld + colc[c];
+            un[c] = Ug[o];
+            vn[c] = Vg[o];
+        }
+        an = ag[n + 1 + vz]; yn = yg[n + 1 + vz]; en = eg[n + 1 + vz];
+
+        if (e_n >= 0.0) {               // reset row: fold the pending update, decay by exp(-c de)
+            double el[CT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const int j = c * 64 + lane;     // (decay rates are read here: resets are rare, registers are not)
+                el[c] = (j < A.W) ? exp(-A.c[(size_t)b * A.W + j] * e_n) : 1.0;
+                sv_e[c * 64 + lane] = el[c];
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int r0 = 0; r0 < RB; r0 += 4) {    // batches of 4 rows, fenced: hipcc otherwise hoists
+                double wi[4], ei[4];                // every LDS read of the loop (and spills)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { wi[k] = sv_w[wave * RB + r0 + k]; ei[k] = sv_e[wave * RB + r0 + k]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+                        S[r0 + k][c] = fma(wi[k], q[c], S[r0 + k][c]) * (ei[k] * el[c]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int c = 0; c < CT; ++c) { Fv[c] = el[c] * fma(q[c], zp, Fv[c]); q[c] = 0.0; }
+            zp = 0.0;
+        }
+        wave_lds_fence();
+
+        double acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = 0.0;
+#pragma unroll
+        for (int r0 = 0; r0 < RB; r0 += 4) {
+            double wi[4], ui[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { wi[k] = sv_w[wave * RB + r0 + k]; ui[k] = sv_u[wave * RB + r0 + k]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    S[r0 + k][c] = fma(wi[k], q[c], S[r0 + k][c]);
+                    acc[c] = fma(ui[k], S[r0 + k][c], acc[c]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        double tmp[CT];
+        if constexpr (NW > 1) {
+            const int buf = (int)(n & 1);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) s_part[buf][wave][c * 64 + lane] = acc[c];
+            wg_lds_barrier();
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                double t2 = s_part[buf][0][c * 64 + lane];
+#pragma unroll
+                for (int w2 = 1; w2 < NW; ++w2) t2 += s_part[buf][w2][c * 64 + lane];
+                tmp[c] = t2;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) tmp[c] = acc[c];
+        }
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            Fv[c] = fma(q[c], zp, Fv[c]);
+            s1 = fma(u[c], tmp[c], s1);
+            s2 = fma(u[c], Fv[c], s2);
+        }
+        wave_sum2(s1, s2);
+        const double dn = a_n - s1;
+        const double zn = y_n - s2;
+        if (!(dn > 0.0)) {              // uniform across the whole workgroup
+            const int64_t ng = A.n_first + n + 1;
+            fail = (int32_t)(ng > 0x7fffffff ? 0x7fffffff : ng);
+            break;
+        }
+        const double inv = fast_rcp(dn);
+        zp = zn;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const double r = v[c] - tmp[c];     // pad lanes: 0 - 0
+            q[c] = r * inv;
+            sv_w[c * 64 + lane] = r;
+        }
+        if (wave == 0 && lane == 0) { A.d[pb + n] = dn; A.z[pb + n] = zn; }
+    }
+    if (fail) {
+        if (wave == 0 && lane == 0) A.info[b] = fail;
+        return;
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int i = wave * RB + r;
+        const double wi = sv_w[i];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) Sg[(size_t)i * WPC + c * 64 + lane] = fma(wi, q[c], S[r][c]);
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) Fg[c * 64 + lane] = fma(q[c], zp, Fv[c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // dispatch helpers
 // ------------------------------------------------------------------------------------
 template <int RB, int CT, int NW>
@@ -3909,6 +4099,20 @@ int dispatch_factor(const FactorArgs &A, int B, int nch, hipStream_t st) {
     if (W <= 128) return launch_factor<32, 2, 4>(A, B, nch, st);
     if (W <= 192) return launch_factor<24, 3, 8>(A, B, nch, st);
     return launch_factor<32, 4, 8>(A, B, nch, st);
+}
+
+template <int RB, int CT, int NW>
+int launch_factor2w(const Factor2wArgs &A, int B, hipStream_t st) {
+    hipLaunchKernelGGL((k_factor2w<RB, CT, NW>), dim3(B), dim3(64 * NW), 0, st, A);
+    return check_launch("gf_factor_scaled");
+}
+
+int dispatch_factor2w(const Factor2wArgs &A, int B, hipStream_t st) {      // same shapes as dispatch_factor
+    const int W = A.W;
+    if (W <= 96)  return launch_factor2w<24, 2, 4>(A, B, st);
+    if (W <= 128) return launch_factor2w<32, 2, 4>(A, B, st);
+    if (W <= 192) return launch_factor2w<24, 3, 8>(A, B, st);
+    return launch_factor2w<32, 4, 8>(A, B, st);
 }
 
 }  // namespace
@@ -3991,6 +4195,9 @@ int gf_factor(int B, int64_t N, int64_t n_first, int W, int ld,
 
 int gf_scaled_supported(int W) { return (W >= 1 && W <= 64) ? 1 : 0; }
 
+// widths the block-scaled build + multi-wave sweep (k_build2 + k_factor2w) take beyond one wave
+int gf_scaled_wide_supported(int W) { return (W > 64 && W <= 192) ? 1 : 0; }   // (beyond: register spills, gf_factor is faster)
+
 int gf_build_scaled(int B, int64_t N, int64_t n_first, int Jr, int Jc, int ld,
                     const double *ar, const double *cr, const double *ac,
                     const double *bc, const double *cc, const double *dc,
@@ -4000,7 +4207,7 @@ int gf_build_scaled(int B, int64_t N, int64_t n_first, int Jr, int Jc, int ld,
                     double *a, double *Ut, double *Vt, double *de, void *stream) {
     const int W = Jr + 2 * Jc;
     if (B < 1 || N < 1) return set_err("gf_build_scaled: empty problem (B=%s%lld, N=%lld)", "", B, N);
-    if (!gf_scaled_supported(W)) return set_err("gf_build_scaled: width %s%lld unsupported (max 64)", "", W);
+    if (!gf_scaled_supported(W) && !gf_scaled_wide_supported(W)) return set_err("gf_build_scaled: width %s%lld unsupported", "", W);
     if (ld < W || (ld & 15)) return set_err("gf_build_scaled: ld=%s%lld must be a multiple of 16 and >= W=%lld", "", ld, W);
     if (block < 1 || block > 64 || (block & (block - 1))) return set_err("gf_build_scaled: block=%s%lld must be a power of two in 1..64", "", block);
     if (n_first < 0 || (n_first % block) != 0) return set_err("gf_build_scaled: n_first=%s%lld must be a non-negative multiple of block=%lld", "", n_first, block);
@@ -4025,11 +4232,18 @@ int gf_factor_scaled(int B, int64_t N, int64_t n_first, int W, int ld, const dou
                      double *d, double *z, double *S_state, double *F_state,
                      int32_t *info, void *stream) {
     if (B < 1 || N < 1) return set_err("gf_factor_scaled: empty problem (B=%s%lld, N=%lld)", "", B, N);
-    if (!gf_scaled_supported(W)) return set_err("gf_factor_scaled: width %s%lld unsupported (max 64)", "", W);
+    if (!gf_scaled_supported(W) && !gf_scaled_wide_supported(W)) return set_err("gf_factor_scaled: width %s%lld unsupported", "", W);
     if (ld < W || (ld & 15)) return set_err("gf_factor_scaled: ld=%s%lld must be a multiple of 16 and >= W=%lld", "", ld, W);
     if (!c || !a || !Ut || !Vt || !de || !y || !d || !z || !S_state || !F_state || !info)
         return set_err("gf_factor_scaled: null pointer%s", "");
     hipStream_t st = (hipStream_t)stream;
+    if (W > 64) {                       // state: gf_state_size(W) / gf_state_cols(W) doubles per problem
+        Factor2wArgs A;
+        A.N = N; A.n_first = n_first; A.W = W; A.ld = ld;
+        A.c = c; A.a = a; A.Ut = Ut; A.Vt = Vt; A.de = de; A.y = y; A.y_bs = y_bs;
+        A.d = d; A.z = z; A.S_state = S_state; A.F_state = F_state; A.info = info;
+        return dispatch_factor2w(A, B, st);
+    }
     const int rows = (W + 3) / 4 * 4;
     switch (rows) {
         GF_F2_CASE(4) GF_F2_CASE(8) GF_F2_CASE(12) GF_F2_CASE(16) GF_F2_CASE(20) GF_F2_CASE(24)

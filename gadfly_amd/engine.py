@@ -440,6 +440,8 @@ class StreamingBatch:
         B, ld = self.B, self.ld
         # W <= 64: block-scaled one-wave-per-problem kernels (k_build2 / k_factor2)
         self.scaled = bool(self.lib.gf_scaled_supported(self.W)) and not force_v1
+        # 64 < W <= 256: the same block-scaled rows swept by several waves per problem (k_factor2w)
+        self.scaled_wide = bool(self.lib.gf_scaled_wide_supported(self.W)) and not force_v1
         # W <= 63 and phases inside the fused kernel's sincos range: nothing is materialised
         self.allow_fused = bool(allow_fused) and self.scaled and self.W <= 63
         # ... and, for an even number of real columns and scaling blocks of >= 16 rows, the
@@ -493,7 +495,7 @@ class StreamingBatch:
         f64 = dict(dtype=torch.float64, device=self.device)
         n = self.B * self.tile_rows + 2
         self.bufs = [dict(a=torch.zeros((n,), **f64), U=self._rows_buf(), V=self._rows_buf(),
-                          P=None if self.scaled else self._rows_buf(),
+                          P=None if (self.scaled or self.scaled_wide) else self._rows_buf(),
                           de=torch.zeros((n,), **f64))
                      for _ in range(self._nbuf)]
 
@@ -558,7 +560,7 @@ class StreamingBatch:
         rows = min(self.tile_rows, self.N - n0)
         real, comp, diag_add, _, cmax, block, _ = self._pack
         p = _lib.ptr
-        if self.scaled:
+        if self.scaled or self.scaled_wide:
             st = self.lib.gf_build_scaled(
                 self.B, rows, n0, self.Jr, self.Jc, self.ld,
                 p(real[0]), p(real[1]), p(comp[0]), p(comp[1]), p(comp[2]), p(comp[3]),
@@ -609,7 +611,7 @@ class StreamingBatch:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(main)
-            if self.scaled:
+            if self.scaled or self.scaled_wide:
                 st = lib.gf_factor_scaled(
                     B, rows, n0, self.W, self.ld, p(self._pack[3]), p(buf["a"]),
                     p(buf["U"]), p(buf["V"]), p(buf["de"]), self.y.data_ptr() + 8 * n0,

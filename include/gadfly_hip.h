@@ -107,10 +107,14 @@ int gf_factor(int B, int64_t N, int64_t n_first, int W, int ld,
  *   outputs of gf_build_scaled: a, de [B][N]; Ut, Vt [B][N][ld]
  *   gf_factor_scaled: y (tile pointer), d, z, S_state [B][64*64], F_state [B][64], info as in
  *   gf_factor (state mandatory; zero it and info before the first tile).  Wm is not produced.
+ *   Widths 64 < W <= 256 (gf_scaled_wide_supported): the same recurrence on several waves per
+ *   problem (k_factor2w: two FMAs per state element and row instead of gf_factor's four operations);
+ *   S_state [B][gf_state_size(W)], F_state [B][gf_state_cols(W)] as for gf_factor.
  *   The sweep prefetches rows n+1, n+2 unconditionally: a, de, y, Ut, Vt must each be readable
  *   two rows (elements) past the last row of the last problem.
  */
 int gf_scaled_supported(int W);
+int gf_scaled_wide_supported(int W);
 int gf_build_scaled(int B, int64_t N, int64_t n_first, int Jr, int Jc, int ld,
                     const double *ar, const double *cr, const double *ac,
                     const double *bc, const double *cc, const double *dc,

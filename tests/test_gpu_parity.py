@@ -229,10 +229,11 @@ STREAM_CASES = [
     ("solar", dict(J=30, N=3000, gaps=True), 1000),      # gap rule resets + ragged last tile
     ("solar", dict(J=30, N=2048, yerr=0.0), 8192),       # single tile
     ("solar", dict(J=32, N=1000), 64),                   # W = 64: no pad lanes
-    ("solar", dict(J=40, N=1500), 256),                  # W = 80: v1 kernels (multi-wave)
+    ("solar", dict(J=40, N=1500), 256),                  # W = 80: multi-wave kernels (scaled-wide / v1)
     ("generic", dict(kind="overdamped", N=700), 128),    # real terms
     ("generic", dict(kind="mixed", N=900), 64),
     ("generic", dict(kind="sho_q100", N=512), 100),      # tile_rows not a multiple of 8
+    ("solar", dict(J=70, N=700), 128),                   # W = 140: three column tiles, eight waves
 ]
 
 
@@ -252,6 +253,8 @@ def test_streaming_loglike(hip, case, mode):
                          allow_fused=allow_fused, allow_blocked=(mode == "blocked"))
     if allow_fused:
         assert eng._fused_ok() == (eng.W <= 63)
+    if eng.W > 64:
+        assert eng.scaled_wide == (not force_v1) and not eng.scaled
     if mode == "blocked" and not eng._blocked_ok():
         pytest.skip("blocked kernel needs Jr even, W <= 62, block >= 16")
     ll = float(eng.log_likelihood()[0])

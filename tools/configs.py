@@ -25,7 +25,7 @@ def run(name, ev, B):
     dt = time.perf_counter() - t0
     assert bool(torch.isfinite(out).all())
     print(f"{name}: B={B} in {dt*1e3:8.1f} ms -> {B/dt:9.1f} evals/s "
-          f"(kernels: {'fused' if ev.engine._fused_ok() else ('scaled' if ev.engine.scaled else 'v1')})")
+          f"(kernels: {'fused' if ev.engine._fused_ok() else ('scaled' if ev.engine.scaled else ('scaled-wide' if ev.engine.scaled_wide else 'v1'))})")
 
 
 # cfg3
