@@ -3216,17 +3216,19 @@ __global__ void __launch_bounds__(64) k_solve_vec(const SolveArgs A) {
 
 // ------------------------------------------------------------------------------------
 // K2/K3/K4 with R right-hand sides: lane r of a wave owns column r of Y/Z and the W-vector
-// F[:, r] in VGPRs; the generator rows are wave-uniform (scalar loads), so there is no
-// cross-lane traffic at all.  Widths above 64 split j over NWV waves (one LDS exchange/row).
+// F[:, r] in VGPRs; the generator rows are wave-uniform operands (prefetched by vector loads,
+// broadcast through LDS).  Widths above 64 split j over NWV waves (one LDS exchange/row).
 // ------------------------------------------------------------------------------------
 template <int JB, int NWV>
 __global__ void __launch_bounds__(64 * NWV) k_solve_rhs(const SolveArgs A) {
+    static_assert(JB % 2 == 0 && JB <= 64, "column slice: even, at most one wave wide");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int b = blockIdx.y;
     const int r = blockIdx.x * 64 + lane;
     const int R = A.R;
     const bool rok = r < R;
+    const int rc = rok ? r : (R - 1);   // idle lanes re-read the last right-hand side, never store
     const int64_t N = A.N;
     const int ld = A.ld;
     const size_t pb = (size_t)b * N;
@@ -3235,51 +3237,100 @@ __global__ void __launch_bounds__(64 * NWV) k_solve_rhs(const SolveArgs A) {
     const double *__restrict__ push = (up ? A.U : A.Wm) + pb * ld;
     const double *__restrict__ pull = (up ? A.Wm : A.U) + pb * ld;
     const double *__restrict__ Pg = A.P + pb * ld;
-    const double *__restrict__ Y = A.Y + pb * R;
+    const double *Y = A.Y + pb * R;     // (Z may alias Y: rows are read ahead of, never behind, the writes)
     const double *__restrict__ sc = A.scale ? A.scale + pb : nullptr;
     double *Z = A.Z + pb * R;
     const int j0 = wave * JB;
     int jn = ld - j0;                    // valid columns in this wave's slice
     if (jn > JB) jn = JB;
     if (jn < 0) jn = 0;
+    // The generator rows of this wave's slice are wave-uniform operands of the per-lane recurrences.
+    // Lane l fetches column j0 + l of the three rows DEPTH rows ahead (plain vector loads into a
+    // register ring), the row being processed is staged in LDS and read back as broadcasts.  (As
+    // scalar loads issued when the row needed them, they cost a memory round trip per row: 5.6 us
+    // per row at W = 172.)
+    constexpr int DEPTH = 8;
+    const bool lok = lane < jn;
+    const int jl = j0 + (lok ? lane : (jn > 0 ? jn - 1 : 0));
+    const int jc = jl < ld ? jl : ld - 1;
+    const int vz = __builtin_amdgcn_mbcnt_lo(0u, 0u);
 
+    __shared__ __attribute__((aligned(16))) double s_row[NWV][3][64];
     __shared__ double s_dot[2][NWV][64];
+    double *sp = s_row[wave][0], *sa = s_row[wave][1], *sb = s_row[wave][2];
 
     double F[JB];
 #pragma unroll
     for (int j = 0; j < JB; ++j) F[j] = 0.0;
-
-    double carry = 0.0;
-    for (int64_t s = 0; s < N; ++s) {
-        const int64_t n = up ? (N - 1 - s) : s;
+    auto row_of = [&](const int64_t s) { return up ? (N - 1 - s) : s; };
+    auto scaled = [&](const double yv, const double sv) {
+        return sc ? (mm ? yv * sqrt(sv) : yv / sv) : yv;
+    };
+    double carry;
+    {
+        const int64_t n = row_of(0);
+        const double yn = scaled(Y[(size_t)n * R + rc], sc ? sc[n] : 1.0);
+        if (rok && wave == 0) Z[(size_t)n * R + r] = yn;
+        carry = yn;
+    }
+    double rp[DEPTH], ra[DEPTH], rb[DEPTH], ry[DEPTH], rs[DEPTH];
+    auto fetch = [&](const int slot, int64_t s) {
+        s = s < N ? s : N - 1;                      // past the end: re-read the last row, never used
+        const int64_t n = row_of(s);
         const int64_t prev = up ? (n + 1) : (n - 1);
         const int64_t prow = up ? (n + 1) : n;
-        double yn = rok ? Y[(size_t)n * R + r] : 0.0;
-        if (sc) { const double sn = sc[n]; yn = mm ? yn * sqrt(sn) : yn / sn; }
+        ry[slot] = Y[(size_t)n * R + rc];
+        rs[slot] = sc ? sc[n + vz] : 1.0;
+        rp[slot] = Pg[(size_t)prow * ld + jc];
+        ra[slot] = push[(size_t)prev * ld + jc];
+        rb[slot] = pull[(size_t)n * ld + jc];
+    };
+    auto process = [&](const int64_t s, const double pv, const double av, const double bv,
+                       const double yv, const double sv) {
+        const int64_t n = row_of(s);
+        const double yn = scaled(yv, sv);
+        wave_lds_fence();                           // the previous row's broadcasts are done
+        sp[lane] = lok ? pv : 0.0;                  // columns past the slice: all zero, F stays 0
+        sa[lane] = lok ? av : 0.0;
+        sb[lane] = lok ? bv : 0.0;
+        wave_lds_fence();
         double dot = 0.0;
-        if (s > 0) {
-            const double *pp = Pg + (size_t)prow * ld + j0;
-            const double *pa = push + (size_t)prev * ld + j0;
-            const double *pl = pull + (size_t)n * ld + j0;
 #pragma unroll
-            for (int j = 0; j < JB; ++j) {
-                if (j < jn) {            // wave-uniform predicate
-                    F[j] = pp[j] * fma(pa[j], carry, F[j]);
-                    dot = fma(pl[j], F[j], dot);
-                }
-            }
-            if constexpr (NWV > 1) {
-                const int buf = (int)(s & 1);
-                s_dot[buf][wave][lane] = dot;
-                wg_lds_barrier();
-                dot = s_dot[buf][0][lane];
+        for (int j = 0; j < JB; j += 2) {
+            const double2 p2 = *(const double2 *)(sp + j), a2 = *(const double2 *)(sa + j);
+            const double2 b2 = *(const double2 *)(sb + j);
+            F[j] = p2.x * fma(a2.x, carry, F[j]);
+            F[j + 1] = p2.y * fma(a2.y, carry, F[j + 1]);
+            dot = fma(b2.x, F[j], dot);
+            dot = fma(b2.y, F[j + 1], dot);
+        }
+        if constexpr (NWV > 1) {
+            const int buf = (int)(s & 1);
+            s_dot[buf][wave][lane] = dot;
+            wg_lds_barrier();
+            dot = s_dot[buf][0][lane];
 #pragma unroll
-                for (int w2 = 1; w2 < NWV; ++w2) dot += s_dot[buf][w2][lane];
-            }
+            for (int w2 = 1; w2 < NWV; ++w2) dot += s_dot[buf][w2][lane];
         }
         const double zn = mm ? (yn + dot) : (yn - dot);
         if (rok && wave == 0) Z[(size_t)n * R + r] = zn;
         carry = mm ? yn : zn;
+    };
+    int64_t s0 = 1;
+    if (N - 1 >= DEPTH) {
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) fetch(k, 1 + k);
+        for (; s0 + DEPTH <= N; s0 += DEPTH) {
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) {
+                process(s0 + k, rp[k], ra[k], rb[k], ry[k], rs[k]);
+                fetch(k, s0 + k + DEPTH);
+            }
+        }
+    }
+    for (; s0 < N; ++s0) {                          // fewer than DEPTH rows left
+        fetch(0, s0);
+        process(s0, rp[0], ra[0], rb[0], ry[0], rs[0]);
     }
 }
 
