@@ -883,15 +883,6 @@ struct RowGen {
         ut = fma(k1, cu, k2 * su);                  // pad lanes: k1 = k2 = 0
         vt = fma(sel_s, su, sel_c * cu) * irho2;
     }
-    // both columns of a complex term from the lane that carries its cos column (k1 = a, k2 = b):
-    // u~ = (a cu + b su, a su - b cu), v~ = (cu, su) / rho^2          (k_factor7's lane tiling)
-    __device__ __forceinline__ void emit2(double &u0, double &u1, double &v0, double &v1) const {
-        u0 = fma(k1, cu, k2 * su);
-        u1 = fma(k1, su, -(k2 * cu));
-        const double w = sel_c * irho2;             // pad lanes: 0
-        v0 = cu * w;
-        v1 = su * w;
-    }
     __device__ __forceinline__ void next(const double tn, const int64_t g, double &ut, double &vt,
                                          bool &rst, double &de) {
         advance(tn, g, rst, de);
@@ -1084,16 +1075,29 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
 // (the cos and sin columns of complex term c: one phasor per lane instead of the same phasor in two
 // lanes) of HALF the rows (pairs of rows 4k + 2g, 4k + 2g + 1): a ds_read_b128 then delivers a
 // different operand pair to each half-wave and feeds 8 FMAs, 30 reads per row instead of 60.  The
-// price: the mat-vec's partial sums of the two halves are added with v_permlane32_swap (12
-// vector instructions), and the row vectors are written to LDS by one half-wave.  Same arguments,
+// row vectors stay one column per lane (lane (g, c) owns column 2c + g, the generator is
+// k_factor3's); two v_permlane32_swap exchanges per row connect the layouts (7 vector
+// instructions: the mat-vec's partial sums, then the multipliers q).  Same arguments,
 // state layout in memory and results as k_factor3; needs Jr = 0 (every gadfly kernel with
 // Q > 1/2) and Jc <= 31 (block 31 carries the pad column 62 and the forward solve in column 63).
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ double xhalf_sum(const double a) {      // a(lane) + a(lane ^ 32), in every lane
-    const int lo = __double2loint(a), hi = __double2hiint(a);
-    const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+// The row vectors (u~, v~, r, q) live one column per lane as in k_factor3 -- lane (g, c) owns column
+// 2c + g -- while the state is tiled two columns x half the rows per lane.  Two exchanges between
+// the half-waves connect the two layouts, each a pair of v_permlane32_swap (which swaps the upper
+// half of its first operand with the lower half of its second):
+//   own_column_sum(a, b): a, b = this half-wave's partial sums of columns 2c, 2c + 1; returns the
+//     full sum of the lane's OWN column (lower half: a_L + a_U, upper half: b_L + b_U);
+//   both_halves(x, lo, up): lo = x of lane c, up = x of lane c + 32, in both lanes.
+__device__ __forceinline__ double own_column_sum(const double a, const double b) {
+    const auto l = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
     return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+}
+__device__ __forceinline__ void both_halves(const double x, double &lo, double &up) {
+    const auto l = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(x), false, false);
+    lo = __hiloint2double(h[0], l[0]);
+    up = __hiloint2double(h[1], l[1]);
 }
 
 constexpr int S7_AHEAD = 1;         // batches (one row pair = 8 FMAs + 2 reads) of LDS look-ahead
@@ -1176,17 +1180,18 @@ k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     const double *__restrict__ gg = has_g ? diag_ + (size_t)pr * diag_bs + g0 : yg;
     double *__restrict__ dg = d_ + pb;
     double *__restrict__ zg = z_ + pb;
-    // chunk-mode row stores (row vectors of 64, columns 2c, 2c + 1 from the lanes of half-wave 0)
-    double2 *__restrict__ rg = r_out ? (double2 *)(r_out + pb * 64) + c : nullptr;
-    double2 *__restrict__ ug = Ut_out ? (double2 *)(Ut_out + pb * 64) + c : nullptr;
-    double2 *__restrict__ wg = Wt_out ? (double2 *)(Wt_out + pb * 64) + c : nullptr;
+    const int own = 2 * c + g;                      // the column whose row-vector entries this lane carries
+    // chunk-mode row stores: loop-invariant per-lane pointers, indexed with opaque_uniform(row)
+    double *__restrict__ rg = r_out ? r_out + pb * 64 + own : nullptr;
+    double *__restrict__ ug = Ut_out ? Ut_out + pb * 64 + own : nullptr;
+    double *__restrict__ wg = Wt_out ? Wt_out + pb * 64 + own : nullptr;
     double *__restrict__ eg = de_out ? de_out + pb : nullptr;
     double *__restrict__ Sg = S_state + (size_t)b * (64 * 64);     // [column][row]
     double *__restrict__ Fg = F_state + (size_t)b * 64;
     const double diag_add = diag_add_[pr];
 
-    RowGen G;                                       // this lane generates term c (its cos column's lane)
-    G.init(2 * c, pr, Jr, Jc, block_sub, gap, ar_, cr_, ac_, bc_, cc_, dc_, cmax_, tg, g0);
+    RowGen G;                                       // this lane generates its own column, as in k_factor3
+    G.init(own, pr, Jr, Jc, block_sub, gap, ar_, cr_, ac_, bc_, cc_, dc_, cmax_, tg, g0);
     const double cj = G.cj;
 
     __shared__ __attribute__((aligned(16))) double s_w[64];     // r_{n-1}  (pending update, row form)
@@ -1195,7 +1200,8 @@ k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     const double2 *pw = (const double2 *)s_w + g, *pu = (const double2 *)s_u + g;
     const double2 *pe = (const double2 *)s_e + g;
     const bool f31 = c == 31;                       // block 31: pad column 62, forward solve in 63
-    const double not31 = f31 ? 0.0 : 1.0, is31 = f31 ? 1.0 : 0.0;
+    const bool fl = lane == 63;                     // own column 63: the forward solve
+    const double not63 = fl ? 0.0 : 1.0, is63 = fl ? 1.0 : 0.0;
 
     // this lane's two columns in memory, from its first row on (column 63 lives in F_state)
     double *__restrict__ col0 = Sg + (size_t)(2 * c) * 64 + 2 * g;
@@ -1212,30 +1218,28 @@ k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     double t_n1 = tg[1], t_n2 = tg[2];
     double y_n = yg[0], y_n1 = yg[1];
     double g_n = gg[0], g_n1 = gg[1];
-    double u0, u1, v0, v1, de;
+    double ut, vt, de;
     bool rst;
-    G.advance(tg[0], g0, rst, de);
-    G.emit2(u0, u1, v0, v1);
+    G.next(tg[0], g0, ut, vt, rst, de);
 
     double2 ub[S7_AHEAD + 1], wb[S7_AHEAD + 1];
-    if (g == 0) {
-        ((double2 *)s_w)[c] = make_double2(0.0, 0.0);
-        ((double2 *)s_u)[c] = make_double2(u0, u1);
-    }
+    s_w[own] = 0.0;
+    s_u[own] = ut;
     wave_lds_fence();
     sweep7_preload<ROWS>(ub, wb, pu, pw);
 
     for (int64_t n = 0; n < rows; ++n) {
         const double a_n = (has_g ? g_n : 0.0) + diag_add, yy = y_n;
-        const double u0c = u0, u1c = u1, v0c = v0, v1c = v1;
+        const double ut_c = ut, vt_c = vt;
         if (eg && lane == 0) eg[n] = rst ? de : -1.0;
         if (rst) {                          // wave-uniform: fold the pending update, then decay
-            const double el = fm_exp(-cj * de);     // pad block: cj = 0 -> 1 (both columns)
-            if (g == 0) ((double2 *)s_e)[c] = make_double2(el, el);
+            const double el = fm_exp(-cj * de);     // pad columns: cj = 0 -> 1
+            s_e[own] = el;
             wave_lds_fence();
-            double d0, d1;
+            double d0, d1, el0, el1;
+            both_halves(el, el0, el1);              // decays of this lane's two state columns
             sweep7_preload<ROWS>(ub, wb, pe, pw);
-            sweep7_run<ROWS, true>(T, ub, wb, pe, pw, q0, q1, el, el, d0, d1);
+            sweep7_run<ROWS, true>(T, ub, wb, pe, pw, q0, q1, el0, el1, d0, d1);
             sweep7_preload<ROWS>(ub, wb, pu, pw);
             q0 = 0.0;
             q1 = 0.0;
@@ -1244,31 +1248,20 @@ k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
         double acc0, acc1;
         sweep7_run<ROWS, false>(T, ub, wb, pu, pw, q0, q1, 0.0, 0.0, acc0, acc1);
         __builtin_amdgcn_s_setprio(GF_CHAIN_PRIO);
-        const double tmp0 = xhalf_sum(acc0), tmp1 = xhalf_sum(acc1);
-        const double r0 = v0c - tmp0, r1 = (v1c - tmp1) * not31;
-        G.advance(t_n1, g0 + n + 1, rst, de);
-        G.emit2(u0, u1, v0, v1);
+        const double tmp = own_column_sum(acc0, acc1);
+        const double r = (vt_c - tmp) * not63;
+        G.next(t_n1, g0 + n + 1, ut, vt, rst, de);
         t_n1 = t_n2; y_n = y_n1; g_n = g_n1;
         t_n2 = tg[n + 3];
         y_n1 = yg[n + 2];
         g_n1 = gg[n + 2];
         wave_lds_fence();
-        if (g == 0) {
-            ((double2 *)s_w)[c] = make_double2(r0, r1);
-            ((double2 *)s_u)[c] = make_double2(u0, u1);
-        }
+        s_w[own] = r;
+        s_u[own] = ut;
         wave_lds_fence();
         sweep7_preload<ROWS>(ub, wb, pu, pw);
-        // u~ . tmp over the 32 column blocks (both half-waves hold the same values): 16-lane row
-        // sums, then row 1 += row 0 -> lane 31 holds the total
-        double x = fma(u0c, tmp0, u1c * tmp1);      // u~ = 0 in the pad / forward-solve columns
-        x += dpp_get<0xB1, 0xf>(x);
-        x += dpp_get<0x4E, 0xf>(x);
-        x += dpp_get<0x141, 0xf>(x);
-        x += dpp_get<0x140, 0xf>(x);
-        x += dpp_get<0x142, 0xf>(x);
-        const double s1 = read_lane(x, 31);
-        const double s2 = read_lane(tmp1, 31);      // u~ . F~ (column 63)
+        const double s1 = wave_sum(ut_c * tmp);     // u~ = 0 in the pad / forward-solve columns
+        const double s2 = read_lane(tmp, 63);       // u~ . F~ (column 63)
         const double dn = a_n - s1;
         const double zn = yy - s2;
         if (!(dn > 0.0)) {
@@ -1277,13 +1270,11 @@ k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
             break;
         }
         const double inv = fast_rcp(dn);
-        q0 = r0 * inv;
-        q1 = fma(zn, is31, r1) * inv;               // column 63: z / d (r is 0 there)
-        if (g == 0) {
-            const size_t ro = opaque_uniform((size_t)n * 32);
-            if (rg) rg[ro] = make_double2(r0, r1);  // r~ rows for k_phi (chunk mode)
-            if (ug) { ug[ro] = make_double2(u0c, u1c); wg[ro] = make_double2(q0, f31 ? 0.0 : q1); }
-        }
+        const double q = fma(zn, is63, r) * inv;    // own column; column 63: z / d (r is 0 there)
+        both_halves(q, q0, q1);                     // multipliers of this lane's two state columns
+        const size_t ro = opaque_uniform((size_t)n * 64);
+        if (rg) rg[ro] = r;                         // r~ rows for k_phi (chunk mode)
+        if (ug) { ug[ro] = ut_c; wg[ro] = fl ? 0.0 : q; }
         if (lane == 0) { dg[n] = dn; zg[n] = zn; }
     }
     if (fail) {
