@@ -1201,7 +1201,7 @@ k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     const double2 *pe = (const double2 *)s_e + g;
     const bool f31 = c == 31;                       // block 31: pad column 62, forward solve in 63
     const bool fl = lane == 63;                     // own column 63: the forward solve
-    const double not63 = fl ? 0.0 : 1.0, is63 = fl ? 1.0 : 0.0;
+    const double not63 = fl ? 0.0 : 1.0, is31 = f31 ? 1.0 : 0.0;
 
     // this lane's two columns in memory, from its first row on (column 63 lives in F_state)
     double *__restrict__ col0 = Sg + (size_t)(2 * c) * 64 + 2 * g;
@@ -1250,6 +1250,8 @@ k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
         __builtin_amdgcn_s_setprio(GF_CHAIN_PRIO);
         const double tmp = own_column_sum(acc0, acc1);
         const double r = (vt_c - tmp) * not63;
+        double r0, r1;
+        both_halves(r, r0, r1);                     // r of this lane's two state columns: off the d-chain
         G.next(t_n1, g0 + n + 1, ut, vt, rst, de);
         t_n1 = t_n2; y_n = y_n1; g_n = g_n1;
         t_n2 = tg[n + 3];
@@ -1270,11 +1272,11 @@ k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
             break;
         }
         const double inv = fast_rcp(dn);
-        const double q = fma(zn, is63, r) * inv;    // own column; column 63: z / d (r is 0 there)
-        both_halves(q, q0, q1);                     // multipliers of this lane's two state columns
+        q0 = r0 * inv;                              // multipliers of this lane's two state columns;
+        q1 = fma(zn, is31, r1) * inv;               // column 63: z / d (r is 0 there)
         const size_t ro = opaque_uniform((size_t)n * 64);
         if (rg) rg[ro] = r;                         // r~ rows for k_phi (chunk mode)
-        if (ug) { ug[ro] = ut_c; wg[ro] = fl ? 0.0 : q; }
+        if (ug) { ug[ro] = ut_c; wg[ro] = r * inv; }
         if (lane == 0) { dg[n] = dn; zg[n] = zn; }
     }
     if (fail) {
