@@ -52,3 +52,15 @@ def test_grid_drift_reorders_by_time():
     k = int(np.flatnonzero(tt == 8.0)[0])
     assert tt[k + 1] == 8.2          # the missing cadence comes BEFORE the late point
     assert ff[k] == np.interp(8.0, t, f) and t[6] < 8.0 < t[7]
+
+
+def test_product_function_validates_before_touching_the_device():
+    """gadfly_amd.interpolate_missing_data rejects malformed input on the host (no GPU needed)."""
+    import pytest
+    import gadfly_amd
+    with pytest.raises(ValueError):
+        gadfly_amd.interpolate_missing_data(np.array([0.0, 2.0, 1.0]), np.zeros(3))
+    with pytest.raises(ValueError):
+        gadfly_amd.interpolate_missing_data(np.arange(4.0), np.zeros(3))
+    with pytest.raises(ValueError):
+        gadfly_amd.interpolate_missing_data(np.arange(4.0), np.zeros(4), cadences=np.arange(3))

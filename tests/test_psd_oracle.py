@@ -79,3 +79,24 @@ def test_batch_of_series():
         _, s1, e1 = psd_ref.bin_power_lookup(freq, power[r], bins=12)
         np.testing.assert_allclose(s[r], s1, rtol=1e-12)
         np.testing.assert_allclose(e[r], e1, rtol=1e-12)
+
+
+def test_power_spectrum_host_methods():
+    """Container methods of gadfly_amd.PowerSpectrum that need no device
+    (reference psd.py:397-421, :611-650)."""
+    import gadfly_amd
+    flux, d = _series(2048, 11)
+    freq, power, norm = psd_ref.fft_power(flux, d)
+    ps = gadfly_amd.PowerSpectrum(freq, power, name="lc", norm=norm)
+    np.testing.assert_array_equal(ps.omega, 2 * np.pi * freq)
+    np.testing.assert_allclose(ps.light_curve_rms, (power * norm) ** 0.5, rtol=1e-15)
+    cut = ps.cutout(100.0, 2000.0)
+    keep = (freq >= 100.0) & (freq <= 2000.0)
+    np.testing.assert_array_equal(cut.frequency, freq[keep])
+    np.testing.assert_array_equal(cut.power, power[keep])
+    assert cut.name == "lc (cutout)" and cut.norm == norm and cut.error is None
+    both = gadfly_amd.PowerSpectrum(freq, np.stack([power, 2 * power]), error=np.stack([power, power]))
+    c2 = both.cutout(frequency_max=500.0)
+    assert c2.power.shape == (2, (freq <= 500.0).sum()) and c2.error.shape == c2.power.shape
+    with pytest.raises(NotImplementedError):
+        ps.plot()
