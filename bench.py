@@ -113,8 +113,25 @@ def main():
     ev = gadfly_amd.BatchedLogLikelihood(walkers(0), t, y, yerr=yerr, device=device,
                                          tile_rows=args.tile_rows,
                                          overlap_build=args.overlap)
-    packs = [ev.pack(walkers(s)) for s in range(nsteps)]
+    # what a sampler hands over per step: (E, J) arrays of proposed hyperparameters.  The celerite
+    # coefficient algebra of the E kernels and its upload are part of every
+    # evaluation and run INSIDE the timed region (vectorised: gadfly_amd.batch.sho_coefficient_pack)
+    delta = walkers(0)[0].delta                     # the kernels' exposure in 1/uHz
+
+    def proposals(step):
+        ids = [(rank * 1000003 + step * E + e) for e in range(E)]
+        hps = [jitter_hyperparameters(base, 1000 + i) for i in ids]
+        return tuple(np.array([[p["hyperparameters"][k] for p in hp] for hp in hps])
+                     for k in ("S0", "w0", "Q"))
+
+    params = [proposals(s) for s in range(nsteps)]
     eng = ev.engine
+    ref_pack, vec_pack = ev.pack(walkers(0)), ev.pack_parameters(*params[0], delta)
+    for a, b in zip(ref_pack[:5], vec_pack[:5]):        # same numbers as the per-object path
+        a = a if isinstance(a, (tuple, list)) else (a,)
+        b = b if isinstance(b, (tuple, list)) else (b,)
+        if not all(bool(torch.equal(x, y)) for x, y in zip(a, b)):
+            raise SystemExit("vectorised coefficient pack differs from the per-kernel path")
     if args.kernel == "fused":
         eng.lib.gf_set_pipelined(4)
     elif args.kernel == "pipelined":
@@ -135,7 +152,7 @@ def main():
 
     outs = []
     for s in range(args.warmup):
-        outs.append(ev.evaluate_device(packs[s]))
+        outs.append(ev.evaluate_device(ev.pack_parameters(*params[s], delta)))
     torch.cuda.synchronize()
     gen_cond = None
     if args.generator_period == 0 and args.warmup > 0:
@@ -146,7 +163,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.warmup, nsteps):
-        outs.append(ev.evaluate_device(packs[s]))
+        outs.append(ev.evaluate_device(ev.pack_parameters(*params[s], delta)))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -187,7 +204,7 @@ def main():
             "workload": f"single solar-like light curve N={N}, J={J} SHO terms (celerite "
                         f"width {W}), 60 s cadence, yerr=30 ppm; {E} independent evaluation(s) "
                         "(MCMC-walker style, fresh hyperparameters each) per rank per step, "
-                        "each = build + factor + solve + reduce; time axis streamed in tiles of "
+                        "each = coefficient algebra + build + factor + solve + reduce; time axis streamed in tiles of "
                         f"{args.tile_rows} rows",
             "N": N, "J": J, "W": W, "evals_per_rank_per_step": E,
             "tile_rows": args.tile_rows, "generator_period": int(eng.generator_period),

@@ -14,7 +14,63 @@ import numpy as np
 
 from .engine import StreamingBatch
 
-__all__ = ["BatchedLogLikelihood", "log_likelihood_batch"]
+__all__ = ["BatchedLogLikelihood", "log_likelihood_batch", "sho_coefficient_pack"]
+
+
+def sho_coefficient_pack(S0, w0, Q, delta, eps=1e-5):
+    """
+    Celerite coefficients of B exposure-integrated sums of J SHO terms at once: the term algebra of
+    ``TermConvolution(TermSum(SHOTerm x J), delta)`` (what ``StellarOscillatorKernel`` is,
+    /root/reference/gadfly/core.py:371-394) vectorised over the batch,
+    so that a sampler proposing hyperparameter arrays does not build B x J Python objects per step
+    (1.5 s for 2048 walkers of 30 terms against a millisecond here).
+
+    ``S0, w0, Q``: arrays of shape (B, J); ``delta``: exposure in 1/uHz (scalar or (B,)).  Terms with
+    Q < 1/2 become two real exponentials each, so the overdamped pattern must be the same for every
+    problem of the batch.  Returns ``(Jr, Jc, real, comp, diag_add, c)`` in the layout of the
+    per-object path (:func:`gadfly_amd.engine._coeff_pack`), with identical values.
+    """
+    S0, w0, Q = (np.atleast_2d(np.asarray(v, dtype=np.float64)) for v in (S0, w0, Q))
+    if not (S0.shape == w0.shape == Q.shape):
+        raise ValueError("dimension mismatch")
+    B = S0.shape[0]
+    over = Q < 0.5
+    if np.any(over != over[0]):
+        raise ValueError("all problems of a batch must share the term structure "
+                         "(the same terms overdamped, Q < 1/2, in every problem)")
+    over = over[0]
+    und = ~over
+    delta = np.broadcast_to(np.asarray(delta, dtype=np.float64), (B,))[:, None]
+    # overdamped terms: two real exponentials each, in term order (SHOTerm.get_coefficients)
+    So, wo, Qo = S0[:, over], w0[:, over], Q[:, over]
+    f = np.sqrt(np.maximum(1.0 - 4.0 * Qo * Qo, eps))
+    amp = 0.5 * So * wo * Qo
+    ar = np.stack([amp * (1.0 + 1.0 / f), amp * (1.0 - 1.0 / f)], axis=-1).reshape(B, -1)
+    cr = np.stack([0.5 * wo / Qo * (1.0 - f), 0.5 * wo / Qo * (1.0 + f)], axis=-1).reshape(B, -1)
+    # underdamped terms (Q == 1/2 lands here with f = sqrt(eps))
+    Su, wu, Qu = S0[:, und], w0[:, und], Q[:, und]
+    f = np.sqrt(np.maximum(4.0 * Qu * Qu - 1.0, eps))
+    a = Su * wu * Qu
+    cc = 0.5 * wu / Qu
+    # exposure integration (TermConvolution.get_coefficients / get_diag_shift), complex form
+    A = np.concatenate([ar.astype(np.complex128), a - 1j * (a / f)], axis=1)
+    z = np.concatenate([cr.astype(np.complex128), cc - 1j * (cc * f)], axis=1)
+    zd = z * delta
+    with np.errstate(over="ignore", invalid="ignore"):
+        Ap = 2.0 * A * (np.cosh(zd) - 1.0) / zd ** 2
+        shift = np.sum((2.0 * A * (zd - np.sinh(zd)) / zd ** 2).real, axis=1)
+    Jr, Jc = ar.shape[1], a.shape[1]
+    real = np.zeros((2, B, max(Jr, 1)))
+    comp = np.zeros((4, B, max(Jc, 1)))
+    real[0, :, :Jr], real[1, :, :Jr] = Ap[:, :Jr].real, z[:, :Jr].real
+    comp[0, :, :Jc], comp[1, :, :Jc] = Ap[:, Jr:].real, -Ap[:, Jr:].imag
+    comp[2, :, :Jc], comp[3, :, :Jc] = z[:, Jr:].real, -z[:, Jr:].imag
+    diag_add = np.sum(real[0, :, :Jr], axis=1) + np.sum(comp[0, :, :Jc], axis=1) + shift
+    c = np.zeros((B, Jr + 2 * Jc))
+    c[:, :Jr] = real[1, :, :Jr]
+    c[:, Jr::2] = comp[2, :, :Jc]
+    c[:, Jr + 1::2] = comp[2, :, :Jc]
+    return Jr, Jc, real, comp, diag_add, c
 
 
 class BatchedLogLikelihood:
@@ -53,6 +109,15 @@ class BatchedLogLikelihood:
     def pack(self, kernels):
         return self.engine.pack_coefficients(
             [k.get_device_coefficients() for k in kernels])
+
+    def pack_parameters(self, S0, w0, Q, delta):
+        """Coefficient pack straight from (B, J) hyperparameter arrays (:func:`sho_coefficient_pack`):
+        the vectorised form of :meth:`pack` for ``StellarOscillatorKernel``-type kernels."""
+        Jr, Jc, real, comp, diag_add, c = sho_coefficient_pack(S0, w0, Q, delta)
+        eng = self.engine
+        if (Jr, Jc) != (eng.Jr, eng.Jc) or real.shape[1] != eng.B:
+            raise ValueError("coefficient pack does not match the batch structure")
+        return eng._make_pack(real, comp, diag_add, c)
 
     def evaluate_device(self, pack=None):
         """Enqueue one evaluation per problem; returns the (B,) device tensor."""

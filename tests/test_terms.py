@@ -149,3 +149,30 @@ def test_solar_kernel_for_star():
     from gadfly_amd import scale
     assert np.isclose(np.median(w) / np.median(2 * np.pi * nu),
                       scale.nu_max(1.2, 6000.0, 1.5), rtol=0.1)
+
+
+def test_vectorised_sho_pack_equals_per_kernel_path():
+    """gadfly_amd.batch.sho_coefficient_pack (the term algebra of B kernels at once)
+    gives the numbers of the per-object path, overdamped and Q = 1/2 terms included."""
+    from gadfly_amd.batch import sho_coefficient_pack
+    from gadfly_amd.engine import _coeff_pack
+    from gadfly_amd.terms import SHOTerm, TermSum, TermConvolution
+    rng = np.random.default_rng(0)
+    B, J = 16, 9
+    S0 = np.exp(rng.uniform(-2, 4, (B, J)))
+    w0 = np.exp(rng.uniform(0, 8, (B, J)))
+    Q = np.exp(rng.uniform(np.log(0.5), 5, (B, J)))
+    Q[:, 2] = rng.uniform(0.05, 0.45, B)
+    Q[:, 7] = rng.uniform(0.05, 0.45, B)
+    Q[:, 4] = 0.5
+    delta = 60e-6
+    ks = [TermConvolution(TermSum(*[SHOTerm(S0=S0[b, j], w0=w0[b, j], Q=Q[b, j]) for j in range(J)]), delta)
+          for b in range(B)]
+    ref = _coeff_pack([k.get_device_coefficients() for k in ks])
+    got = sho_coefficient_pack(S0, w0, Q, delta)
+    assert got[:2] == ref[:2] == (4, 7)
+    for a, b in zip(ref[2:], got[2:]):
+        np.testing.assert_array_equal(a, b)
+    Q[3, 0] = 0.3                      # a different overdamped pattern in one problem
+    with pytest.raises(ValueError):
+        sho_coefficient_pack(S0, w0, Q, delta)
