@@ -112,6 +112,13 @@ def load():
             "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
             "gadfly_amd has no CPU fallback."
         )
+    # The library links against libamdhip64; PyTorch ships its own copy of that runtime.  Whichever is
+    # loaded first serves both, and device buffers made by one runtime are unknown to the other (kernel
+    # launches then fail with "no ROCm-capable device"): load torch's runtime first, always.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(SO_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a symbol is missing
