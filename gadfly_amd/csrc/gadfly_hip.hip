@@ -1292,6 +1292,108 @@ k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     }
 }
 
+// k_phi in k_factor7's lane tiling (same arguments and results as k_phi; Jr = 0, Jc <= 31): the
+// closed-loop transition sweep reads half the LDS operands per FMA as well.
+template <int ROWS>
+__global__ void __launch_bounds__(64, 2)
+k_phi7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int nch,
+      const int Jr, const int Jc, const int block_sub, const double gap,
+      const double *__restrict__ ar_, const double *__restrict__ cr_,
+      const double *__restrict__ ac_, const double *__restrict__ bc_,
+      const double *__restrict__ cc_, const double *__restrict__ dc_,
+      const double *__restrict__ cmax_,
+      const double *__restrict__ t_, const int64_t t_bs,
+      const double *__restrict__ dbar_, const double *__restrict__ rbar_,
+      double *__restrict__ h_out, double *__restrict__ Phi_out) {
+    const int lane = threadIdx.x;
+    const int g = lane >> 5, c = lane & 31, own = 2 * c + g;    // k_factor7's tiling: state columns 2c, 2c + 1
+    const int b = blockIdx.x;                                   // of half the rows; row vectors: column `own`
+    const int pr = b / nch, ch = b - pr * nch;
+    const int64_t c0 = (int64_t)ch * chunk_len;
+    const int64_t rows = (N - c0 < chunk_len) ? (N - c0) : chunk_len;
+    const int64_t g0 = n_first + c0;
+    const size_t pb = (size_t)pr * N + c0;
+    const double *__restrict__ tg = t_ + (size_t)pr * t_bs + g0;
+    const double *__restrict__ dg = dbar_ + pb;
+    const double *__restrict__ rg = rbar_ + pb * 64 + own;
+    double *__restrict__ hg = h_out + pb * 64 + own;
+    double *__restrict__ col0 = Phi_out + (size_t)b * (64 * 64) + (size_t)(2 * c) * 64 + 2 * g;
+    double *__restrict__ col1 = col0 + 64;
+
+    RowGen G;
+    G.init(own, pr, Jr, Jc, block_sub, gap, ar_, cr_, ac_, bc_, cc_, dc_, cmax_, tg, g0);
+    const double cj = G.cj;
+
+    __shared__ __attribute__((aligned(16))) double s_w[64], s_u[64], s_e[64];
+    const double2 *pw = (const double2 *)s_w + g, *pu = (const double2 *)s_u + g;
+    const double2 *pe = (const double2 *)s_e + g;
+    double T[ROWS / 2][2];
+#pragma unroll
+    for (int m = 0; m < ROWS / 2; ++m) {                        // Phi = I
+        const int row = 4 * (m >> 1) + 2 * g + (m & 1);
+        T[m][0] = (row == 2 * c) ? 1.0 : 0.0;
+        T[m][1] = (row == 2 * c + 1) ? 1.0 : 0.0;
+    }
+    double q0 = 0.0, q1 = 0.0;
+
+    double t_n1 = tg[1], t_n2 = tg[2];
+    double d_n = dg[0], d_n1 = dg[1];               // dbar, rbar are padded by the caller
+    double r_n = rg[0], r_n1 = rg[64];
+    double ut, vt, de;
+    bool rst;
+    G.next(tg[0], g0, ut, vt, rst, de);
+
+    double2 ub[S7_AHEAD + 1], wb[S7_AHEAD + 1];
+    s_w[own] = 0.0;
+    s_u[own] = ut;
+    wave_lds_fence();
+    sweep7_preload<ROWS>(ub, wb, pu, pw);
+
+    for (int64_t n = 0; n < rows; ++n) {
+        const double dcur = d_n, rcur = r_n;
+        if (rst) {                          // Phi <- E (Phi + pending): row scaling only
+            const double el = fm_exp(-cj * de);
+            s_e[own] = el;
+            wave_lds_fence();
+            double d0, d1;
+            sweep7_preload<ROWS>(ub, wb, pe, pw);
+            sweep7_run<ROWS, true>(T, ub, wb, pe, pw, q0, q1, 1.0, 1.0, d0, d1);
+            sweep7_preload<ROWS>(ub, wb, pu, pw);
+            q0 = 0.0;
+            q1 = 0.0;
+        }
+        double acc0, acc1;
+        sweep7_run<ROWS, false>(T, ub, wb, pu, pw, q0, q1, 0.0, 0.0, acc0, acc1);
+        const double h = own_column_sum(acc0, acc1);
+        hg[(size_t)n * 64] = h;
+        G.next(t_n1, g0 + n + 1, ut, vt, rst, de);
+        t_n1 = t_n2;
+        t_n2 = tg[n + 3];
+        d_n = d_n1; r_n = r_n1;
+        d_n1 = dg[n + 2];
+        r_n1 = rg[(size_t)(n + 2) * 64];
+        wave_lds_fence();
+        s_w[own] = rcur;                    // pending: Phi_i -= (r_i / d) h_j
+        s_u[own] = ut;
+        wave_lds_fence();
+        sweep7_preload<ROWS>(ub, wb, pu, pw);
+        both_halves(-h / dcur, q0, q1);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int m = 0; m < ROWS / 2; ++m) {
+        const int ro = 4 * (m >> 1) + (m & 1);
+        const double w = s_w[2 * g + ro];
+        col0[ro] = fma(w, q0, T[m][0]);
+        col1[ro] = fma(w, q1, T[m][1]);
+    }
+#pragma unroll
+    for (int k2 = ROWS / 4; k2 < 16; ++k2) {                    // rows past ROWS: zero
+        col0[4 * k2] = 0.0; col0[4 * k2 + 1] = 0.0;
+        col1[4 * k2] = 0.0; col1[4 * k2 + 1] = 0.0;
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // k_factor6: k_factor3 with the sweep SPLIT so that half of it runs under the row's serial chain.
 //
@@ -4404,7 +4506,8 @@ int gf_chunk_sweep(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc,
                         Ut_out, Wt_out, de_out, S_state, F_state, info, stream);
 }
 
-#define GF_PHI_CASE(R) case R: hipLaunchKernelGGL((k_phi<R>), dim3(B * nch), dim3(64), 0, st, N, (int64_t)0, chunk_len, nch, Jr, Jc, (block | (g_gen_period << 8)), gap, ar, cr, ac, bc, cc, dc, cmax, t, t_bs, dbar, rbar, h_out, Phi_out); break;
+#define GF_PHI_ARGS dim3(B * nch), dim3(64), 0, st, N, (int64_t)0, chunk_len, nch, Jr, Jc, (block | (g_gen_period << 8)), gap, ar, cr, ac, bc, cc, dc, cmax, t, t_bs, dbar, rbar, h_out, Phi_out
+#define GF_PHI_CASE(R) case R: if ((g_pipelined == 0 || g_pipelined == 3) && Jr == 0 && Jc <= 31) hipLaunchKernelGGL((k_phi7<R>), GF_PHI_ARGS); else hipLaunchKernelGGL((k_phi<R>), GF_PHI_ARGS); break;
 
 int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc, int block,
                         const double *ar, const double *cr, const double *ac,
