@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Latency of the drop-in GaussianProcess API on BASELINE.json's single-series configs:
 cfg2 (N=1e6, J=30: compute, log_likelihood, predict) and cfg5 (N=5e5, J=30: sample(size=64)).
-With --cpu the oracle's C restatement is timed beside it on one host core."""
+(The CPU side of the comparison is bench.py's cpu_baseline leg.)"""
 import os
 import sys
 import time
@@ -24,7 +24,6 @@ def clock(fn, reps=3):
 
 
 def main():
-    cpu = "--cpu" in sys.argv
     J = 30
     k = gadfly_amd.StellarOscillatorKernel(solar_like_hyperparameters(J), texp=60.0)
     rng = np.random.Generator(np.random.PCG64(12345))
@@ -43,12 +42,6 @@ def main():
     ts = np.sort(rng.uniform(t[0], t[-1], 1000))
     ms, mus = clock(lambda: gp.predict(y, t=ts), reps=2)
     print(f"cfg2 N={N} J={J}: predict(y, t*=1000)  {ms:9.1f} ms")
-    if cpu:
-        from oracle import cref
-        co = k.get_device_coefficients()
-        t0 = time.perf_counter()
-        ref, _ = cref.loglike(co[:6], t, np.full(N, 900.0) + co[6], y)
-        print(f"     CPU port (1 core): build+factor+solve {1e3*(time.perf_counter()-t0):9.1f} ms  rel diff {abs(ll-ref)/abs(ref):.1e}")
     del gp
     torch.cuda.empty_cache()
     # ---- cfg5 ----
