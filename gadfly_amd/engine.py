@@ -745,6 +745,9 @@ class StreamingBatch:
             _lib.check(rc, "gf_chunk_sweep")
             transition()
             self._tp_combine(w, nch, st)
+            # a nominal pass (zero start state: pivots >= the true ones) can only fail at or after
+            # the true failing row; the final pass decides, from exact start states up to there
+            w["info"].zero_()
         stores = (p(w["Ut"]), p(w["Wt"]), p(w["de"])) if store else none3
         rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, self.Jr, self.Jc, block, *coeffs,
                                 p(diag_add), p(cmax), *tyd, p(w["d"]), p(w["z"]),
@@ -755,8 +758,12 @@ class StreamingBatch:
             transition("PhiT")              # on the TRUE rows: the true chunk transitions
         rc = lib.gf_reduce_tile(B, N, p(w["d"]), p(w["z"]), p(w["work"]), p(w["acc"]), 1, st)
         _lib.check(rc, "gf_reduce_tile")
-        # a chunk that failed marks its problem
-        self.info.copy_(w["info"].view(B, nch).max(dim=1).values)
+        # a chunk that failed marks its problem with the FIRST non-positive pivot (celerite2 and the
+        # sequential sweep stop there; chunks after a failed one ran from meaningless start states)
+        ci = w["info"].view(B, nch)
+        big = torch.iinfo(torch.int32).max
+        first = torch.where(ci != 0, ci, torch.full_like(ci, big)).min(dim=1).values
+        self.info.copy_(torch.where(first == big, torch.zeros_like(first), first))
         out = torch.empty((B,), **f64)
         rc = lib.gf_loglike_finish(B, N, p(w["acc"]), p(self.info), p(out), None, st)
         _lib.check(rc, "gf_loglike_finish")

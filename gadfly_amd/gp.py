@@ -305,8 +305,6 @@ class GaussianProcess:
         elif diag is not None:
             self._diag += np.broadcast_to(np.asarray(diag, dtype=np.float64), (N,))
 
-        self._factor = None            # stored-factor engine, built on first need
-        self._fast = None              # fused / time-parallel log-likelihood engine
         self._do_compute(quiet)
 
     def recompute(self, *, quiet=False):
@@ -335,6 +333,10 @@ class GaussianProcess:
         return self._factor
 
     def _do_compute(self, quiet):
+        # celerite2's recompute() refactorises everything: a stored factor of the previous kernel
+        # must not survive (apply_inverse / dot_tril / predict / sample rebuild it on first need)
+        self._factor = None
+        self._fast = None
         co = self.kernel.get_device_coefficients()
         W = len(co[0]) + 2 * len(co[2])
         fast = None
@@ -353,7 +355,6 @@ class GaussianProcess:
             _, logdet = fast.evaluate()
             info = fast.info
         else:
-            self._factor = None
             eng = DeviceBatch([co], self._t, diag=self._diag, device=self._device)
             self._factor = eng
             info = eng.factor(keep_W=True)

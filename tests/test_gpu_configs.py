@@ -1,0 +1,185 @@
+"""
+GPU parity at the BATCHED shapes of BASELINE.json's configs 3, 4 and 5, against the
+oracle's C restatement (oracle/cref.py) on identical inputs:
+
+  cfg3  batch of light curves, J = 20 (W = 40): own t, y and kernel per problem -> k_factor7<40> with
+        per-problem t / y / diag strides (streamed) and the time-parallel route small batches take;
+  cfg4  MCMC walkers, J = 40 (W = 80): shared t, y, own hyperparameters -> the wide kernels
+        (fused wide sweep / k_build2 + k_factor2w / k_build + k_factor) with B > 1;
+  cfg5  dot_tril of 64 normal vectors, J = 30 (W = 60): multi-right-hand-side chunk sweeps.
+
+Small sizes compare EVERY entry; the full sizes (256 x 65 000, 512 x 200 000, 64 x 500 000) run once
+each and compare sampled entries / columns (an oracle evaluation costs about a second there).
+Bars: log-likelihood 1e-8 relative (north_star), draws 1e-6.
+"""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+RTOL_LL = 1e-8
+TOL_VEC = 1e-6
+
+
+def _relmax(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def _cfg3_problem(B, N, J=20, seed=2000):
+    """B stars = the solar-like kernel with (w0, S0) scaled by nu_max factors log-spaced 0.3..1.0,
+    Kepler short cadence (58.85 s) with per-star time offsets (odd stars: jittered stamps, which
+    the in-kernel row generator must take as exact rows), own y and yerr."""
+    import gadfly_amd
+    from gadfly_amd.synth import solar_like_hyperparameters, scale_hyperparameters
+    base = solar_like_hyperparameters(J)
+    kernels = [gadfly_amd.StellarOscillatorKernel(scale_hyperparameters(base, f), texp=58.85)
+               for f in np.geomspace(0.3, 1.0, B)]
+    rng = np.random.Generator(np.random.PCG64(seed))
+    # own time axis per light curve: same cadence, different start and a little jitter
+    t = np.arange(N)[None, :] * 58.85e-6 + rng.uniform(0.0, 1e-3, (B, 1))
+    t[1::2] += rng.uniform(-2e-7, 2e-7, t[1::2].shape)      # every other star: jittered stamps
+    y = rng.normal(size=(B, N)) * 50.0 + np.cumsum(rng.normal(size=(B, N)), axis=1)
+    yerr = rng.uniform(20.0, 40.0, (B, 1)) * np.ones((1, N))
+    return kernels, t, y, yerr
+
+
+def _cfg4_problem(B, N, J=40, seed=12345):
+    """B walkers: hyperparameters jittered +-10 % (seed 1000 + id) on ONE series (shared t, y)."""
+    import gadfly_amd
+    from gadfly_amd.synth import solar_like_hyperparameters, jitter_hyperparameters
+    base = solar_like_hyperparameters(J)
+    kernels = [gadfly_amd.StellarOscillatorKernel(jitter_hyperparameters(base, 1000 + i), texp=60.0)
+               for i in range(B)]
+    rng = np.random.Generator(np.random.PCG64(seed))
+    t = np.arange(N) * 60e-6
+    y = np.cumsum(rng.normal(size=N)) * 5.0 + 30.0 * rng.normal(size=N)
+    return kernels, t, y
+
+
+def _ref_ll(kernel, t, diag, y):
+    from oracle import cref
+    co = kernel.get_device_coefficients()
+    ref, info = cref.loglike(co[:6], t, diag + co[6], y)
+    assert info == 0
+    return ref
+
+
+# ---------------------------------------------------------------------------------------------
+# cfg3 shape: B > 1 at W = 40 with own t, y, diag per problem
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("route", ["streamed", "chunked"])
+def test_cfg3_shape_every_entry(hip, route):
+    import gadfly_amd
+    B, N = 9, 2100
+    kernels, t, y, yerr = _cfg3_problem(B, N)
+    ev = gadfly_amd.BatchedLogLikelihood(kernels, t, y, yerr=yerr, tile_rows=512)
+    eng = ev.engine
+    assert eng.W == 40 and eng._fused_ok() and eng.t.shape[0] == B and eng.diag.shape[0] == B
+    eng.generator_period = 1
+    if route == "streamed":
+        ll = eng.log_likelihood().cpu().numpy()            # 5 tiles with state hand-off
+    else:
+        ll = eng.log_likelihood_time_parallel(chunk_len=256).cpu().numpy()
+        assert eng._tp_used
+    for i, k in enumerate(kernels):
+        ref = _ref_ll(k, t[i], yerr[i] ** 2, y[i])
+        assert abs(ll[i] - ref) <= RTOL_LL * abs(ref), (route, i, ll[i], ref)
+
+
+def test_cfg3_full_size_sampled(hip):
+    """256 light curves x N = 65 000, J = 20, through the route the product picks (B <= 256 and long
+    series: time-parallel) AND the streamed sweep; entries 0, 100 and 255 against the oracle, all
+    256 between the two routes."""
+    import gadfly_amd
+    B, N = 256, 65_000
+    kernels, t, y, yerr = _cfg3_problem(B, N)
+    ev = gadfly_amd.BatchedLogLikelihood(kernels, t, y, yerr=yerr)
+    ll_tp = ev.evaluate()                                  # auto route + generator calibration
+    assert ev.engine._tp_used
+    ev.engine.force_streaming = True
+    ll_st = ev.evaluate()
+    assert not ev.engine._tp_used
+    assert np.all(np.isfinite(ll_tp)) and np.all(np.isfinite(ll_st))
+    assert np.max(np.abs(ll_tp - ll_st) / np.abs(ll_st)) <= RTOL_LL
+    for i in (0, 100, 255):
+        ref = _ref_ll(kernels[i], t[i], yerr[i] ** 2, y[i])
+        assert abs(ll_tp[i] - ref) <= RTOL_LL * abs(ref), (i, ll_tp[i], ref)
+        assert abs(ll_st[i] - ref) <= RTOL_LL * abs(ref), (i, ll_st[i], ref)
+
+
+# ---------------------------------------------------------------------------------------------
+# cfg4 shape: B > 1 walkers at W = 80 on the wide kernels
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", ["auto", "scaled_wide", "v1"])
+def test_cfg4_shape_every_entry(hip, path):
+    from gadfly_amd.engine import StreamingBatch
+    B, N = 9, 1700
+    kernels, t, y = _cfg4_problem(B, N)
+    diag = np.full(N, 900.0)
+    eng = StreamingBatch([k.get_device_coefficients() for k in kernels], t, y, diag=diag,
+                         tile_rows=512, force_v1=(path == "v1"),
+                         allow_fused=(path == "auto"))
+    assert eng.W == 80 and eng.t.shape[0] == 1
+    if path == "scaled_wide":
+        assert eng.scaled_wide and not eng._fused_ok()
+    if path == "v1":
+        assert not eng.scaled_wide and not eng.scaled
+    eng.generator_period = 1
+    ll = eng.log_likelihood().cpu().numpy()
+    for i, k in enumerate(kernels):
+        ref = _ref_ll(k, t, diag, y)
+        assert abs(ll[i] - ref) <= RTOL_LL * abs(ref), (path, i, ll[i], ref)
+    # second evaluation with fresh coefficient packs (what a sampler does per step)
+    kernels2, _, _ = _cfg4_problem(B, N)
+    pack = eng.pack_coefficients([k.get_device_coefficients() for k in kernels2[::-1]])
+    eng.use_coefficients(pack)
+    ll2 = eng.log_likelihood().cpu().numpy()
+    assert np.max(np.abs(ll2 - ll[::-1]) / np.abs(ll[::-1])) <= 1e-12
+
+
+def test_cfg4_full_size_sampled(hip):
+    """512 walkers x N = 200 000, J = 40 (W = 80), shared t, y: walkers 0 and 511 against the
+    oracle (about 2 s of host time each), all finite."""
+    import gadfly_amd
+    B, N = 512, 200_000
+    kernels, t, y = _cfg4_problem(B, N)
+    ev = gadfly_amd.BatchedLogLikelihood(kernels, t, y, yerr=30.0)
+    ll = ev.evaluate()
+    assert ll.shape == (B,) and np.all(np.isfinite(ll))
+    for i in (0, 511):
+        ref = _ref_ll(kernels[i], t, np.full(N, 900.0), y)
+        assert abs(ll[i] - ref) <= RTOL_LL * abs(ref), (i, ll[i], ref)
+
+
+# ---------------------------------------------------------------------------------------------
+# cfg5: dot_tril of 64 draws at N = 5e5, J = 30
+# ---------------------------------------------------------------------------------------------
+def test_cfg5_full_size_sampled(hip):
+    """GaussianProcess.dot_tril on (5e5, 64) normal vectors: columns 0, 31 and 63 against the
+    oracle's matmul_lower on its own factor; then sample(size=64) with the same vectors through
+    numpy's legacy global RNG reproduces gadfly's mean-subtraction quirk (gp.py:392)."""
+    import gadfly_amd
+    from gadfly_amd.synth import solar_like_hyperparameters, uniform_times
+    from oracle import cref, seq
+    N, J, R = 500_000, 30, 64
+    k = gadfly_amd.StellarOscillatorKernel(solar_like_hyperparameters(J), texp=60.0)
+    t = uniform_times(N, 60.0)
+    gp = gadfly_amd.GaussianProcess(k, t=t, yerr=30.0)
+    np.random.seed(42)
+    n = np.random.randn(N, R)
+    Z = gp.dot_tril(n)
+    assert Z.shape == (N, R) and np.all(np.isfinite(Z))
+    prob = dict(kernel=k, t=t, diag_user=np.full(N, 900.0))
+    c, a, U, V = util.oracle_matrices(prob, seq)
+    d_ref, W_ref, info = cref.factor(t, c, a, U, V)
+    assert info == 0
+    cols = [0, 31, 63]
+    ref = cref.matmul_lower(t, c, U, W_ref, n[:, cols] * np.sqrt(d_ref)[:, None])
+    assert _relmax(Z[:, cols], ref) < TOL_VEC
+    np.random.seed(42)
+    draws = gp.sample(size=R)
+    assert draws.shape == (R, N)
+    want = Z.T - Z.T.mean(axis=0)
+    assert _relmax(draws, want) < 1e-12

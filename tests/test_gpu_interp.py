@@ -36,6 +36,21 @@ def test_matches_numpy_bit_for_bit(hip, n, frac, jitter, with_cadences):
         assert len(tt) == len(t)
 
 
+def _case_names():
+    from tests.interp_cases import CASES
+    return list(CASES)
+
+
+@pytest.mark.parametrize("name", _case_names())
+def test_matches_reference_fixtures(hip, name):
+    """The HIP kernels against the outputs of the REFERENCE's own interpolate_missing_data
+    (tests/golden/interp_reference.npz, made by tests/golden/make_interp_golden.py from
+    /root/reference/gadfly/interp.py): bit-identical times and fluxes."""
+    import gadfly_amd
+    from tests.test_interp_reference import check_against_fixture
+    check_against_fixture(name, gadfly_amd.interpolate_missing_data)
+
+
 def test_full_size_properties_and_device_output(hip):
     """N = 2e6 cadences with 10 % missing: the filled grid is complete and in time order, the input
     points are untouched, new points lie on the chords; the output can stay on the device and feed the

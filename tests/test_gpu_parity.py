@@ -592,3 +592,58 @@ def test_scaled_factor_sweeps(hip, case):
     Yd = torch.as_tensor(Y).cuda().reshape(1, N, 3)
     ref = cref.solve_upper(t, c, U, W_ref, cref.solve_lower(t, c, U, W_ref, Y) / d_ref[:, None])
     assert _relmax(fac1.apply_inverse(Yd)[0].cpu().numpy(), ref) < TOL_VEC
+
+
+def test_recompute_refactorises_everything(hip):
+    """celerite2's recompute() after a kernel change refactorises: apply_inverse / predict / dot_tril
+    must use the NEW kernel's factor (a stored factor of the old kernel survived)."""
+    import gadfly_amd
+    from gadfly_amd.synth import solar_like_hyperparameters, jitter_hyperparameters
+    from oracle import cref, seq
+    prob = util.solar_problem(12, 20000)
+    t, y = prob["t"], prob["y"]
+    gp = gadfly_amd.GaussianProcess(prob["kernel"], t=t, yerr=30.0)
+    old = gp.apply_inverse(y)                       # builds the stored factor of the first kernel
+    assert gp._factor is not None
+    k2 = gadfly_amd.StellarOscillatorKernel(
+        jitter_hyperparameters(solar_like_hyperparameters(12), 77, frac=0.3), texp=60.0)
+    gp.kernel = k2
+    gp.recompute()
+    c, a, U, V = util.oracle_matrices(dict(prob, kernel=k2), seq)
+    d_ref, W_ref, info = cref.factor(t, c, a, U, V)
+    assert info == 0
+    alpha = cref.solve_upper(t, c, U, W_ref, cref.solve_lower(t, c, U, W_ref, y) / d_ref)
+    new = gp.apply_inverse(y)
+    assert _relmax(new, alpha) < TOL_VEC
+    assert _relmax(old, alpha) > 1e-3               # the kernels really differ
+    assert _relmax(gp.predict(y), y - prob["diag_user"] * alpha) < TOL_VEC
+    n = np.random.default_rng(1).normal(size=len(t))
+    assert _relmax(gp.dot_tril(n), cref.matmul_lower(t, c, U, W_ref, n * np.sqrt(d_ref))) < TOL_VEC
+    co = k2.get_device_coefficients()
+    ref, _ = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y)
+    assert abs(gp.log_likelihood(y) - ref) <= RTOL_LL * abs(ref)
+
+
+def test_time_parallel_reports_first_failing_pivot(hip):
+    """A matrix that stops being positive definite part-way: the time-parallel evaluation must name
+    the FIRST non-positive pivot, as celerite2 and the sequential sweep do, although
+    every chunk after it also fails (and fails first in wall-clock order)."""
+    import gadfly_amd
+    from gadfly_amd.engine import StreamingBatch
+    from oracle import seq
+    prob = util.solar_problem(6, 12000)
+    k, t, y = prob["kernel"], prob["t"], prob["y"]
+    bad = prob["diag_user"].copy()
+    bad[5000:] = -2.0 * k.get_value(np.zeros(1))[0]
+    co = k.get_device_coefficients()
+    c, a, U, V = util.oracle_matrices(dict(prob, diag_user=bad), seq)
+    _, _, info_ref = seq.factor(t, c, a, U, V)
+    assert info_ref == 5001
+    eng = StreamingBatch([co], t, y, diag=bad, tile_rows=1024)
+    assert eng.log_likelihood().cpu().numpy()[0] == -np.inf and int(eng.info[0]) == info_ref
+    for L in (256, 1024, 4096):
+        ll = eng.log_likelihood_time_parallel(chunk_len=L).cpu().numpy()
+        assert ll[0] == -np.inf and int(eng.info[0]) == info_ref, (L, int(eng.info[0]))
+    gp = gadfly_amd.GaussianProcess(k)
+    with pytest.raises(gadfly_amd.LinAlgError, match="pivot 5001 "):
+        gp.compute(t, diag=bad)

@@ -176,3 +176,14 @@ def test_vectorised_sho_pack_equals_per_kernel_path():
     Q[3, 0] = 0.3                      # a different overdamped pattern in one problem
     with pytest.raises(ValueError):
         sho_coefficient_pack(S0, w0, Q, delta)
+
+
+@pytest.mark.parametrize("example_freq", [3033.886, 3082.471, 3098.327, 3160.028, 3168.773, 3217.916])
+def test_broomhall_known_frequencies(example_freq):
+    """The reference's own known answers for the p-mode table (/root/reference/gadfly/tests/
+    test_sun.py:7-19): each example frequency is the table entry nearest to it."""
+    from gadfly_amd.synth import broomhall_modes
+    nu, ell = broomhall_modes()
+    assert len(nu) == len(ell) == 81 and set(ell) <= {0, 1, 2, 3}
+    closest = nu[np.argmin(np.abs(nu - example_freq))]
+    np.testing.assert_allclose(example_freq, closest)
