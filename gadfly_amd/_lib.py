@@ -19,6 +19,7 @@ SOURCES = [os.path.join(CSRC, "gadfly_hip.hip")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "gadfly_hip.h")
 
 GF_SOLVE_LOWER, GF_SOLVE_UPPER, GF_MATMUL_LOWER = 0, 1, 2
+GF_SWEEP_AUTO, GF_SWEEP_COLUMN, GF_SWEEP_TILED = 0, 1, 2
 GF_MAX_WIDTH = 256
 
 _lib = None
@@ -45,20 +46,15 @@ SIGNATURES = {
                         + [_vp, _i64, _vp, _i64] + [_vp] * 4 + [_vp]),
     "gf_factor_scaled": (_int, [_int, _i64, _i64, _int, _int] + [_vp] * 5 + [_vp, _i64]
                          + [_vp] * 5 + [_vp]),
-    "gf_loglike_fused": (_int, [_int, _i64, _i64, _int, _int, _int] + [_vp] * 8
+    "gf_loglike_fused": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int] + [_vp] * 8
                          + [_vp, _i64, _vp, _i64, _vp, _i64] + [_vp] * 5 + [_vp]),
-    "gf_set_generator_period": (_int, [_int]),
-    "gf_set_pipelined": (_int, [_int]),
-    "gf_blocked_supported": (_int, [_int, _int, _int]),
-    "gf_loglike_blocked": (_int, [_int, _i64, _i64, _int, _int, _int] + [_vp] * 8
-                         + [_vp, _i64, _vp, _i64, _vp, _i64] + [_vp] * 5 + [_vp]),
-    "gf_chunk_sweep": (_int, [_int, _i64, _i64, _int, _int, _int, _int] + [_vp] * 8
+    "gf_chunk_sweep": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int, _int] + [_vp] * 8
                        + [_vp, _i64, _vp, _i64, _vp, _i64] + [_vp] * 9 + [_vp]),
     "gf_chunk_linear": (_int, [_int, _int, _i64, _i64, _int, _int, _int, _int, _int]
                         + [_vp] * 8 + [_vp]),
     "gf_chunk_linear_combine": (_int, [_int, _int, _i64, _i64, _int, _int, _int] + [_vp] * 5
                                 + [_vp]),
-    "gf_chunk_transition": (_int, [_int, _i64, _i64, _int, _int, _int, _int] + [_vp] * 7
+    "gf_chunk_transition": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int, _int] + [_vp] * 7
                             + [_vp, _i64] + [_vp] * 7 + [_vp]),
     "gf_chunk_combine": (_int, [_int, _int] + [_vp] * 5 + [_vp]),
     "gf_chunk_combine_tree": (_int, [_int, _int] + [_vp] * 7 + [_vp]),

@@ -101,6 +101,10 @@ class BatchedLogLikelihood:
         #: choosing its re-anchoring period from the measured conditioning
         self.generator_target = 1e-9
         self.auto_generator_period = True
+        #: evaluations whose accuracy guard has not been looked at yet: (out, flag, pack, period)
+        self._unresolved = []
+        #: evaluations repeated with exact generator rows by the guard so far
+        self.guard_reruns = 0
 
     @property
     def B(self):
@@ -120,15 +124,62 @@ class BatchedLogLikelihood:
         return eng._make_pack(real, comp, diag_add, c)
 
     def evaluate_device(self, pack=None):
-        """Enqueue one evaluation per problem; returns the (B,) device tensor."""
+        """Enqueue one evaluation per problem; returns the (B,) device tensor (no host sync).
+
+        Accuracy guard (device side): with a generator period > 1 the rows between anchors carry a
+        rotation error that the log-likelihood amplifies by the problem's condition number, and the
+        period was chosen from the conditioning of EARLIER evaluations.  Every evaluation therefore
+        also leaves a flag per problem on the device -- GEN_ERR * period * max(a) / min(d) above the
+        target, from the min pivot its own reduction returns -- and :meth:`resolve` (called by
+        :meth:`evaluate`, :meth:`calibrate`, or by the caller before reading asynchronous results)
+        repeats flagged evaluations with exact rows, writing the corrected values into the tensor
+        returned here.  A walker that wanders into a badly conditioned region is thus never silently
+        evaluated at a period its conditioning does not allow.
+        """
         eng = self.engine
         if pack is not None:
             eng.use_coefficients(pack)
         # small batches of long series are chunked in time as well (exact, see engine.evaluate)
-        return eng.evaluate()[0]
+        out = eng.evaluate()[0]
+        period = int(eng.generator_period)
+        if period > 1 and eng._fused_ok():
+            torch = eng.torch
+            acc = eng._tp["acc"] if getattr(eng, "_tp_used", False) else eng.acc
+            amax = eng._pack[2] if eng.diag is None else eng._pack[2] + eng._diag_amax
+            # a non-positive pivot (failed factorisation: -inf either way) is not an accuracy case
+            flag = (eng.GEN_ERR * period * amax > self.generator_target * acc[:, 2]) & (acc[:, 2] > 0)
+            self._unresolved.append((out, flag, eng._pack, period))
+            if len(self._unresolved) > 64:      # bound the backlog of a caller that never resolves
+                self.resolve()
+        return out
+
+    def resolve(self):
+        """Look at the accuracy guards of all evaluations enqueued since the last call (one host
+        sync) and repeat the flagged ones with exact generator rows, in place.  Returns the number
+        of evaluations repeated."""
+        if not self._unresolved:
+            return 0
+        eng = self.engine
+        torch = eng.torch
+        pending, self._unresolved = self._unresolved, []
+        flags = torch.stack([f for _, f, _, _ in pending]).cpu().numpy()      # the sync
+        redone = 0
+        keep_pack, keep_period = eng._pack, eng.generator_period
+        for (out, flag, pack, _), hit in zip(pending, flags):
+            if not hit.any():
+                continue
+            eng.use_coefficients(pack)
+            eng.generator_period = 1
+            exact = eng.evaluate()[0]
+            out.copy_(torch.where(flag, exact, out))
+            redone += int(hit.sum())
+        eng._pack, eng.generator_period = keep_pack, keep_period
+        self.guard_reruns += redone
+        return redone
 
     def evaluate(self, kernels=None):
         out = self.evaluate_device(None if kernels is None else self.pack(kernels))
+        self.resolve()
         res = out.cpu().numpy()
         if self.auto_generator_period:
             # the result copy synchronised anyway: adapt the generator period of the NEXT
@@ -139,6 +190,7 @@ class BatchedLogLikelihood:
     def calibrate(self):
         """After asynchronous evaluations (:meth:`evaluate_device`): set the generator period
         from the condition estimate of the last one.  Returns (condition, period)."""
+        self.resolve()
         return self.engine.calibrate_generator(self.generator_target)
 
 

@@ -17,6 +17,7 @@
 // No CUDA compatibility layer, no Triton, no CPU fallback.
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <utility>
 #include <type_traits>
 #include <stdint.h>
@@ -1394,912 +1395,17 @@ k_phi7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const in
     }
 }
 
-// ------------------------------------------------------------------------------------
-// k_factor6: k_factor3 with the sweep SPLIT so that half of it runs under the row's serial chain.
-//
-// k_factor3's sweep of row n folds the update of row n-1 and takes the mat-vec in one pass, so it
-// waits for q_{n-1} and the chain (reduction, reciprocal) waits for it.  Here the two halves are
-// separate passes over T:
-//     A_n :  acc   = T u~_n                      (T still lacks the update of row n-1: no q needed)
-//            tmp_n = acc + q_{n-1} sigma_{n-1} ,  sigma_{n-1} = r_{n-1} . u~_n
-//     B_n :  T    += r_{n-1} q_{n-1}^T           (the fold; nothing in row n's chain reads it)
-// B_n's 64 FMAs are issued with row n's chain (d_n, z_n, 1/d_n, q_n, sigma_n) in stages between
-// its batches; the chain then costs latency only where it is longer than the fold.  Same flops as
-// k_factor3, one more reduction (sigma, interleaved with the first), one live update as before:
-// no parking, no extra LDS state beyond a second r buffer.  Same arguments and results.
-// Measured: 13.3 ms per tile against 10.0 -- k_factor3's chain already hides
-// under the row generator, which is left exposed here, and the kernel is VALU-issue-bound, so the
-// second reduction's ~30 instructions cost more than the overlap returns.  Experimental switch
-// (gf_set_pipelined(2)), parity-tested, not the default.
-// ------------------------------------------------------------------------------------
-constexpr int SP_BR = 4, SP_AHEAD = 1;
-
-template <int ROWS>
-__device__ __forceinline__ void split_preload(double (&rb)[SP_AHEAD + 1][SP_BR], const double *x) {
-#pragma unroll
-    for (int k = 0; k < SP_AHEAD && k < ROWS / SP_BR; ++k) {
-#pragma unroll
-        for (int r = 0; r < SP_BR; ++r) rb[k][r] = x[k * SP_BR + r];
-    }
-}
-
-template <int ROWS>
-__device__ __forceinline__ double split_matvec(const double (&T)[ROWS], double (&rb)[SP_AHEAD + 1][SP_BR],
-                                               const double *xa) {
-    constexpr int BR = SP_BR, NB = ROWS / BR, AHEAD = SP_AHEAD;
-    static_assert(ROWS % BR == 0, "ROWS must be a multiple of 4");
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        if (k + AHEAD < NB) {
-#pragma unroll
-            for (int r = 0; r < BR; ++r) rb[(k + AHEAD) % (AHEAD + 1)][r] = xa[(k + AHEAD) * BR + r];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const int c = k % (AHEAD + 1);
-        acc0 = fma(rb[c][0], T[k * BR + 0], acc0);
-        acc1 = fma(rb[c][1], T[k * BR + 1], acc1);
-        acc2 = fma(rb[c][2], T[k * BR + 2], acc2);
-        acc3 = fma(rb[c][3], T[k * BR + 3], acc3);
-        asm volatile("" : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3));
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    return (acc0 + acc2) + (acc1 + acc3);
-}
-
+// helpers shared with the archived variants
+#define GF_MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+typedef double d4 __attribute__((ext_vector_type(4)));
 template <class F, int... K>
 __device__ __forceinline__ void static_for(F &&f, std::integer_sequence<int, K...>) {
     (f(std::integral_constant<int, K>{}), ...);
 }
 
-// T_i += xw_i q, hook(k) issued after batch k (the row's chain, one stage per batch)
-template <int ROWS, class Hook>
-__device__ __forceinline__ void split_fold(double (&T)[ROWS], double (&rb)[SP_AHEAD + 1][SP_BR],
-                                           const double *xw, const double q, Hook &&hook) {
-    constexpr int BR = SP_BR, NB = ROWS / BR, AHEAD = SP_AHEAD;
-    static_for([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        if constexpr (k + AHEAD < NB) {
-#pragma unroll
-            for (int r = 0; r < BR; ++r) rb[(k + AHEAD) % (AHEAD + 1)][r] = xw[(k + AHEAD) * BR + r];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        constexpr int c = k % (AHEAD + 1);
-#pragma unroll
-        for (int r = 0; r < BR; ++r) T[k * BR + r] = fma(rb[c][r], q, T[k * BR + r]);
-        // pin the batch here: LLVM otherwise sinks the whole fold below the pivot test that follows
-        // the sweep (T is dead on the failure path) and keeps all 64 row operands alive
-        asm volatile("" : "+v"(T[k * BR + 0]), "+v"(T[k * BR + 1]), "+v"(T[k * BR + 2]), "+v"(T[k * BR + 3]));
-        hook(kc);
-        __builtin_amdgcn_sched_barrier(0);
-    }, std::make_integer_sequence<int, NB>{});
-}
-
-template <int ROWS>
-__global__ void __launch_bounds__(64, 2)
-k_factor6(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int nch,
-          const int Jr, const int Jc, const int block_sub, const double gap,
-          const double *__restrict__ ar_, const double *__restrict__ cr_,
-          const double *__restrict__ ac_, const double *__restrict__ bc_,
-          const double *__restrict__ cc_, const double *__restrict__ dc_,
-          const double *__restrict__ diag_add_, const double *__restrict__ cmax_,
-          const double *__restrict__ t_, const int64_t t_bs,
-          const double *__restrict__ diag_, const int64_t diag_bs,
-          const double *__restrict__ y_, const int64_t y_bs,
-          double *__restrict__ d_, double *__restrict__ z_, double *__restrict__ r_out,
-          double *__restrict__ Ut_out, double *__restrict__ Wt_out, double *__restrict__ de_out,
-          double *__restrict__ S_state, double *__restrict__ F_state,
-          int32_t *__restrict__ info) {
-    const int lane = threadIdx.x;
-    const int b = blockIdx.x;                       // state slot = problem * nch + chunk
-    if (info[b] != 0) return;
-    const int pr = b / nch, ch = b - pr * nch;
-    const int64_t c0 = (int64_t)ch * chunk_len;     // first row of the chunk within this call
-    const int64_t rows = (N - c0 < chunk_len) ? (N - c0) : chunk_len;
-    const int64_t g0 = n_first + c0;                // global index of the chunk's first row
-    const size_t pb = (size_t)pr * N + c0;
-    const double *__restrict__ tg = t_ + (size_t)pr * t_bs + g0;
-    const double *__restrict__ yg = y_ + (size_t)pr * y_bs + g0;
-    const double *__restrict__ gg = diag_ ? diag_ + (size_t)pr * diag_bs + g0 : nullptr;
-    double *__restrict__ dg = d_ + pb;
-    double *__restrict__ zg = z_ + pb;
-    // chunk-mode row stores: loop-invariant per-lane pointers, indexed with opaque_uniform(row)
-    double *__restrict__ rg = r_out ? r_out + pb * 64 + lane : nullptr;
-    double *__restrict__ ug = Ut_out ? Ut_out + pb * 64 + lane : nullptr;   // stored factor:
-    double *__restrict__ wg = Wt_out ? Wt_out + pb * 64 + lane : nullptr;   // u~, w~ = r/d rows
-    double *__restrict__ eg = de_out ? de_out + pb : nullptr;               // reset spans (-1: none)
-    double *__restrict__ Sg = S_state + (size_t)b * (64 * 64) + (size_t)lane * 64;
-    double *__restrict__ Fg = F_state + (size_t)b * 64;
-    const double diag_add = diag_add_[pr];
-
-    RowGen G;
-    G.init(lane, pr, Jr, Jc, block_sub, gap, ar_, cr_, ac_, bc_, cc_, dc_, cmax_, tg, g0);
-    const double cj = G.cj;
-
-    __shared__ __attribute__((aligned(16))) double s_w[2][64];   // r_{n-1} | r_n (pending update, row form)
-    __shared__ __attribute__((aligned(16))) double s_u[64];      // u~_n
-    __shared__ __attribute__((aligned(16))) double s_e[64];      // block decay E at reset rows
-    const bool fl = lane == 63;     // pad lane carrying the forward solve (W < 64)
-
-    double T[ROWS];
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) T[i] = fl ? Fg[i] : Sg[i];
-    double q = 0.0, sg = 0.0;       // q_{n-1} (lane form; lane 63: z/d), sigma_{n-1}
-    int32_t fail = 0;
-
-    double t_n1 = tg[1], t_n2 = tg[2];
-    double y_n = yg[0], y_n1 = yg[1], y_n2 = yg[2];
-    double g_n = gg ? gg[0] : 0.0, g_n1 = gg ? gg[1] : 0.0, g_n2 = gg ? gg[2] : 0.0;
-    double ut, vt, de;
-    bool rst;
-    G.next(tg[0], g0, ut, vt, rst, de);
-
-    double rb[SP_AHEAD + 1][SP_BR];
-    double *swc = s_w[0], *swn = s_w[1];    // r of the pending update | r of this row
-    swc[lane] = 0.0;
-    s_u[lane] = ut;
-    wave_lds_fence();
-    split_preload<ROWS>(rb, s_u);
-
-    for (int64_t n = 0; n < rows; ++n) {
-        const double a_n = g_n + diag_add, yy = y_n;
-        const double ut_c = ut, vt_c = vt;
-        if (eg && lane == 0) eg[n] = rst ? de : -1.0;
-        if (rst) {                          // wave-uniform: fold the pending update, then decay
-            const double el = fm_exp(-cj * de);     // pad lanes: cj = 0 -> 1
-            s_e[lane] = el;
-            wave_lds_fence();
-#pragma unroll
-            for (int k = 0; k < ROWS / 4; ++k) {
-                double w4[4], e4[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { w4[r] = swc[4 * k + r]; e4[r] = s_e[4 * k + r]; }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) T[4 * k + r] = fma(w4[r], q, T[4 * k + r]) * (e4[r] * el);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            q = 0.0;
-            sg = 0.0;
-        }
-        __builtin_amdgcn_s_setprio(0);
-        const double acc = split_matvec<ROWS>(T, rb, s_u);
-        __builtin_amdgcn_s_setprio(GF_CHAIN_PRIO);
-        const double tmp = fma(q, sg, acc);
-        const double r = fl ? 0.0 : (vt_c - tmp);
-        G.next(t_n1, g0 + n + 1, ut, vt, rst, de);
-        t_n1 = t_n2; y_n = y_n1; y_n1 = y_n2; g_n = g_n1; g_n1 = g_n2;
-        t_n2 = tg[n + 3];
-        y_n2 = yg[n + 3];
-        g_n2 = gg ? gg[n + 3] : 0.0;
-        wave_lds_fence();
-        swn[lane] = r;
-        s_u[lane] = ut;
-        wave_lds_fence();
-        split_preload<ROWS>(rb, swc);
-        // row n's chain, one stage per batch of the fold (everything the fold does not need is
-        // finished or stored before it: the fold block is the register-pressure peak)
-        double x = ut_c * tmp, y = r * ut, dn = 1.0, inv = 1.0, qn = 0.0, sgn = 0.0;
-        const double zn = yy - read_lane(tmp, 63);
-        const double rz = fl ? zn : r;
-        const size_t ro = opaque_uniform((size_t)n * 64);
-        if (rg) rg[ro] = r;                         // r~ rows for k_phi (chunk mode)
-        if (ug) ug[ro] = ut_c;
-        constexpr int NS = 11, NB = ROWS / SP_BR;
-        auto chain = [&](auto sc) {
-            constexpr int st = decltype(sc)::value;
-            if constexpr (st == 0) { x += dpp_get<0xB1, 0xf>(x); y += dpp_get<0xB1, 0xf>(y); }
-            else if constexpr (st == 1) { x += dpp_get<0x4E, 0xf>(x); y += dpp_get<0x4E, 0xf>(y); }
-            else if constexpr (st == 2) { x += dpp_get<0x141, 0xf>(x); y += dpp_get<0x141, 0xf>(y); }
-            else if constexpr (st == 3) { x += dpp_get<0x140, 0xf>(x); y += dpp_get<0x140, 0xf>(y); }
-            else if constexpr (st == 4) { x += dpp_get<0x142, 0xf>(x); y += dpp_get<0x142, 0xf>(y); }
-            else if constexpr (st == 5) { x += dpp_get<0x143, 0xf>(x); y += dpp_get<0x143, 0xf>(y); }
-            else if constexpr (st == 6) { dn = a_n - read_lane(x, 63); sgn = read_lane(y, 63); }
-            // (pinned like the fold's batches: these would otherwise sink below the pivot test)
-            else if constexpr (st == 7) { inv = __builtin_amdgcn_rcp(dn); asm volatile("" : "+v"(inv)); }
-            else if constexpr (st == 8) { inv = fma(fma(-dn, inv, 1.0), inv, inv); asm volatile("" : "+v"(inv)); }
-            else if constexpr (st == 9) { inv = fma(fma(-dn, inv, 1.0), inv, inv); asm volatile("" : "+v"(inv)); }
-            else if constexpr (st == 10) { qn = rz * inv; asm volatile("" : "+v"(qn)); }
-        };
-        split_fold<ROWS>(T, rb, swc, q, [&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            // one stage per batch from the first batch on; narrow problems (fewer batches than
-            // stages) spread the stages evenly
-            constexpr int lo = (NB >= NS) ? (k < NS ? k : NS) : k * NS / NB;
-            constexpr int hi = (NB >= NS) ? (k < NS ? k + 1 : NS) : (k + 1) * NS / NB;
-            static_for([&](auto jc) { chain(std::integral_constant<int, lo + decltype(jc)::value>{}); },
-                       std::make_integer_sequence<int, hi - lo>{});
-        });
-        split_preload<ROWS>(rb, s_u);
-        if (!(dn > 0.0)) {
-            const int64_t gf = g0 + n + 1;
-            fail = (int32_t)(gf > 0x7fffffff ? 0x7fffffff : gf);
-            break;
-        }
-        q = qn;
-        sg = sgn;
-        { double *t = swc; swc = swn; swn = t; }
-        if (wg) wg[ro] = fl ? 0.0 : qn;
-        if (lane == 0) { dg[n] = dn; zg[n] = zn; }
-    }
-    if (fail) {
-        if (lane == 0) info[b] = fail;
-        return;
-    }
-    wave_lds_fence();
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-        const double v = fma(swc[i], q, T[i]);
-        if (fl) Fg[i] = v; else Sg[i] = v;
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// k_factor5: k_factor3 with the per-row serial chain taken off the sweep's critical path.
-//
-// In k_factor3 the sweep of row n+1 folds the rank-1 update of row n, so it cannot start before
-// q_n = r_n / d_n is known: sweep -> DPP reduction -> reciprocal -> sweep is one dependent chain
-// and a wave spends more than half of every row waiting on it (one wave alone: 2300 cycles per
-// row for ~900 cycles of issued work; two waves per SIMD do not cover it).  Here T stays ONE
-// update behind:
-//     sweep n :  T += r_{n-2} q_{n-2}^T ;  tmp_p = T u~_n                    (= T_{n-2} u~_n)
-//     tmp_n   =  tmp_p + q_{n-1} sigma_{n-1} ,   sigma_{n-1} = r_{n-1} . u~_n
-//     d_n     =  a_n - (u~_n . tmp_p + sigma_{n-1}^2 / d_{n-1}) ;  z_n = y_n - tmp_n[63]
-//     r_n = v~_n - tmp_n ;  q_n = r_n / d_n ;  sigma_n = r_n . u~_{n+1}
-// which is the same arithmetic (T_{n-1} u~_n = T_{n-2} u~_n + q_{n-1} (r_{n-1} . u~_n)).  Sweep n
-// needs only r_{n-2}, q_{n-2} and u~_n, all known one row earlier, so the "post" work of row n-1
-// (two DPP reductions, the reciprocal, r and q) is independent of it and is issued in stages
-// BETWEEN the sweep's FMA batches; the only chain left from row to row is d_{n-1} -> d_n (a few
-// scalar operations).  Costs one more reduction per row.  Reset rows drain the pipeline (fold
-// both pending updates, decay) and restart it.  Same arguments, state hand-off and results as
-// k_factor3, chunk mode included.
-// ------------------------------------------------------------------------------------
-//   MODE 0:  T_i += xw_i q ;  acc += xa_i T_i     (fold + mat-vec; hook(k) after batch k)
-//   MODE 1:  T_i  = (T_i + xw_i q) (xa_i el)      (fold + decay)
-//   MODE 2:  T_i += xw_i q                         (fold only)
-constexpr int PP_BR = 4, PP_AHEAD = 2;  // 4-row batches, 2 batches (8 rows) of LDS look-ahead
-template <int ROWS, int MODE, class Hook>
-__device__ __forceinline__ double sweep_pipe(double (&T)[ROWS], double (&ab)[PP_AHEAD + 1][PP_BR],
-                                             double (&wb)[PP_AHEAD + 1][PP_BR], const double *xa,
-                                             const double *xw, const double q, const double el,
-                                             Hook &&hook) {
-    constexpr int BR = PP_BR, NB = ROWS / BR, AHEAD = PP_AHEAD;
-    static_assert(ROWS % BR == 0, "ROWS must be a multiple of 4");
-    double acc0 = 0.0, acc1 = 0.0;
-    static_for([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        if constexpr (k + AHEAD < NB) {
-#pragma unroll
-            for (int r = 0; r < BR; ++r) {
-                if constexpr (MODE != 2) ab[(k + AHEAD) % (AHEAD + 1)][r] = xa[(k + AHEAD) * BR + r];
-                wb[(k + AHEAD) % (AHEAD + 1)][r] = xw[(k + AHEAD) * BR + r];
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        constexpr int c = k % (AHEAD + 1);
-        if constexpr (MODE == 1) {
-#pragma unroll
-            for (int r = 0; r < BR; ++r)
-                T[k * BR + r] = fma(wb[c][r], q, T[k * BR + r]) * (ab[c][r] * el);
-        } else if constexpr (MODE == 2) {
-#pragma unroll
-            for (int r = 0; r < BR; ++r) T[k * BR + r] = fma(wb[c][r], q, T[k * BR + r]);
-        } else {
-            T[k * BR + 0] = fma(wb[c][0], q, T[k * BR + 0]);
-            T[k * BR + 1] = fma(wb[c][1], q, T[k * BR + 1]);
-            T[k * BR + 2] = fma(wb[c][2], q, T[k * BR + 2]);
-            T[k * BR + 3] = fma(wb[c][3], q, T[k * BR + 3]);
-            acc0 = fma(ab[c][0], T[k * BR + 0], acc0);
-            acc1 = fma(ab[c][1], T[k * BR + 1], acc1);
-            acc0 = fma(ab[c][2], T[k * BR + 2], acc0);
-            acc1 = fma(ab[c][3], T[k * BR + 3], acc1);
-            asm volatile("" : "+v"(acc0), "+v"(acc1));
-            hook(kc);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }, std::make_integer_sequence<int, NB>{});
-    return acc0 + acc1;
-}
-
-template <int ROWS>
-__device__ __forceinline__ void pipe_preload(double (&ab)[PP_AHEAD + 1][PP_BR],
-                                             double (&wb)[PP_AHEAD + 1][PP_BR],
-                                             const double *xa, const double *xw) {
-    constexpr int NB = ROWS / PP_BR;
-#pragma unroll
-    for (int k = 0; k < PP_AHEAD && k < NB; ++k) {
-#pragma unroll
-        for (int r = 0; r < PP_BR; ++r) { ab[k][r] = xa[k * PP_BR + r]; wb[k][r] = xw[k * PP_BR + r]; }
-    }
-}
-
-// STORES: the chunk-mode extras (r~, u~, w~ rows, reset spans) are compiled in; the plain
-// log-likelihood sweep (gf_loglike_fused) runs the variant without them.
-// No global memory access in the hot loop: t, y, diag come through a 64-row LDS window refilled
-// 32 rows at a time, d and z leave through a 32-row LDS buffer flushed with coalesced stores
-// (base pointers and prefetched scalars would otherwise not fit the SGPR file next to the
-// pipeline's state and end up, via VGPRs, in scratch).
-template <int ROWS, bool STORES>
-__global__ void __launch_bounds__(64, 2)
-k_factor5(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int nch,
-          const int Jr, const int Jc, const int block_sub, const double gap,
-          const double *__restrict__ ar_, const double *__restrict__ cr_,
-          const double *__restrict__ ac_, const double *__restrict__ bc_,
-          const double *__restrict__ cc_, const double *__restrict__ dc_,
-          const double *__restrict__ diag_add_, const double *__restrict__ cmax_,
-          const double *__restrict__ t_, const int64_t t_bs,
-          const double *__restrict__ diag_, const int64_t diag_bs,
-          const double *__restrict__ y_, const int64_t y_bs,
-          double *__restrict__ d_, double *__restrict__ z_, double *__restrict__ r_out,
-          double *__restrict__ Ut_out, double *__restrict__ Wt_out, double *__restrict__ de_out,
-          double *__restrict__ S_state, double *__restrict__ F_state,
-          int32_t *__restrict__ info) {
-    const int lane = threadIdx.x;
-    const int b = blockIdx.x;                       // state slot = problem * nch + chunk
-    if (info[b] != 0) return;
-    const int pr = b / nch, ch = b - pr * nch;
-    const int64_t c0 = (int64_t)ch * chunk_len;
-    const int rows = (int)((N - c0 < chunk_len) ? (N - c0) : chunk_len);    // < 2^31 rows per chunk / tile
-    const int64_t g0 = n_first + c0;
-    const size_t pb = (size_t)pr * N + c0;
-    const double *__restrict__ tg = t_ + (size_t)pr * t_bs + g0;
-    const double *__restrict__ yg = y_ + (size_t)pr * y_bs + g0;
-    const double *__restrict__ gg = diag_ ? diag_ + (size_t)pr * diag_bs + g0 : nullptr;
-    double *__restrict__ dg = d_ + pb;
-    double *__restrict__ zg = z_ + pb;
-    double *__restrict__ Sg = S_state + (size_t)b * (64 * 64) + (size_t)lane * 64;
-    double *__restrict__ Fg = F_state + (size_t)b * 64;
-    const double diag_add = diag_add_[pr];
-
-    RowGen G;
-    G.init(lane, pr, Jr, Jc, block_sub, gap, ar_, cr_, ac_, bc_, cc_, dc_, cmax_, tg, g0);
-
-    __shared__ double s_gen[10 * 64];   // the generator's per-lane state, parked during the sweeps
-    __shared__ __attribute__((aligned(16))) double s_w[2][64];   // r_{n-2} | r_{n-1}  (by parity)
-    __shared__ __attribute__((aligned(16))) double s_u[2][64];   // u~_n    | u~_{n+1}
-    __shared__ __attribute__((aligned(16))) double s_e[64];      // block decay E at reset rows
-    __shared__ double s_in[3][64];      // t, y, diag of rows [n, n + 32 ...) at slot row & 63
-    __shared__ double s_out[2][32];     // d, z of the last <= 32 rows at slot row & 31
-    __shared__ double s_v[2][64];       // v~_n | v~_{n+1} (lane form, by parity)
-    const bool fl = lane == 63;     // pad lane carrying the forward solve (W < 64)
-
-    double T[ROWS];
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) T[i] = fl ? Fg[i] : Sg[i];
-    int32_t fail = 0;
-
-    // rows [first, first + 32) of t, y, diag into the window (the caller pads the series by three
-    // elements: row rows + 2 is the last one that may be read)
-    auto refill = [&](const int first) {
-        if (lane < 32) {
-            int i = first + lane;
-            if (i > rows + 2) i = rows + 2;
-            const int slot = (first + lane) & 63;
-            s_in[0][slot] = tg[i];
-            s_in[1][slot] = yg[i];
-            s_in[2][slot] = gg ? gg[i] : 0.0;
-        }
-    };
-    // d, z of rows [m & ~31, m] to memory (lanes 0..31: d, lanes 32..63: z)
-    auto flush = [&](const int m) {
-        const int first = m & ~31;
-        const int k = lane & 31;
-        if (first + k <= m) {
-            double *dst = (lane < 32) ? dg : zg;
-            dst[first + k] = s_out[lane >> 5][k];
-        }
-    };
-    refill(0);
-    refill(32);
-
-    // row m = n - 1 ("previous") and row n lane values; scalars of row m
-    double u_m = 0.0, u_n, v_n;                     // (v~ rows and a, y of row m wait in LDS)
-    double tp = 0.0;                                // tmp_p of row m
-    double qo = 0.0, sgo = 0.0, invo = 1.0;         // q_{m-1}, sigma_{m-1}, 1 / d_{m-1}
-    double de_n;
-    bool rst_n;
-    G.next(tg[0], g0, u_n, v_n, rst_n, de_n);
-    G.park(s_gen, lane);
-    s_w[0][lane] = 0.0; s_w[1][lane] = 0.0;
-    s_u[0][lane] = u_n;
-    s_v[0][lane] = v_n;
-    wave_lds_fence();
-
-    double ab[PP_AHEAD + 1][PP_BR], wb[PP_AHEAD + 1][PP_BR];
-    auto nohook = [](auto) {};
-    constexpr int NS = 19, NB = ROWS / PP_BR;
-    int n = 0;              // row within this chunk (g0 is a multiple of block: the block phase is n's)
-
-    // post work of row m = n - 1 in NS branch-free stages; results in the variables below
-    double x, tm, r_m = 0.0, d_m = 1.0, z_m = 0.0, inv = 1.0, q_m = 0.0, xs, sg_m = 0.0;
-    double *swn = s_w[1];
-    auto post = [&](auto sc) {
-        constexpr int st = decltype(sc)::value;
-        if constexpr (st == 0) { x = u_m * tp; tm = fma(qo, sgo, tp); }
-        else if constexpr (st == 1) x += dpp_get<0xB1, 0xf>(x);
-        else if constexpr (st == 2) x += dpp_get<0x4E, 0xf>(x);
-        else if constexpr (st == 3) x += dpp_get<0x141, 0xf>(x);
-        else if constexpr (st == 4) x += dpp_get<0x140, 0xf>(x);
-        else if constexpr (st == 5) x += dpp_get<0x142, 0xf>(x);
-        else if constexpr (st == 6) x += dpp_get<0x143, 0xf>(x);
-        else if constexpr (st == 7) {
-            const double sp = read_lane(x, 63), t63 = read_lane(tm, 63);
-            const int mm = n - 1;
-            d_m = (s_in[2][mm & 63] + diag_add) - fma(sgo * invo, sgo, sp);
-            z_m = s_in[1][mm & 63] - t63;
-            r_m = fl ? 0.0 : (s_v[mm & 1][lane] - tm);
-            swn[lane] = r_m;                        // operand of the fold in sweep n+1
-        }
-        else if constexpr (st == 8) inv = __builtin_amdgcn_rcp(d_m);
-        else if constexpr (st == 9) inv = fma(fma(-d_m, inv, 1.0), inv, inv);
-        else if constexpr (st == 10) inv = fma(fma(-d_m, inv, 1.0), inv, inv);
-        else if constexpr (st == 11) { q_m = (fl ? z_m : r_m) * inv; xs = r_m * u_n; }
-        else if constexpr (st == 12) xs += dpp_get<0xB1, 0xf>(xs);
-        else if constexpr (st == 13) xs += dpp_get<0x4E, 0xf>(xs);
-        else if constexpr (st == 14) xs += dpp_get<0x141, 0xf>(xs);
-        else if constexpr (st == 15) xs += dpp_get<0x140, 0xf>(xs);
-        else if constexpr (st == 16) xs += dpp_get<0x142, 0xf>(xs);
-        else if constexpr (st == 17) xs += dpp_get<0x143, 0xf>(xs);
-        else if constexpr (st == 18) sg_m = read_lane(xs, 63);
-    };      // (no branches in the stages: a branch would cut the sweep's basic block in two)
-
-    // results of row m = n - 1 out; false if its pivot is not positive
-    auto emit = [&](const double q_st) -> bool {
-        const int m = n - 1;
-        if (!(read_lane(d_m, 0) > 0.0)) {           // (uniform by construction; say so)
-            const int64_t gf = g0 + m + 1;
-            fail = (int32_t)(gf > 0x7fffffff ? 0x7fffffff : gf);
-            return false;
-        }
-        if constexpr (STORES) {
-            const size_t o = (pb + (size_t)m) * 64 + lane;
-            if (r_out) r_out[o] = r_m;
-            if (Ut_out) { Ut_out[o] = u_m; Wt_out[o] = fl ? 0.0 : q_st; }
-        }
-        const int slot = m & 31;
-        s_out[0][slot] = d_m;                       // every lane writes the same value
-        s_out[1][slot] = z_m;
-        if (slot == 31 || m == rows - 1) {          // wave-uniform, once per 32 rows
-            wave_lds_fence();
-            flush(m);
-        }
-        return true;
-    };
-    // make row n the "previous" one; (u_c, v_c) is row n+1, already generated
-    auto rotate = [&](const double tp_new, const double u_c, const double v_c) {
-        s_u[(n + 1) & 1][lane] = u_c;
-        s_v[(n + 1) & 1][lane] = v_c;
-        tp = tp_new;
-        u_m = u_n; u_n = u_c;
-        qo = q_m; sgo = sg_m; invo = inv;
-        n = __builtin_amdgcn_readfirstlane(n + 1);
-        if ((n & 31) == 0) refill(n + 31);          // wave-uniform, once per 32 rows; row n-1's
-                                                    // slot (read by its post work) stays intact
-        wave_lds_fence();
-    };
-    // row n+1 with everything the generator may need (anchor, refreshed multipliers); only
-    // called outside the inner loop, which handles plain rotation steps itself
-    auto advance_any = [&](const double tp_new) {
-        double u_c = 0.0, v_c = 0.0;
-        rst_n = false; de_n = -1.0;
-        if (n + 1 < rows) {
-            G.unpark(s_gen, lane);
-            G.next(read_lane(s_in[0][(n + 1) & 63], 0), g0 + n + 1, u_c, v_c, rst_n, de_n);
-            G.park_state(s_gen, lane);
-        }
-        rotate(tp_new, u_c, v_c);
-    };
-
-    for (;;) {
-        // ---- row n opens a scaling block (or n == rows): drain the pipeline, decay, restart ----
-        if (rst_n || n == 0 || n == rows) {
-            const int par = n & 1;
-            double *swc = s_w[par], *suc = s_u[par];
-            swn = s_w[par ^ 1];
-            if (n > 0) {
-                static_for(post, std::make_integer_sequence<int, NS>{});
-                wave_lds_fence();
-                pipe_preload<ROWS>(ab, wb, swc, swc);                       // fold update n-2
-                (void)sweep_pipe<ROWS, 2>(T, ab, wb, swc, swc, qo, 0.0, nohook);
-                if (!emit(q_m)) break;
-            }
-            if (n == rows) {
-                pipe_preload<ROWS>(ab, wb, swn, swn);                       // fold update n-1
-                (void)sweep_pipe<ROWS, 2>(T, ab, wb, swn, swn, q_m, 0.0, nohook);
-                break;
-            }
-            if constexpr (STORES) { if (de_out && lane == 0) de_out[pb + n] = rst_n ? de_n : -1.0; }
-            const double el = fm_exp(-s_gen[lane] * (rst_n ? de_n : 0.0));  // c_j; pad lanes: 0 -> 1
-            s_e[lane] = el;
-            wave_lds_fence();
-            pipe_preload<ROWS>(ab, wb, s_e, swn);                           // fold update n-1, decay
-            (void)sweep_pipe<ROWS, 1>(T, ab, wb, s_e, swn, q_m, el, nohook);
-            pipe_preload<ROWS>(ab, wb, suc, swc);
-            const double tp_new = sweep_pipe<ROWS, 0>(T, ab, wb, suc, swc, 0.0, 0.0, nohook);
-            q_m = 0.0; sg_m = 0.0; inv = 1.0;                               // nothing pending any more
-            advance_any(tp_new);
-            continue;
-        }
-        // ---- rows inside the block: sweep n with the post work of row n-1 between its batches;
-        //      the loop itself only takes plain rotation steps of the generator ----------------
-        double tp_last = 0.0;
-        {
-            // loop-invariant, wave-uniform scalars of the generator's row test (peek), held in
-            // SGPRs explicitly: the inner loop never refreshes the cadence or re-anchors
-            const double dtr = read_lane(G.dt_ref, 0);
-            const double gth = read_lane(G.gthr, 0), jth = read_lane(G.jthr, 0);
-            const int bmask = __builtin_amdgcn_readfirstlane(G.block - 1);
-            const int nrows = __builtin_amdgcn_readfirstlane(rows);
-            double tm1 = read_lane(G.t_m1, 0);
-            for (;;) {
-                const int par = n & 1;
-                double *swc = s_w[par], *suc = s_u[par];
-                swn = s_w[par ^ 1];
-                if constexpr (STORES) { if (de_out && lane == 0) de_out[pb + n] = -1.0; }
-                pipe_preload<ROWS>(ab, wb, suc, swc);
-                const double tp_new = sweep_pipe<ROWS, 0>(T, ab, wb, suc, swc, qo, 0.0, [&](auto kc) {
-                    constexpr int k = decltype(kc)::value;
-                    constexpr int lo = k * NS / NB, hi = (k + 1) * NS / NB;
-                    static_for([&](auto jc) { post(std::integral_constant<int, lo + decltype(jc)::value>{}); },
-                               std::make_integer_sequence<int, hi - lo>{});
-                });
-                tp_last = tp_new;
-                if (!emit(q_m)) break;
-                if (n + 1 >= nrows) break;
-                // kind of row n+1 (RowGen::peek; g0 is a multiple of block, so the block phase is n's)
-                const double t_next = read_lane(s_in[0][(n + 1) & 63], 0);
-                const double dt = t_next - tm1, ddt = dt - dtr;
-                if ((((n + 1) & bmask) == 0) || (((n + 1) & G.sub_mask) == 0) || (dt > gth)
-                    || !(fabs(ddt) < jth)) break;
-                tm1 = t_next;
-                G.unpark(s_gen, lane);
-                G.step(t_next, ddt);
-                double u_c, v_c;
-                G.emit(u_c, v_c);
-                G.park_state(s_gen, lane);
-                rotate(tp_new, u_c, v_c);
-            }
-            G.t_m1 = tm1;
-        }
-        if (fail) break;
-        advance_any(tp_last);       // row n+1 is a reset row, needs new multipliers, or does not exist
-    }
-    if (fail) {
-        if (lane == 0) info[b] = fail;
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-        if (fl) Fg[i] = T[i]; else Sg[i] = T[i];
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// k_factor4: the fused sweep in BLOCKED (rank-16) form on the FP64 matrix pipe.
-//
-// k_factor3 spends 2 W^2 vector FMAs per row and is bound by the rate at which one wave can
-// issue vector instructions (~300 per row, 120 of them the FMAs).  Sixteen consecutive rows of
-// one scaling block can be taken together (scaled coordinates: no decay inside a block):
-//     P  = T U~                        (64 x 16)   U~ = [u~_0 .. u~_15], T the state at block start
-//     B  = V~ - P
-//     H  = B^T U~  (+ diag)            (16 x 16)   = conditional covariance of the 16 rows
-//     H  = L D L^T,  N = L^-T          (16 x 16, in LDS: the only sequential part)
-//     R~ = B N D^-1/2                  (64 x 16)   columns r~_m / sqrt(d_m)
-//     T += R~ R~^T
-// which is the same arithmetic re-associated (d_m = H_mm - sum_k<m c_km^2 / d_k, c_km = r_k.u~_m);
-// scratch/proto_block.py checks it against the sequential recurrence (d to 1e-13).  The four
-// products run as v_mfma_f64_16x16x4_f64 (10 per row): one issue slot per 1024 FMAs instead of 16.
-//
-// Layout.  Lane = (m, g) = (lane & 15, lane >> 4).  T lives in accumulator layout as 4 x 4 tiles:
-// T[it][jt][r] @ lane (j, g) = T(16 it + 4 r + g, 16 jt + j).  A register in that layout is
-// directly a B operand (its K index is the row 4 r + g) and, read transposed, an A operand, so
-// T, B^T and R~^T never leave the accumulator layout; only V~/B pass through LDS (to reach the
-// A layout for H).  U~ is generated in A layout: lane (m, k) makes u~_m(k + 4 q), q = 0..15.
-// State columns are PERMUTED so that a lane's 16 columns are 8 (cos, sin) pairs: logical column
-// l = 2 kappa + s sits at physical index (kappa >> 3) + 4 (2 (kappa & 7) + s); column 63 carries
-// the forward solve (v~_63 = y, u~_63 = 0: T(.,63) = F~, r~_m(63) = z_m / sqrt(d_m)).
-// Rows past a reset (new scaling block, gap) or past the end of the tile are "null" rows
-// (u~ = v~ = 0, H_mm = 1): they change nothing.  Needs Jr even, W <= 62, block >= 16.
-// ------------------------------------------------------------------------------------
-typedef double d4 __attribute__((ext_vector_type(4)));
-#define GF_MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
-constexpr int F4_TAB = 8;           // doubles per (cos, sin) pair in the constants table
-
-__device__ __forceinline__ int f4_logical(int p) {      // physical -> logical column
-    const int k = p & 3, q = p >> 2;
-    return 2 * (8 * k + (q >> 1)) + (q & 1);
-}
-// 16 x 64 staging matrix in LDS, row stride 64 with the column XOR-swizzled by the row (a fixed
-// column read down 16 rows and 16 consecutive columns of 4 rows both spread over the banks)
-__device__ __forceinline__ int f4_vs(int row, int col) { return row * 64 + (col ^ (4 * row)); }
-
-__global__ void __launch_bounds__(64, 2)
-k_factor4(const int64_t N, const int64_t n_first, const int Jr, const int Jc, const int block,
-          const double gap,
-          const double *__restrict__ ar_, const double *__restrict__ cr_,
-          const double *__restrict__ ac_, const double *__restrict__ bc_,
-          const double *__restrict__ cc_, const double *__restrict__ dc_,
-          const double *__restrict__ diag_add_, const double *__restrict__ cmax_,
-          const double *__restrict__ t_, const int64_t t_bs,
-          const double *__restrict__ diag_, const int64_t diag_bs,
-          const double *__restrict__ y_, const int64_t y_bs,
-          double *__restrict__ d_, double *__restrict__ z_,
-          double *__restrict__ S_state, double *__restrict__ F_state,
-          int32_t *__restrict__ info) {
-    const int lane = threadIdx.x;
-    const int b = blockIdx.x;
-    if (info[b] != 0) return;
-    const int m = lane & 15, g = lane >> 4;
-    const int W = Jr + 2 * Jc;
-    const double *__restrict__ tg = t_ + (size_t)b * t_bs + n_first;
-    const double *__restrict__ yg = y_ + (size_t)b * y_bs + n_first;
-    const double *__restrict__ gg = diag_ ? diag_ + (size_t)b * diag_bs + n_first : nullptr;
-    double *__restrict__ dg = d_ + (size_t)b * N;
-    double *__restrict__ zg = z_ + (size_t)b * N;
-    double *__restrict__ Sg = S_state + (size_t)b * 4096;
-    double *__restrict__ Fg = F_state + (size_t)b * 64;
-    const double cmax = cmax_[b];
-
-    // 19 KB of LDS per wave: eight waves (2 per SIMD) fit one CU's 160 KB
-    __shared__ __attribute__((aligned(16))) double tab[32 * F4_TAB];
-    __shared__ __attribute__((aligned(16))) double Us[16 * 64];     // u~ operands, [q][lane]
-    __shared__ __attribute__((aligned(16))) double Vs[16 * 64];     // V~^T, then B^T (swizzled)
-    __shared__ __attribute__((aligned(16))) double es[64];
-    __shared__ __attribute__((aligned(16))) double rp[16];      // pivot row, permuted [m & 3][m >> 2]
-    __shared__ __attribute__((aligned(16))) double gk[16];      // row k of L^-1, [g][r]
-    __shared__ __attribute__((aligned(16))) double db[32];      // d_m, sqrt(d_m)
-
-    // ---- constants table: pair kappa = lane < 32 -------------------------------------------
-    // u~_0 = (A0 co + B0 si) rho_0 ,  u~_1 = (A1 own1 + B1 co) rho_1 ,  v~_0 = co / rho_0 ,
-    // v~_1 = own1 / rho_1 ,  own1 = si (complex pair) or co = 1 (two real columns, rf = 1).
-    // Pad pairs have zero coefficients: their u~ vanish, so whatever their v~ put into the pad
-    // rows and columns of T never reaches a real entry (and is not stored).
-    double suma = 0.0;
-    if (lane < 32) {
-        double c0 = 0, c1 = 0, dd = 0, rf = 0, A0 = 0, B0 = 0, A1 = 0, B1 = 0;
-        const int l0 = 2 * lane;
-        if (l0 + 1 < Jr) {                  // two real columns
-            c0 = cr_[(size_t)b * Jr + l0]; c1 = cr_[(size_t)b * Jr + l0 + 1];
-            A0 = ar_[(size_t)b * Jr + l0]; A1 = ar_[(size_t)b * Jr + l0 + 1];
-            rf = 1.0;
-            suma = A0 + A1;
-        } else if (l0 >= Jr && l0 + 1 < W) {
-            const size_t ck = (size_t)b * Jc + ((l0 - Jr) >> 1);
-            c0 = c1 = cc_[ck]; dd = dc_[ck];
-            A0 = A1 = ac_[ck]; B0 = bc_[ck]; B1 = -B0;
-            suma = A0;
-        }
-        double *tp = tab + lane * F4_TAB;
-        tp[0] = c0; tp[1] = c1; tp[2] = dd; tp[3] = rf;
-        tp[4] = A0; tp[5] = B0; tp[6] = A1; tp[7] = B1;
-    }
-    suma = wave_sum(suma);
-    const double dshift = diag_add_[b] - suma;          // a_n - v~_n.u~_n = diag_n + dshift
-    // decay rate of this lane's physical column (lane = physical index)
-    wave_lds_fence();
-    const double c_col = tab[(8 * (lane & 3) + (lane >> 3)) * F4_TAB + ((lane >> 2) & 1)];
-
-    // ---- state -> accumulator layout ------------------------------------------------------
-    d4 T[4][4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int lr = f4_logical(16 * it + 4 * r + g), lc = f4_logical(16 * jt + m);
-                const double vS = Sg[(size_t)lc * 64 + lr];
-                const double vF = Fg[(lr == 63) ? lc : lr];
-                const bool isF = (lr == 63) != (lc == 63);
-                const int lo = (lr == 63) ? lc : lr, hi = (lr == 63) ? lr : lc;
-                double v = isF ? vF : vS;
-                if (!(lo < W && (hi < W || isF))) v = 0.0;
-                T[it][jt][r] = v;
-            }
-
-    // reference time of the scaling block that precedes the first row (see RowGen::init)
-    double tref = tg[0];
-    if (n_first > 0) {
-        int64_t q = -1;
-        while (!(((n_first + q) & (block - 1)) == 0 || cmax * (tg[q] - tg[q - 1]) > gap)) --q;
-        tref = tg[q];
-    }
-
-    int32_t fail = 0;
-    for (int64_t n = 0; n < N;) {
-        // ---- extent of this block: up to 16 rows, ends before the next reset row --------------
-        const int64_t ri = n + m;
-        const bool in_tile = ri < N;
-        const int64_t rc = in_tile ? ri : N - 1;
-        const double tm = tg[rc];
-        const double tprev = (n_first + rc > 0) ? tg[rc - 1] : tm;
-        const double ym = yg[rc];
-        const double gm = gg ? gg[rc] : 0.0;
-        const bool rs_m = in_tile && ((((n_first + ri) & (block - 1)) == 0) || (cmax * (tm - tprev) > gap));
-        const unsigned int mb = (unsigned int)(__ballot(rs_m) & 0xffffull);
-        const unsigned int later = mb >> 1;
-        int cnt = later ? (int)__ffs((int)later) : 16;
-        if ((int64_t)cnt > N - n) cnt = (int)(N - n);
-        const double t0 = read_lane(tm, 0);
-        if ((mb & 1u) && (n_first + n) > 0) {       // reset row: T <- E T E, new reference time
-            const double de = t0 - tref;
-            wave_lds_fence();
-            es[lane] = fm_exp(-c_col * de);
-            wave_lds_fence();
-            double ec[4];
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) ec[jt] = es[16 * jt + m];
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const d4 er = d4{es[16 * it + g], es[16 * it + 4 + g], es[16 * it + 8 + g], es[16 * it + 12 + g]};
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) T[it][jt][r] *= er[r] * ec[jt];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (mb & 1u) tref = t0;
-        const bool valid = m < cnt;
-
-        // ---- generator rows: lane (m, g) makes columns g + 4 q of row m ------------------------
-        // u~ goes to LDS as this lane's own A operands (kept out of the registers: with T and
-        // the polynomial constants of sincos / exp live they would not fit), V~^T to the
-        // staging matrix
-        const double dl = tm - tref;
-        wave_lds_fence();
-#pragma unroll
-        for (int pq = 0; pq < 8; ++pq) {
-            const double *tp = tab + (8 * g + pq) * F4_TAB;
-            const d4 k0 = *reinterpret_cast<const d4 *>(tp);        // c0 c1 dd rf
-            const d4 k1 = *reinterpret_cast<const d4 *>(tp + 4);    // A0 B0 A1 B1
-            double si, co;
-            fm_sincos(k0[2] * tm, &si, &co);
-            const double r0 = fm_exp(-k0[0] * dl), r1 = fm_exp(-k0[1] * dl);
-            const double i0 = fast_rcp(r0), i1 = fast_rcp(r1);
-            const double own1 = fma(k0[3], co - si, si);
-            const double u0 = fma(k1[0], co, k1[1] * si) * r0;
-            const double u1 = fma(k1[2], own1, k1[3] * co) * r1;
-            const double v0 = co * i0;
-            double v1 = own1 * i1;
-            if (pq == 7 && g == 3) v1 = ym;                          // column 63: forward solve
-            Us[(2 * pq) * 64 + lane] = valid ? u0 : 0.0;
-            Us[(2 * pq + 1) * 64 + lane] = valid ? u1 : 0.0;
-            Vs[f4_vs(m, g + 4 * (2 * pq))] = valid ? v0 : 0.0;
-            Vs[f4_vs(m, g + 4 * (2 * pq + 1))] = valid ? v1 : 0.0;
-        }
-        const double avv = valid ? (gm + dshift) : 1.0;
-
-        // ---- P^T = U~^T T ;  B^T = V~^T - P^T  (accumulator layout, kept in LDS) ---------------
-        __builtin_amdgcn_sched_barrier(0);
-        wave_lds_fence();
-        {
-            d4 acc[4];
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) acc[jt] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const double uq = Us[q * 64 + lane];
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt) acc[jt] = GF_MFMA64(uq, T[q >> 2][jt][q & 3], acc[jt]);
-            }
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double *vp = &Vs[f4_vs(g + 4 * r, 16 * jt + m)];
-                    *vp = *vp - acc[jt][r];         // same lane reads and writes the element
-                }
-            wave_lds_fence();
-        }
-        __builtin_amdgcn_sched_barrier(0);
-
-        // ---- H = B^T U~ (+ diagonal) -----------------------------------------------------------
-        d4 Hh;
-        {
-            d4 h[4];
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                h[it] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    h[it] = GF_MFMA64(Vs[f4_vs(m, 16 * it + 4 * r + g)], Us[(4 * it + r) * 64 + lane], h[it]);
-            }
-            Hh = (h[0] + h[1]) + (h[2] + h[3]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (g + 4 * r == m) Hh[r] += avv;
-
-        // ---- 16 x 16 LDL^T with L^-1 alongside; element (g + 4 r, m) lives at lane (m, g) ------
-        d4 Gm;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Gm[r] = (g + 4 * r == m) ? 1.0 : 0.0;
-        double dm = 1.0;
-        int fk = 16;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int kg = k & 3, kr = k >> 2;
-            wave_lds_fence();
-            if (g == kg) rp[(m & 3) * 4 + (m >> 2)] = Hh[kr];
-            if (m == k) *reinterpret_cast<d4 *>(&gk[g * 4]) = Gm;
-            wave_lds_fence();
-            const double ckm = rp[(m & 3) * 4 + (m >> 2)];
-            const d4 ckr = *reinterpret_cast<const d4 *>(&rp[g * 4]);
-            const d4 gkv = *reinterpret_cast<const d4 *>(&gk[g * 4]);
-            const double dk = rp[kg * 4 + kr];
-            if (k < cnt && !(dk > 0.0) && fk == 16) fk = k;
-            const double f = ckm * fast_rcp(dk);
-            if (m == k) dm = dk;
-            if (m > k) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (g + 4 * r > k) Hh[r] = fma(-ckr[r], f, Hh[r]);
-                    Gm[r] = fma(-f, gkv[r], Gm[r]);
-                }
-            }
-        }
-        if (fk < 16) {                              // wave-uniform (dk is)
-            const int64_t gf = n_first + n + fk + 1;
-            fail = (int32_t)(gf > 0x7fffffff ? 0x7fffffff : gf);
-            break;
-        }
-        const double sq = sqrt(dm);
-        const double rsq = fast_rcp(sq);
-        wave_lds_fence();
-        if (g == 0) { db[m] = dm; db[16 + m] = sq; }
-        wave_lds_fence();
-
-        // ---- R~^T = (N D^-1/2)^T B^T ;  T += R~ R~^T -------------------------------------------
-        __builtin_amdgcn_sched_barrier(0);
-        d4 Rt[4];
-        {
-            d4 Mg;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Mg[r] = Gm[r] * rsq;
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) Rt[jt] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt)
-                    Rt[jt] = GF_MFMA64(Mg[r], Vs[f4_vs(g + 4 * r, 16 * jt + m)], Rt[jt]);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int it = 0; it < 4; ++it)
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt) T[it][jt] = GF_MFMA64(Rt[it][r], Rt[jt][r], T[it][jt]);
-
-        // ---- outputs: d_m (lanes 0..15), z_m = r~_m(63) sqrt(d_m) (lanes (15, g)) -------------
-        if (g == 0 && valid) dg[n + m] = dm;
-        if (m == 15) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (g + 4 * r < cnt) zg[n + g + 4 * r] = Rt[3][r] * db[16 + g + 4 * r];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        n += cnt;
-    }
-    if (fail) {
-        if (lane == 0) info[b] = fail;
-        return;
-    }
-    // ---- accumulator layout -> state ---------------------------------------------------------
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int lr = f4_logical(16 * it + 4 * r + g), lc = f4_logical(16 * jt + m);
-                const double v = T[it][jt][r];
-                if (lc == 63) { if (lr < W) Fg[lr] = v; }
-                else if (lr != 63 && lr < W && lc < W) Sg[(size_t)lc * 64 + lr] = v;
-            }
-}
+#ifdef GF_EXPERIMENTAL_SWEEPS
+#include "experimental/sweeps_456.inc"     // archived variants (k_factor4/5/6), never in the product build
+#endif
 
 // ------------------------------------------------------------------------------------
 // Exact time-parallel evaluation of ONE series (Lainiotis-type partitioning; the numpy
@@ -4400,14 +3506,30 @@ int gf_factor_scaled(int B, int64_t N, int64_t n_first, int W, int ld, const dou
     return check_launch("gf_factor_scaled");
 }
 
-#define GF_F3_ARGS dim3(B * nch), dim3(64), 0, st, N, n_first, chunk_len, nch, Jr, Jc, (block | (g_gen_period << 8)), gap, ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out, Ut_out, Wt_out, de_out, S_state, F_state, info
-#define GF_F3_CASE(R) case R: if ((g_pipelined == 0 || g_pipelined == 3) && Jr == 0 && Jc <= 31) hipLaunchKernelGGL((k_factor7<R>), GF_F3_ARGS); else if (g_pipelined == 0 || g_pipelined >= 3) hipLaunchKernelGGL((k_factor3<R>), GF_F3_ARGS); else if (g_pipelined == 2) hipLaunchKernelGGL((k_factor6<R>), GF_F3_ARGS); else if (r_out || Ut_out || de_out) hipLaunchKernelGGL((k_factor5<R, true>), GF_F3_ARGS); else hipLaunchKernelGGL((k_factor5<R, false>), GF_F3_ARGS); break;
-static int g_gen_period = 4;        // gf_set_generator_period
-static int g_pipelined = 0;         // gf_set_pipelined: 0 auto (k_factor7 where it applies, else k_factor3), 1 k_factor5, 2 k_factor6, 3 k_factor7, 4 k_factor3
+// which fused sweep runs (argument `variant` of gf_loglike_fused / gf_chunk_sweep / gf_chunk_transition)
+//   GF_SWEEP_AUTO   the lane-tiled k_factor7 / k_phi7 for kernels of complex terms only (Jr = 0,
+//                   Jc <= 31: every gadfly kernel with Q >= 1/2), k_factor3 / k_phi otherwise
+//   GF_SWEEP_COLUMN k_factor3 / k_phi (one column per lane), any term mix
+//   GF_SWEEP_TILED  k_factor7 / k_phi7; an error if the term structure does not allow it
+static bool sweep_tiled(int variant, int Jr, int Jc) {
+    return variant != GF_SWEEP_COLUMN && Jr == 0 && Jc <= 31;
+}
 
+#define GF_F3_ARGS dim3(B * nch), dim3(64), 0, st, N, n_first, chunk_len, nch, Jr, Jc, (block | (gen_period << 8)), gap, ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out, Ut_out, Wt_out, de_out, S_state, F_state, info
+#define GF_F3_CASE(R) case R: if (tiled) hipLaunchKernelGGL((k_factor7<R>), GF_F3_ARGS); else hipLaunchKernelGGL((k_factor3<R>), GF_F3_ARGS); break;
+
+static int check_sweep_options(const char *who, int gen_period, int variant, int Jr, int Jc) {
+    if (gen_period < 1 || gen_period > 64 || (gen_period & (gen_period - 1)))
+        return set_err("%s: gen_period=%lld must be a power of two in 1..64", who, gen_period);
+    if (variant < GF_SWEEP_AUTO || variant > GF_SWEEP_TILED)
+        return set_err("%s: unknown sweep variant %lld", who, variant);
+    if (variant == GF_SWEEP_TILED && !(Jr == 0 && Jc <= 31))
+        return set_err("%s: GF_SWEEP_TILED needs complex terms only (Jr = 0) and Jc <= 31 (Jc=%lld)", who, Jc);
+    return 0;
+}
 
 static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int64_t chunk_len, int nch,
-                        int Jr, int Jc, int block,
+                        int Jr, int Jc, int block, int gen_period, int variant,
                         const double *ar, const double *cr, const double *ac,
                         const double *bc, const double *cc, const double *dc,
                         const double *diag_add, const double *cmax,
@@ -4428,6 +3550,8 @@ static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int6
         return set_err("%s: bad chunking (chunk_len=%lld, nch=%lld)", who, chunk_len, nch);
     if (!t || !y || !d || !z || !S_state || !F_state || !info || !diag_add || !cmax)
         return set_err("%s: null pointer%s", who);
+    if (check_sweep_options(who, gen_period, variant, Jr, Jc)) return -1;
+    const bool tiled = sweep_tiled(variant, Jr, Jc);
     const double gap = (block > 1) ? SC_SPAN / (double)(block - 1) : 0.0;
     hipStream_t st = (hipStream_t)stream;
     const int rows = (W + 3) / 4 * 4;
@@ -4440,19 +3564,8 @@ static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int6
     return check_launch(who);
 }
 
-int gf_set_generator_period(int period) {
-    const int old = g_gen_period;
-    if (period >= 1 && period <= 64 && !(period & (period - 1))) g_gen_period = period;
-    return old;
-}
-
-int gf_set_pipelined(int on) {
-    const int old = g_pipelined;
-    g_pipelined = (on >= 0 && on <= 4) ? on : 0;
-    return old;
-}
-
 int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int block,
+                     int gen_period, int variant,
                      const double *ar, const double *cr, const double *ac,
                      const double *bc, const double *cc, const double *dc,
                      const double *diag_add, const double *cmax,
@@ -4460,39 +3573,13 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
                      const double *y, int64_t y_bs,
                      double *d, double *z, double *S_state, double *F_state,
                      int32_t *info, void *stream) {
-    return fused_launch("gf_loglike_fused", B, N, n_first, N, 1, Jr, Jc, block, ar, cr, ac, bc, cc, dc,
+    return fused_launch("gf_loglike_fused", B, N, n_first, N, 1, Jr, Jc, block, gen_period, variant, ar, cr, ac, bc, cc, dc,
                         diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, nullptr,
                         nullptr, nullptr, nullptr, S_state, F_state, info, stream);
 }
 
-// Blocked (rank-16, FP64 MFMA) form of gf_loglike_fused; same arguments and results.
-int gf_blocked_supported(int Jr, int Jc, int block) {
-    const int W = Jr + 2 * Jc;
-    return (W >= 1 && W <= 62 && (Jr & 1) == 0 && block >= 16 && block <= 64 && !(block & (block - 1))) ? 1 : 0;
-}
-
-int gf_loglike_blocked(int B, int64_t N, int64_t n_first, int Jr, int Jc, int block,
-                       const double *ar, const double *cr, const double *ac,
-                       const double *bc, const double *cc, const double *dc,
-                       const double *diag_add, const double *cmax,
-                       const double *t, int64_t t_bs, const double *diag, int64_t diag_bs,
-                       const double *y, int64_t y_bs,
-                       double *d, double *z, double *S_state, double *F_state,
-                       int32_t *info, void *stream) {
-    if (B < 1 || N < 1) return set_err("gf_loglike_blocked: empty problem (N=%s%lld)", "", N);
-    if (!gf_blocked_supported(Jr, Jc, block))
-        return set_err("gf_loglike_blocked: needs Jr even, W <= 62, block in {16, 32, 64} (block=%s%lld)", "", block);
-    if (n_first < 0 || (n_first % block) != 0) return set_err("gf_loglike_blocked: n_first=%s%lld must be a non-negative multiple of block=%lld", "", n_first, block);
-    if (!t || !y || !d || !z || !S_state || !F_state || !info || !diag_add || !cmax)
-        return set_err("gf_loglike_blocked: null pointer%s", "");
-    const double gap = SC_SPAN / (double)(block - 1);
-    hipLaunchKernelGGL(k_factor4, dim3(B), dim3(64), 0, (hipStream_t)stream, N, n_first, Jr, Jc, block, gap,
-                       ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs,
-                       d, z, S_state, F_state, info);
-    return check_launch("gf_loglike_blocked");
-}
-
 int gf_chunk_sweep(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc, int block,
+                   int gen_period, int variant,
                    const double *ar, const double *cr, const double *ac,
                    const double *bc, const double *cc, const double *dc,
                    const double *diag_add, const double *cmax,
@@ -4501,15 +3588,16 @@ int gf_chunk_sweep(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc,
                    double *d, double *z, double *r_out, double *Ut_out, double *Wt_out,
                    double *de_out, double *S_state, double *F_state,
                    int32_t *info, void *stream) {
-    return fused_launch("gf_chunk_sweep", B, N, 0, chunk_len, nch, Jr, Jc, block, ar, cr, ac, bc, cc, dc,
+    return fused_launch("gf_chunk_sweep", B, N, 0, chunk_len, nch, Jr, Jc, block, gen_period, variant, ar, cr, ac, bc, cc, dc,
                         diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out,
                         Ut_out, Wt_out, de_out, S_state, F_state, info, stream);
 }
 
-#define GF_PHI_ARGS dim3(B * nch), dim3(64), 0, st, N, (int64_t)0, chunk_len, nch, Jr, Jc, (block | (g_gen_period << 8)), gap, ar, cr, ac, bc, cc, dc, cmax, t, t_bs, dbar, rbar, h_out, Phi_out
-#define GF_PHI_CASE(R) case R: if ((g_pipelined == 0 || g_pipelined == 3) && Jr == 0 && Jc <= 31) hipLaunchKernelGGL((k_phi7<R>), GF_PHI_ARGS); else hipLaunchKernelGGL((k_phi<R>), GF_PHI_ARGS); break;
+#define GF_PHI_ARGS dim3(B * nch), dim3(64), 0, st, N, (int64_t)0, chunk_len, nch, Jr, Jc, (block | (gen_period << 8)), gap, ar, cr, ac, bc, cc, dc, cmax, t, t_bs, dbar, rbar, h_out, Phi_out
+#define GF_PHI_CASE(R) case R: if (tiled) hipLaunchKernelGGL((k_phi7<R>), GF_PHI_ARGS); else hipLaunchKernelGGL((k_phi<R>), GF_PHI_ARGS); break;
 
 int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc, int block,
+                        int gen_period, int variant,
                         const double *ar, const double *cr, const double *ac,
                         const double *bc, const double *cc, const double *dc,
                         const double *cmax, const double *t, int64_t t_bs,
@@ -4525,6 +3613,8 @@ int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int Jr, in
         return set_err("gf_chunk_transition: bad chunking (chunk_len=%s%lld, nch=%lld)", "", chunk_len, nch);
     if (!t || !dbar || !zbar || !rbar || !h_out || !Phi_out || !G_out || !m_out || !cmax)
         return set_err("gf_chunk_transition: null pointer%s", "");
+    if (check_sweep_options("gf_chunk_transition", gen_period, variant, Jr, Jc)) return -1;
+    const bool tiled = sweep_tiled(variant, Jr, Jc);
     const double gap = (block > 1) ? SC_SPAN / (double)(block - 1) : 0.0;
     hipStream_t st = (hipStream_t)stream;
     const int rows = (W + 3) / 4 * 4;
@@ -4538,15 +3628,26 @@ int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int Jr, in
     return check_launch("gf_chunk_transition");
 }
 
-// the > 64 KB dynamic-LDS opt-in is a per-device function attribute: remember it per device
-// (false the first time kernel group `which` is launched on the current device)
-static bool lds_opted_in(int which) {
-    static bool done[2][64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    const bool was = done[which][dev];
-    done[which][dev] = true;
-    return was;
+// the > 64 KB dynamic-LDS opt-in is a per-device function attribute: remember it per device -- the
+// device the STREAM belongs to (not the calling thread's current device) -- and apply it with that
+// device current.  Returns false if the attribute could not be set.
+static bool lds_opt_in(int which, hipStream_t st, const void *const *funcs, int nfuncs, size_t bytes) {
+    static std::atomic<bool> done[2][64];
+    int dev = -1;
+    if (st == nullptr || hipStreamGetDevice(st, &dev) != hipSuccess) {
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+    }
+    if (dev < 0 || dev >= 64) return false;
+    if (done[which][dev].load(std::memory_order_acquire)) return true;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return false;
+    if (cur != dev && hipSetDevice(dev) != hipSuccess) return false;
+    bool ok = true;
+    for (int i = 0; i < nfuncs; ++i)
+        ok = ok && hipFuncSetAttribute(funcs[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+    if (cur != dev) (void)hipSetDevice(cur);
+    if (ok) done[which][dev].store(true, std::memory_order_release);
+    return ok;
 }
 
 static size_t cb_lds_bytes(bool with_xn) {
@@ -4559,7 +3660,8 @@ int gf_chunk_combine(int B, int nch, const double *Phi, const double *G, const d
     if (B < 1 || nch < 1) return set_err("gf_chunk_combine: empty problem%s", "");
     if (!Phi || !G || !m || !S_state || !F_state) return set_err("gf_chunk_combine: null pointer%s", "");
     const size_t lds = cb_lds_bytes(true);
-    if (!lds_opted_in(0)) (void)hipFuncSetAttribute((const void *)k_combine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const void *fn[1] = {(const void *)k_combine};
+    if (!lds_opt_in(0, (hipStream_t)stream, fn, 1, lds)) return set_err("gf_chunk_combine: cannot opt in to %s%lld bytes of LDS", "", (long long)lds);
     hipLaunchKernelGGL(k_combine, dim3(B), dim3(256), lds, (hipStream_t)stream, nch, Phi, G, m, S_state, F_state);
     return check_launch("gf_chunk_combine");
 }
@@ -4574,10 +3676,8 @@ int gf_chunk_combine_tree(int B, int P, double *Phi, double *G, double *m, doubl
     if (!Phi || !G || !m || !S || !F || !Xst || !Yst) return set_err("gf_chunk_combine_tree: null pointer%s", "");
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = cb_lds_bytes(false);
-    if (!lds_opted_in(1)) {
-        (void)hipFuncSetAttribute((const void *)k_tree_compose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)k_tree_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
+    const void *fn[2] = {(const void *)k_tree_compose, (const void *)k_tree_apply};
+    if (!lds_opt_in(1, st, fn, 2, lds)) return set_err("gf_chunk_combine_tree: cannot opt in to %s%lld bytes of LDS", "", (long long)lds);
     TreeArgs A;
     A.P = P; A.Phi = Phi; A.G = G; A.S = S; A.F = F; A.m = m; A.Xst = Xst; A.Yst = Yst;
     for (int d = 1; d < P; d *= 2) {        // up-sweep

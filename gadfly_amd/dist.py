@@ -9,7 +9,7 @@ gloo in the CPU tests).  The gather is the only communication and carries a few 
 """
 import numpy as np
 
-__all__ = ["shard_bounds", "sharded_log_likelihood"]
+__all__ = ["shard_bounds", "sharded_log_likelihood", "gather_results"]
 
 
 def shard_bounds(B, world, rank):
@@ -17,6 +17,33 @@ def shard_bounds(B, world, rank):
     base, extra = divmod(B, world)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_results(local, B, group=None, device=None):
+    """All ranks' blocks of results -> the full (B,) array on every rank: ONE ``all_gather`` of
+    ceil(B / world) float64 per rank (RCCL over xGMI with the nccl backend, gloo on CPU).  ``local`` is
+    this rank's block of the static partition (:func:`shard_bounds`).  Runs the collective at any
+    world size, 1 included (the GPU test drives it that way on a one-GPU box)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = shard_bounds(B, world, rank)
+    local = np.asarray(local, dtype=np.float64)
+    if local.shape != (hi - lo,):
+        raise ValueError("dimension mismatch")
+    width = -(-B // world)
+    backend = dist.get_backend(group)
+    dev = torch.device(device if device is not None else
+                       (f"cuda:{torch.cuda.current_device()}" if backend == "nccl" else "cpu"))
+    buf = torch.full((width,), float("nan"), dtype=torch.float64, device=dev)
+    buf[:hi - lo] = torch.as_tensor(local, dtype=torch.float64, device=dev)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    res = np.empty(B)
+    for r in range(world):
+        a, b = shard_bounds(B, world, r)
+        res[a:b] = out[r][:b - a].cpu().numpy()
+    return res
 
 
 def sharded_log_likelihood(kernels, t, y, yerr=None, diag=None, mean=0.0, evaluate=None,
@@ -30,7 +57,6 @@ def sharded_log_likelihood(kernels, t, y, yerr=None, diag=None, mean=0.0, evalua
     (the tests inject a checker so the partition/gather logic runs under gloo without a GPU).
     Returns the full (B,) numpy array on every rank.
     """
-    import torch
     import torch.distributed as dist
 
     if evaluate is None:
@@ -56,16 +82,4 @@ def sharded_log_likelihood(kernels, t, y, yerr=None, diag=None, mean=0.0, evalua
                                     diag=part(diag), mean=mean), dtype=np.float64)
     if world == 1:
         return local
-    width = -(-B // world)
-    backend = dist.get_backend(group)
-    dev = torch.device(device if device is not None else
-                       (f"cuda:{torch.cuda.current_device()}" if backend == "nccl" else "cpu"))
-    buf = torch.full((width,), float("nan"), dtype=torch.float64, device=dev)
-    buf[:hi - lo] = torch.as_tensor(local, dtype=torch.float64, device=dev)
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf, group=group)
-    res = np.empty(B)
-    for r in range(world):
-        a, b = shard_bounds(B, world, r)
-        res[a:b] = out[r][:b - a].cpu().numpy()
-    return res
+    return gather_results(local, B, group=group, device=device)

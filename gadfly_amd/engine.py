@@ -15,11 +15,23 @@ HBM layout (float64, row-major, all torch tensors on one device):
                                 hold 0 for U/V/W and 1 for P)
     c              (B, Wd)      decay rates per column (prediction hops only)
 """
+import functools
 import math
 
 import numpy as np
 
 from . import _lib
+
+
+def _on_device(method):
+    """Run an engine method with the engine's own device current (allocations made inside, and
+    per-device attributes the library applies, then belong to the device of the buffers and the
+    stream -- whatever the caller's current device is)."""
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        with self.torch.cuda.device(self.device):
+            return method(self, *args, **kwargs)
+    return wrapper
 
 
 def _coeff_pack(coeffs_list):
@@ -128,6 +140,7 @@ class DeviceBatch:
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
+    @_on_device
     def _build(self):
         p = _lib.ptr
         st = self.lib.gf_build_matrices(
@@ -140,6 +153,7 @@ class DeviceBatch:
             p(self.a), p(self.U), p(self.V), p(self.P), self._stream())
         _lib.check(st, "gf_build_matrices")
 
+    @_on_device
     def matrices_at(self, tstar):
         """U*, V* at new times (M,) or (B, M) with zero diagonal (prediction)."""
         torch = self.torch
@@ -162,6 +176,7 @@ class DeviceBatch:
         return ts, Us, Vs
 
     # -- factor / log-likelihood ------------------------------------------
+    @_on_device
     def factor(self, y=None, keep_W=True):
         """LDL^T factor; with ``y`` (resid, (N,) | (1,N) | (B,N) device tensor) also the
         forward solve z = L^-1 y in the same sweep."""
@@ -199,6 +214,7 @@ class DeviceBatch:
         _lib.check(st, "gf_factor")
         return self.info
 
+    @_on_device
     def reduce(self, with_quad):
         """(loglike (B,), logdet (B,)) device tensors from d (and z when with_quad)."""
         torch = self.torch
@@ -224,6 +240,7 @@ class DeviceBatch:
         return out
 
     # -- sweeps with a stored factor ---------------------------------------
+    @_on_device
     def _sweep(self, mode, Y, scale=None, out=None):
         """Y: (B, N, R) contiguous device tensor."""
         torch = self.torch
@@ -252,6 +269,7 @@ class DeviceBatch:
         """L D^{1/2} Y (sqrt(d) fused into the sweep)."""
         return self._sweep(_lib.GF_MATMUL_LOWER, Y, scale=self.d)
 
+    @_on_device
     def predict_at(self, alpha, ts, Us, Vs, other=None):
         """Conditional mean at new times; ``other`` supplies (c, U, V, P) of a different
         kernel evaluated at the observed times (celerite2's ``kernel=`` argument)."""
@@ -313,6 +331,7 @@ class ScaledFactor:
         self._v1 = None
         self._D = None
 
+    @_on_device
     def _sweep(self, mode, Y, scale):
         torch = self.torch
         lib, p = self.lib, _lib.ptr
@@ -384,7 +403,7 @@ class StreamingBatch:
     """
 
     def __init__(self, coeffs_list, t, y, diag=None, tile_rows=8192, device=None,
-                 force_v1=False, overlap_build=False, allow_fused=True, allow_blocked=False):
+                 force_v1=False, overlap_build=False, allow_fused=True):
         torch = _lib.require_device()
         self.torch = torch
         self.lib = _lib.load()
@@ -435,6 +454,8 @@ class StreamingBatch:
             if diag.shape[1] != self.N:
                 raise ValueError("dimension mismatch")
             self.diag, self._dpad = padded(diag)
+        # largest user diagonal per problem (condition estimates and the accuracy guard)
+        self._diag_amax = None if self.diag is None else self.diag.amax(dim=1)
         self._coeff_host = (real, comp, diag_add, c)
         self._coeffs_list = list(coeffs_list)
         B, ld = self.B, self.ld
@@ -444,12 +465,10 @@ class StreamingBatch:
         self.scaled_wide = bool(self.lib.gf_scaled_wide_supported(self.W)) and not force_v1
         # W <= 63 and phases inside the fused kernel's sincos range: nothing is materialised
         self.allow_fused = bool(allow_fused) and self.scaled and self.W <= 63
-        # ... and, for an even number of real columns and scaling blocks of >= 16 rows, the
-        # blocked (rank-16) form of the same sweep on v_mfma_f64 (k_factor4).  Off by default:
-        # on gfx950 FP64 MFMA and vector instructions do not execute concurrently and run at the
-        # same FMA rate, so the blocked form is no faster than k_factor3
-        self.allow_blocked = bool(allow_blocked)
-        # rows between exact re-anchorings of the in-register generator (gf_set_generator_period):
+        # which fused sweep runs (GF_SWEEP_AUTO: lane-tiled where the term structure allows it);
+        # a call argument of the C-ABI, so engines with different settings coexist in one process
+        self.sweep_variant = _lib.GF_SWEEP_AUTO
+        # rows between exact re-anchorings of the in-register generator (`gen_period` argument):
         # 4 = throughput setting (log-likelihood within ~2e-9 at a condition of 4e5; 3 % slower than
         # 16, which reaches 1e-8 there), 1 = exact generation every row (float64-class accuracy,
         # 15 % slower)
@@ -529,10 +548,6 @@ class StreamingBatch:
         self.generator_period = period
         return cond, period
 
-    def _blocked_ok(self):
-        return (self.allow_blocked and self._fused_ok()
-                and bool(self.lib.gf_blocked_supported(self.Jr, self.Jc, self._pack[5])))
-
     def _make_pack(self, real, comp, diag_add, c):
         dev = self._dev
         cmax = np.max(c, axis=1)
@@ -577,6 +592,7 @@ class StreamingBatch:
             p(buf["a"]), p(buf["U"]), p(buf["V"]), p(buf["P"]), stream.cuda_stream)
         _lib.check(st, "gf_build_matrices")
 
+    @_on_device
     def log_likelihood(self):
         """Enqueue one evaluation per problem; returns the (B,) device tensor (no sync)."""
         torch = self.torch
@@ -648,10 +664,8 @@ class StreamingBatch:
         lib, p = self.lib, _lib.ptr
         T, N, B = self.tile_rows, self.N, self.B
         real, comp, diag_add, _, cmax, block, _ = self._pack
-        blocked = self._blocked_ok()
-        lib.gf_set_generator_period(int(self.generator_period))
-        sweep = lib.gf_loglike_blocked if blocked else lib.gf_loglike_fused
-        self.kernel_used = "blocked" if blocked else "fused"
+        period, variant = int(self.generator_period), int(self.sweep_variant)
+        self.kernel_used = "fused"
         for k in range((N + T - 1) // T):
             n0 = k * T
             rows = min(T, N - n0)
@@ -659,14 +673,14 @@ class StreamingBatch:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(main)
-            st = sweep(
-                B, rows, n0, self.Jr, self.Jc, block,
+            st = lib.gf_loglike_fused(
+                B, rows, n0, self.Jr, self.Jc, block, period, variant,
                 p(real[0]), p(real[1]), p(comp[0]), p(comp[1]), p(comp[2]), p(comp[3]),
                 p(diag_add), p(cmax), p(self.t), self._bs(self.t),
                 p(self.diag), 0 if self.diag is None else self._bs(self.diag),
                 p(self.y), self._bs(self.y), p(self.d), p(self.z),
                 p(self.S_state), p(self.F_state), p(self.info), main.cuda_stream)
-            _lib.check(st, "gf_loglike_blocked" if blocked else "gf_loglike_fused")
+            _lib.check(st, "gf_loglike_fused")
             if self.time_factor:
                 e1.record(main)
                 self.factor_events.append((e0, e1, rows))
@@ -692,6 +706,7 @@ class StreamingBatch:
         chunk_len = max(block, (int(chunk_len) + 63) // 64 * 64)
         return chunk_len, -(-N // chunk_len)
 
+    @_on_device
     def _tp_run(self, chunk_len=None, store=False):
         """Chunk-parallel factor + forward solve.  store=True also keeps the factor in scaled
         form (u~, w~ rows, reset spans, per-chunk true transitions) for :class:`ScaledFactor`."""
@@ -702,7 +717,7 @@ class StreamingBatch:
         N, B = self.N, self.B
         real, comp, diag_add, _, cmax, block, _ = self._pack
         chunk_len, nch = self._tp_chunking(chunk_len)
-        lib.gf_set_generator_period(int(self.generator_period))
+        opts = (int(self.generator_period), int(self.sweep_variant))
         f64 = dict(dtype=torch.float64, device=self.device)
         key = (chunk_len, nch)
         if getattr(self, "_tp_key", None) != key:
@@ -732,14 +747,14 @@ class StreamingBatch:
         none3 = (None, None, None)
 
         def transition(phi="Phi"):
-            rc = lib.gf_chunk_transition(B, N, chunk_len, nch, self.Jr, self.Jc, block, *coeffs,
+            rc = lib.gf_chunk_transition(B, N, chunk_len, nch, self.Jr, self.Jc, block, *opts, *coeffs,
                                          p(cmax), p(self.t), self._bs(self.t), p(w["d"]),
                                          p(w["z"]), p(w["r"]), p(w["h"]), p(w[phi]),
                                          p(w["G"]), p(w["m"]), st)
             _lib.check(rc, "gf_chunk_transition")
 
         if nch > 1:
-            rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, self.Jr, self.Jc, block, *coeffs,
+            rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, self.Jr, self.Jc, block, *opts, *coeffs,
                                     p(diag_add), p(cmax), *tyd, p(w["d"]), p(w["z"]), p(w["r"]),
                                     *none3, p(w["S"]), p(w["F"]), p(w["info"]), st)
             _lib.check(rc, "gf_chunk_sweep")
@@ -749,7 +764,7 @@ class StreamingBatch:
             # the true failing row; the final pass decides, from exact start states up to there
             w["info"].zero_()
         stores = (p(w["Ut"]), p(w["Wt"]), p(w["de"])) if store else none3
-        rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, self.Jr, self.Jc, block, *coeffs,
+        rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, self.Jr, self.Jc, block, *opts, *coeffs,
                                 p(diag_add), p(cmax), *tyd, p(w["d"]), p(w["z"]),
                                 p(w["r"]) if (store and nch > 1) else None, *stores,
                                 p(w["S"]), p(w["F"]), p(w["info"]), st)
@@ -805,6 +820,7 @@ class StreamingBatch:
         w["S"].view(B, nch, 4096).copy_(tr["X"][:, :nch])
         w["F"].view(B, nch, 64).copy_(tr["Y"][:, :nch])
 
+    @_on_device
     def log_likelihood_time_parallel(self, chunk_len=None):
         """
         One evaluation per problem with the time axis swept in parallel chunks and stitched by
@@ -819,6 +835,7 @@ class StreamingBatch:
             return self.log_likelihood()
         return self._tp_run(chunk_len, store=False)[0]
 
+    @_on_device
     def stored_factor(self, chunk_len=None):
         """Factorise (time-parallel) and keep the factor for triangular sweeps."""
         _, chunk_len, nch = self._tp_run(chunk_len, store=True)
@@ -833,6 +850,7 @@ class StreamingBatch:
             raise ValueError("dimension mismatch")
         self.y.copy_(r)
 
+    @_on_device
     def evaluate(self, time_parallel=None):
         """(loglike (B,), logdet (B,)) device tensors; picks the time-parallel evaluation for
         few long series (B * N large per problem, B small) unless told otherwise."""

@@ -111,23 +111,24 @@ class ConditionalDistribution:
         delta = float(getattr(kernel, "delta", 0.0) or 0.0)
         st = torch.cuda.current_stream(dev).cuda_stream
         for j0 in range(0, len(xs), self._RB):
-            xb = np.ascontiguousarray(xs[j0:j0 + self._RB])
-            R = len(xb)
-            xb_d = torch.as_tensor(xb, device=dev)
-            K = torch.empty((1, N, R), dtype=torch.float64, device=dev)
-            rc = lib.gf_cross_covariance(1, N, R, Jr, Jc, *[p(v) if v.numel() else None for v in cod],
-                                         p(t_d), 0, p(xb_d), 0, p(K), st)
-            _lib.check(rc, "gf_cross_covariance")
-            if delta > 0.0:
-                lo = np.searchsorted(gp._t, xb - delta, side="right")
-                hi = np.searchsorted(gp._t, xb + delta, side="left")
-                rows = np.concatenate([np.arange(a, b) for a, b in zip(lo, hi)]) if np.any(hi > lo) else np.empty(0, int)
-                if rows.size:
-                    cols = np.concatenate([np.full(b - a, r) for r, (a, b) in enumerate(zip(lo, hi))])
-                    vals = kernel.get_value(gp._t[rows] - xb[cols])
-                    K[0, torch.as_tensor(rows, device=dev), torch.as_tensor(cols, device=dev)] = \
-                        torch.as_tensor(vals, device=dev)
-            sol = gp._engine.apply_inverse(K)
+            with torch.cuda.device(dev):        # launches below go to the engine's GPU
+                xb = np.ascontiguousarray(xs[j0:j0 + self._RB])
+                R = len(xb)
+                xb_d = torch.as_tensor(xb, device=dev)
+                K = torch.empty((1, N, R), dtype=torch.float64, device=dev)
+                rc = lib.gf_cross_covariance(1, N, R, Jr, Jc, *[p(v) if v.numel() else None for v in cod],
+                                             p(t_d), 0, p(xb_d), 0, p(K), st)
+                _lib.check(rc, "gf_cross_covariance")
+                if delta > 0.0:
+                    lo = np.searchsorted(gp._t, xb - delta, side="right")
+                    hi = np.searchsorted(gp._t, xb + delta, side="left")
+                    rows = np.concatenate([np.arange(a, b) for a, b in zip(lo, hi)]) if np.any(hi > lo) else np.empty(0, int)
+                    if rows.size:
+                        cols = np.concatenate([np.full(b - a, r) for r, (a, b) in enumerate(zip(lo, hi))])
+                        vals = kernel.get_value(gp._t[rows] - xb[cols])
+                        K[0, torch.as_tensor(rows, device=dev), torch.as_tensor(cols, device=dev)] = \
+                            torch.as_tensor(vals, device=dev)
+                sol = gp._engine.apply_inverse(K)
             yield slice(j0, j0 + R), K[0], sol[0]
 
     @property

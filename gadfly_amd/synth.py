@@ -28,7 +28,7 @@ from .core import Hyperparameters, default_hyperparameter_path
 
 __all__ = [
     "solar_like_hyperparameters", "uniform_times", "jitter_hyperparameters",
-    "scale_hyperparameters", "broomhall_modes",
+    "scale_hyperparameters", "broomhall_modes", "cfg3_light_curves", "cfg4_walkers",
 ]
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
@@ -120,3 +120,30 @@ def scale_hyperparameters(hp, nu_factor):
                                              w0=h["w0"] * nu_factor, Q=h["Q"]),
                         metadata=dict(p["metadata"])))
     return Hyperparameters(out, name=hp.name)
+
+
+# ---- BASELINE.json's batched configurations, shared by tests/, tools/ and bench.py ----
+def cfg3_light_curves(B=256, N=65_000, J=20, seed=2000):
+    """cfg3: B stars = the solar-like kernel with (w0, S0) scaled by nu_max factors log-spaced
+    0.3 ... 1.0, Kepler short cadence (58.85 s) with a per-star start time (odd stars: jittered
+    time stamps, which the in-kernel row generator must take as exact rows), own y and yerr.
+    Returns (hyperparameter sets, t (B, N), y (B, N), yerr (B, N), exposure [s])."""
+    base = solar_like_hyperparameters(J)
+    hps = [scale_hyperparameters(base, f) for f in np.geomspace(0.3, 1.0, B)]
+    rng = np.random.Generator(np.random.PCG64(seed))
+    t = np.arange(N)[None, :] * 58.85e-6 + rng.uniform(0.0, 1e-3, (B, 1))
+    t[1::2] += rng.uniform(-2e-7, 2e-7, t[1::2].shape)
+    y = rng.normal(size=(B, N)) * 50.0 + np.cumsum(rng.normal(size=(B, N)), axis=1)
+    yerr = rng.uniform(20.0, 40.0, (B, 1)) * np.ones((1, N))
+    return hps, t, y, yerr, 58.85
+
+
+def cfg4_walkers(B=512, N=200_000, J=40, seed=12345):
+    """cfg4: B MCMC walkers (hyperparameters jittered +-10 %, seed 1000 + id) on ONE series:
+    shared t (60 s cadence) and y.  Returns (hyperparameter sets, t (N,), y (N,), exposure [s])."""
+    base = solar_like_hyperparameters(J)
+    hps = [jitter_hyperparameters(base, 1000 + i) for i in range(B)]
+    rng = np.random.Generator(np.random.PCG64(seed))
+    t = uniform_times(N, 60.0)
+    y = np.cumsum(rng.normal(size=N)) * 5.0 + 30.0 * rng.normal(size=N)
+    return hps, t, y, 60.0

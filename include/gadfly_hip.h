@@ -24,7 +24,8 @@
  *   - B independent problems per call (light curves or MCMC walkers); per-array
  *     batch strides are in elements, 0 = shared by all problems;
  *   - the caller owns every buffer (torch tensors on the Python side); the library allocates
- *     nothing and keeps no global state except the thread-local last-error string;
+ *     nothing and keeps no mutable global state: every option is a call argument (the only statics
+ *     are the thread-local last-error string and a per-device "large-LDS attribute applied" flag);
  *   - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work;
  *   - return value: 0 ok, < 0 bad arguments / launch error (see gf_last_error()).
  *     Numerical failure (non-positive pivot, celerite2's LinAlgError) is reported per problem
@@ -45,6 +46,12 @@ extern "C" {
 #define GF_SOLVE_LOWER   0      /* Z = L^-1 Y          driver.solve_lower  */
 #define GF_SOLVE_UPPER   1      /* Z = L^-T Y          driver.solve_upper  */
 #define GF_MATMUL_LOWER  2      /* Z = L Y             driver.matmul_lower (with V := W) */
+
+/* `variant` of gf_loglike_fused / gf_chunk_sweep / gf_chunk_transition: which fused sweep runs.
+ * Both agree to rounding and are parity-tested; callers pass GF_SWEEP_AUTO. */
+#define GF_SWEEP_AUTO    0      /* lane-tiled sweep where the term structure allows it, else by column */
+#define GF_SWEEP_COLUMN  1      /* k_factor3 / k_phi: one state column per lane, any mix of terms */
+#define GF_SWEEP_TILED   2      /* k_factor7 / k_phi7: 2 x 32 lane tiling; needs Jr = 0, Jc <= 31 */
 
 int gf_version(void);
 const char *gf_last_error(void);
@@ -136,8 +143,18 @@ int gf_factor_scaled(int B, int64_t N, int64_t n_first, int W, int ld, const dou
  * Cody-Waite sincos; the caller checks).  Arguments as in gf_build_scaled / gf_factor_scaled;
  * t, diag (NULL = 0), y are the WHOLE series (global row index, batch strides t_bs, diag_bs,
  * y_bs) and must be readable three elements past row n_first + N - 1.
+ *
+ * gen_period: accuracy / speed of the in-register generator rows (also of gf_chunk_sweep and
+ * gf_chunk_transition).  Between exact anchors the rows advance by a cached complex rotation; every
+ * `gen_period` rows (a power of two, 1..64) the phasor is recomputed exactly.  Measured at a
+ * condition (diagonal / pivot) of 4e5 against an 80-bit recurrence, per 8192-row tile of 2048
+ * evaluations: 1 (exact rows) 2e-10 / 12.2 ms, 4: 2e-9 / 10.4 ms, 16: 1e-8 / 10.0 ms, 64: several
+ * 1e-8 / 10.0 ms, i.e. error ~ 1.6e-15 * gen_period * condition.  Callers pick it from the condition
+ * estimate max(a) / min(d) that gf_reduce_tile returns (1 when in doubt).  Irregular spacings are
+ * always generated exactly.  variant: GF_SWEEP_AUTO (see the GF_SWEEP_* constants).
  */
 int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int block,
+                     int gen_period, int variant,
                      const double *ar, const double *cr, const double *ac,
                      const double *bc, const double *cc, const double *dc,
                      const double *diag_add, const double *cmax,
@@ -145,49 +162,6 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
                      const double *y, int64_t y_bs,
                      double *d, double *z, double *S_state, double *F_state,
                      int32_t *info, void *stream);
-
-/*
- * Accuracy / speed of the in-register generator rows of gf_loglike_fused, gf_chunk_sweep and
- * gf_chunk_transition: between exact anchors the rows advance by a cached complex rotation; every
- * `period` rows (a power of two, 1..64; default 4) the phasor is recomputed exactly.  Measured at a
- * condition (diagonal/pivot) of 4e5 against an 80-bit recurrence, and per 8192-row tile of 2048
- * evaluations: period 1 (exact rows) 2e-10 / 12.2 ms, 4: 2e-9 / 10.4 ms, 16: 1e-8 / 10.0 ms,
- * 64: several 1e-8 / 10.0 ms, i.e. error ~ 1.6e-15 * period * condition (1e-11 on the benchmark's
- * workload, condition 48, at any period).  Callers pick the period from the condition estimate
- * max(a) / min(d) that gf_reduce_tile returns.  Irregular spacings are always generated exactly.
- * Process-wide switch, returns the previous setting.
- */
-int gf_set_generator_period(int period);
-
-/*
- * Which fused sweep gf_loglike_fused / gf_chunk_sweep run (process-wide, returns the previous
- * setting; all variants agree to rounding and are parity-tested):
- *   0  automatic (default): k_factor7 -- 2 x 32 lane tiling, half the LDS operand traffic -- for
- *      kernels made of complex terms only (Jr = 0, Jc <= 31: every SHO term with Q > 1/2),
- *      k_factor3 (one column per lane) otherwise;
- *   3 / 4  the same two kernels by name (4 = k_factor3 everywhere), for A/B measurements;
- *   1  k_factor5, software-pipelined (the reductions, reciprocal and r, q of row n-1 issued between
- *      the FMA batches of sweep n);  2  k_factor6, split sweep (mat-vec with the not-yet-updated T,
- *      then the fold under the row's chain).  Both experimental and slower.
- */
-int gf_set_pipelined(int on);
-
-/*
- * The same fused sweep in blocked (rank-16) form on the FP64 matrix pipe: sixteen
- * rows of one scaling block are taken together, P = T U~, H = (V~ - P)^T U~ = L D L^T, T += R~ R~^T
- * run as v_mfma_f64_16x16x4_f64 and only the 16 x 16 LDL^T is sequential.  Same arguments, state
- * hand-off (S_state/F_state) and results (d, z to rounding) as gf_loglike_fused, but t, y, diag
- * need no padding.  gf_blocked_supported: Jr even, W <= 62, block in {16, 32, 64}.
- */
-int gf_blocked_supported(int Jr, int Jc, int block);
-int gf_loglike_blocked(int B, int64_t N, int64_t n_first, int Jr, int Jc, int block,
-                       const double *ar, const double *cr, const double *ac,
-                       const double *bc, const double *cc, const double *dc,
-                       const double *diag_add, const double *cmax,
-                       const double *t, int64_t t_bs, const double *diag, int64_t diag_bs,
-                       const double *y, int64_t y_bs,
-                       double *d, double *z, double *S_state, double *F_state,
-                       int32_t *info, void *stream);
 
 /*
  * Exact time-parallel evaluation of ONE long series (or a few): the N rows are cut into nch
@@ -211,10 +185,12 @@ int gf_loglike_blocked(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bl
  *                          Ut_out, Wt_out [B][N][64] and de_out [B][N] the pass also stores the
  *                          factor in scaled form (rows u~, w~ = r/d and the reset spans) for
  *                          gf_chunk_linear.
- * Same argument conventions and padding rules as gf_loglike_fused; dbar and rbar must be
+ * Same argument conventions (gen_period and variant included: pass the SAME values to all
+ * calls of one evaluation) and padding rules as gf_loglike_fused; dbar and rbar must be
  * readable two rows past the end.  Width 1..63, phases |d t| < 1.6e6.
  */
 int gf_chunk_sweep(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc, int block,
+                   int gen_period, int variant,
                    const double *ar, const double *cr, const double *ac,
                    const double *bc, const double *cc, const double *dc,
                    const double *diag_add, const double *cmax,
@@ -224,6 +200,7 @@ int gf_chunk_sweep(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc,
                    double *de_out, double *S_state, double *F_state,
                    int32_t *info, void *stream);
 int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc, int block,
+                        int gen_period, int variant,
                         const double *ar, const double *cr, const double *ac,
                         const double *bc, const double *cc, const double *dc,
                         const double *cmax, const double *t, int64_t t_bs,
@@ -262,7 +239,7 @@ int gf_chunk_linear_combine(int mode, int B, int64_t N, int64_t chunk_len, int n
  *                      rows; init != 0 overwrites acc, init == 0 accumulates (tiles in order).
  *                      z == NULL: second sum is 0.  work: B * gf_reduce_work(N) doubles.
  *                      min d gives the condition estimate max(a) / min(d) that selects the
- *                      generator period (gf_set_generator_period).
+ *                      generator period (gen_period of gf_loglike_fused).
  *   gf_loglike_finish: out[b] = -0.5 (acc0 + Ntot log 2pi) - 0.5 acc1; logdet[b] = acc0
  *                      (either may be NULL); info[b] != 0 -> -inf for both.
  */

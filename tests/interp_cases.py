@@ -1,5 +1,5 @@
 """Seeded input series for the ``interpolate_missing_data`` fixtures (inputs only: shared by
-tests/golden/make_interp_golden.py, which runs the REFERENCE on them, and by the tests, which compare
+tests/golden/reference/make_interp_golden.py, which runs the REFERENCE on them, and by the tests, which compare
 the oracle restatement and the HIP kernels with the stored reference outputs)."""
 import numpy as np
 

@@ -48,9 +48,12 @@ def test_bad_arguments_are_status_codes_not_crashes():
     st = lib.gf_build_scaled(1, 16, 3, 0, 2, 16, *([None] * 8), 8, None, 0, None, 0,
                              *([None] * 4), None)
     assert st < 0 and b"n_first" in lib.gf_last_error()
-    st = lib.gf_loglike_fused(1, 16, 0, 0, 32, 8, *([None] * 8), None, 0, None, 0, None, 0,
+    st = lib.gf_loglike_fused(1, 16, 0, 0, 32, 8, 1, 0, *([None] * 8), None, 0, None, 0, None, 0,
                               *([None] * 5), None)
     assert st < 0 and b"width" in lib.gf_last_error()
+    # the product ABI has no process-wide switches and ships no experimental sweeps
+    for gone in ("gf_set_generator_period", "gf_set_pipelined", "gf_loglike_blocked"):
+        assert not hasattr(lib, gone)
 
 
 @pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="CPU-only behaviour")

@@ -27,35 +27,18 @@ def _relmax(a, b):
     return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
 
 
-def _cfg3_problem(B, N, J=20, seed=2000):
-    """B stars = the solar-like kernel with (w0, S0) scaled by nu_max factors log-spaced 0.3..1.0,
-    Kepler short cadence (58.85 s) with per-star time offsets (odd stars: jittered stamps, which
-    the in-kernel row generator must take as exact rows), own y and yerr."""
+def _cfg3_problem(B, N):
     import gadfly_amd
-    from gadfly_amd.synth import solar_like_hyperparameters, scale_hyperparameters
-    base = solar_like_hyperparameters(J)
-    kernels = [gadfly_amd.StellarOscillatorKernel(scale_hyperparameters(base, f), texp=58.85)
-               for f in np.geomspace(0.3, 1.0, B)]
-    rng = np.random.Generator(np.random.PCG64(seed))
-    # own time axis per light curve: same cadence, different start and a little jitter
-    t = np.arange(N)[None, :] * 58.85e-6 + rng.uniform(0.0, 1e-3, (B, 1))
-    t[1::2] += rng.uniform(-2e-7, 2e-7, t[1::2].shape)      # every other star: jittered stamps
-    y = rng.normal(size=(B, N)) * 50.0 + np.cumsum(rng.normal(size=(B, N)), axis=1)
-    yerr = rng.uniform(20.0, 40.0, (B, 1)) * np.ones((1, N))
-    return kernels, t, y, yerr
+    from gadfly_amd.synth import cfg3_light_curves
+    hps, t, y, yerr, texp = cfg3_light_curves(B, N)
+    return [gadfly_amd.StellarOscillatorKernel(hp, texp=texp) for hp in hps], t, y, yerr
 
 
-def _cfg4_problem(B, N, J=40, seed=12345):
-    """B walkers: hyperparameters jittered +-10 % (seed 1000 + id) on ONE series (shared t, y)."""
+def _cfg4_problem(B, N):
     import gadfly_amd
-    from gadfly_amd.synth import solar_like_hyperparameters, jitter_hyperparameters
-    base = solar_like_hyperparameters(J)
-    kernels = [gadfly_amd.StellarOscillatorKernel(jitter_hyperparameters(base, 1000 + i), texp=60.0)
-               for i in range(B)]
-    rng = np.random.Generator(np.random.PCG64(seed))
-    t = np.arange(N) * 60e-6
-    y = np.cumsum(rng.normal(size=N)) * 5.0 + 30.0 * rng.normal(size=N)
-    return kernels, t, y
+    from gadfly_amd.synth import cfg4_walkers
+    hps, t, y, texp = cfg4_walkers(B, N)
+    return [gadfly_amd.StellarOscillatorKernel(hp, texp=texp) for hp in hps], t, y
 
 
 def _ref_ll(kernel, t, diag, y):

@@ -38,7 +38,7 @@ def test_sharded_log_likelihood_rccl(hip):
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["GADFLY_ROOT"])
 import gadfly_amd
-from gadfly_amd.dist import sharded_log_likelihood
+from gadfly_amd.dist import sharded_log_likelihood, gather_results
 from gadfly_amd.synth import solar_like_hyperparameters, uniform_times, jitter_hyperparameters
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
@@ -47,6 +47,9 @@ ks = [gadfly_amd.StellarOscillatorKernel(jitter_hyperparameters(base, 10 + i), t
 t = uniform_times(4096, 60.0)
 y = np.random.default_rng(0).normal(size=4096) * 50
 ll = sharded_log_likelihood(ks, t, y, yerr=30.0)
+# the gather helper itself over RCCL (sharded_log_likelihood returns before it at world size 1)
+full = gather_results(ll, len(ks), device="cuda:0")
+assert full.shape == (5,) and np.array_equal(full, ll)
 buf = torch.tensor([1.5], dtype=torch.float64, device="cuda:0")
 dist.all_reduce(buf, op=dist.ReduceOp.MAX)
 out = [torch.empty_like(buf)]

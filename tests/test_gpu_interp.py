@@ -44,7 +44,7 @@ def _case_names():
 @pytest.mark.parametrize("name", _case_names())
 def test_matches_reference_fixtures(hip, name):
     """The HIP kernels against the outputs of the REFERENCE's own interpolate_missing_data
-    (tests/golden/interp_reference.npz, made by tests/golden/make_interp_golden.py from
+    (tests/golden/reference/interp_reference.npz, made by tests/golden/reference/make_interp_golden.py from
     /root/reference/gadfly/interp.py): bit-identical times and fluxes."""
     import gadfly_amd
     from tests.test_interp_reference import check_against_fixture

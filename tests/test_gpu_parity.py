@@ -238,11 +238,11 @@ STREAM_CASES = [
 
 
 @pytest.mark.parametrize("case", STREAM_CASES, ids=lambda c: f"{c[0]}-{c[1]}-T{c[2]}")
-@pytest.mark.parametrize("mode", ["blocked", "fused", "scaled", "v1"])
+@pytest.mark.parametrize("mode", ["fused", "scaled", "v1"])
 def test_streaming_loglike(hip, case, mode):
     """Tile-streamed evaluation (all three kernel families) against the oracle, including the
     state hand-off between tiles and the block-scaled coordinates' reset rows."""
-    force_v1, allow_fused = mode == "v1", mode in ("fused", "blocked")
+    force_v1, allow_fused = mode == "v1", mode == "fused"
     from gadfly_amd.engine import StreamingBatch
     from oracle import cref
     kind, kw, tile = case
@@ -250,16 +250,12 @@ def test_streaming_loglike(hip, case, mode):
     k, t, y = prob["kernel"], prob["t"], prob["y"]
     co = k.get_device_coefficients()
     eng = StreamingBatch([co], t, y, diag=prob["diag_user"], tile_rows=tile, force_v1=force_v1,
-                         allow_fused=allow_fused, allow_blocked=(mode == "blocked"))
+                         allow_fused=allow_fused)
     if allow_fused:
         assert eng._fused_ok() == (eng.W <= 63)
     if eng.W > 64:
         assert eng.scaled_wide == (not force_v1) and not eng.scaled
-    if mode == "blocked" and not eng._blocked_ok():
-        pytest.skip("blocked kernel needs Jr even, W <= 62, block >= 16")
     ll = float(eng.log_likelihood()[0])
-    if mode == "blocked":
-        assert eng.kernel_used == "blocked"
     ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y)
     assert info == 0
     assert abs(ll - ref) <= RTOL_LL * abs(ref), (ll, ref)
@@ -332,43 +328,6 @@ def test_streaming_irregular_cadence_fused(hip):
         assert info == 0 and abs(ll - ref) <= RTOL_LL * abs(ref), (allow_fused, ll, ref)
 
 
-@pytest.mark.parametrize("case", [STREAM_CASES[0], STREAM_CASES[1], STREAM_CASES[2], STREAM_CASES[6]],
-                         ids=["solar6", "solar20jitter", "solar30gaps", "overdamped"])
-@pytest.mark.parametrize("mode", [1, 2, 3], ids=["pipelined", "split", "tiled"])
-def test_pipelined_variant(hip, case, mode):
-    """The alternative sweeps (gf_set_pipelined(1): software-pipelined k_factor5; (2): split-sweep
-    k_factor6; (3): 2 x 32 lane tiling k_factor7, complex terms only, others fall back) give the
-    results of the default kernel: streamed tiles with state hand-off, and the time-parallel evaluation
-    (chunk mode with the extra row stores)."""
-    from gadfly_amd.engine import StreamingBatch
-    from oracle import cref
-    kind, kw, tile = case
-    prob = _make((kind, kw))
-    k, t, y = prob["kernel"], prob["t"], prob["y"]
-    co = k.get_device_coefficients()
-    ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y)
-    assert info == 0
-    lib = hip.load()
-    old = lib.gf_set_pipelined(mode)
-    try:
-        eng = StreamingBatch([co], t, y, diag=prob["diag_user"], tile_rows=tile)
-        assert eng._fused_ok()
-        ll = float(eng.log_likelihood()[0])
-        assert abs(ll - ref) <= RTOL_LL * abs(ref), (ll, ref)
-        ll_tp = float(eng.log_likelihood_time_parallel(chunk_len=128)[0])
-        assert abs(ll_tp - ref) <= RTOL_LL * abs(ref), (ll_tp, ref)
-        fac = eng.stored_factor(chunk_len=128)
-    finally:
-        lib.gf_set_pipelined(old)
-    import torch
-    c, a, U, V = util.oracle_matrices(prob, __import__("oracle.seq", fromlist=["seq"]))
-    d_ref, W_ref, _ = cref.factor(t, c, a, U, V)
-    Y = np.random.default_rng(5).normal(size=(len(t), 3))
-    ref_ai = cref.solve_upper(t, c, U, W_ref, cref.solve_lower(t, c, U, W_ref, Y) / d_ref[:, None])
-    got = fac.apply_inverse(torch.as_tensor(Y).cuda().reshape(1, len(t), 3))[0].cpu().numpy()
-    assert _relmax(got, ref_ai) < TOL_VEC
-
-
 @pytest.mark.parametrize("J,N,tile", [(1, 700, 128), (6, 1500, 256), (30, 2500, 512), (31, 2000, 320)],
                          ids=["W2", "W12", "W60", "W62"])
 def test_fused_kernels_by_name(hip, J, N, tile):
@@ -389,24 +348,41 @@ def test_fused_kernels_by_name(hip, J, N, tile):
     d_ref, W_ref, _ = cref.factor(t, c, a, U, V)
     Y = np.random.default_rng(J).normal(size=(len(t), 2))
     ref_ai = cref.solve_upper(t, c, U, W_ref, cref.solve_lower(t, c, U, W_ref, Y) / d_ref[:, None])
-    lib = hip.load()
     got = {}
-    for mode in (3, 4):
-        old = lib.gf_set_pipelined(mode)
-        try:
-            eng = StreamingBatch([co], t, y, diag=prob["diag_user"], tile_rows=tile)
-            assert eng._fused_ok()
-            ll = float(eng.log_likelihood()[0])
-            ll_tp = float(eng.log_likelihood_time_parallel(chunk_len=128)[0])
-            fac = eng.stored_factor(chunk_len=128)
-        finally:
-            lib.gf_set_pipelined(old)
+    engines = {}
+    for mode in (hip.GF_SWEEP_TILED, hip.GF_SWEEP_COLUMN):
+        # the variant is a call argument of the C-ABI: both engines stay alive side by side
+        eng = engines[mode] = StreamingBatch([co], t, y, diag=prob["diag_user"], tile_rows=tile)
+        eng.sweep_variant = mode
+        assert eng._fused_ok()
+    for mode, eng in engines.items():
+        ll = float(eng.log_likelihood()[0])
+        ll_tp = float(eng.log_likelihood_time_parallel(chunk_len=128)[0])
+        fac = eng.stored_factor(chunk_len=128)
         assert abs(ll - ref) <= RTOL_LL * abs(ref), (mode, ll, ref)
         assert abs(ll_tp - ref) <= RTOL_LL * abs(ref), (mode, ll_tp, ref)
         ai = fac.apply_inverse(torch.as_tensor(Y).cuda().reshape(1, len(t), 2))[0].cpu().numpy()
         assert _relmax(ai, ref_ai) < TOL_VEC, mode
         got[mode] = ll
-    assert abs(got[3] - got[4]) <= 1e-11 * abs(ref)
+    assert abs(got[hip.GF_SWEEP_TILED] - got[hip.GF_SWEEP_COLUMN]) <= 1e-11 * abs(ref)
+
+
+def test_sweep_options_are_checked(hip):
+    """gen_period / variant are validated call arguments (no process-wide switches): a tiled sweep
+    asked for a kernel with real terms, or a period that is not a power of two, is refused."""
+    from gadfly_amd.engine import StreamingBatch
+    prob = util.generic_problem("mixed", 300)
+    co = prob["kernel"].get_device_coefficients()
+    eng = StreamingBatch([co], prob["t"], prob["y"], diag=prob["diag_user"], tile_rows=64)
+    eng.sweep_variant = hip.GF_SWEEP_TILED
+    with pytest.raises(hip.GadflyHipError, match="GF_SWEEP_TILED"):
+        eng.log_likelihood()
+    eng.sweep_variant = hip.GF_SWEEP_AUTO
+    eng.generator_period = 3
+    with pytest.raises(hip.GadflyHipError, match="gen_period"):
+        eng.log_likelihood()
+    eng.generator_period = 1
+    assert np.isfinite(float(eng.log_likelihood()[0]))
 
 
 TP_CASES = [

@@ -144,3 +144,47 @@ def test_generator_calibration(hip):
     assert cond > 1e5 and period == 1
     ref, _ = cref.loglike(co[:6], prob["t"], prob["diag_user"] + co[6], prob["y"])
     assert abs(float(eng.log_likelihood()[0]) - ref) <= 2e-9 * abs(ref)
+
+
+def test_accuracy_guard_reruns_an_ill_conditioned_walker(hip):
+    """The generator period is calibrated on well-conditioned walkers (period 64); then ONE walker of
+    a later proposal is badly conditioned (amplitudes x 3e4: condition ~1e6).  The device-side guard
+    must flag exactly that evaluation and repeat it with exact rows, so that every entry still
+    matches the oracle at 1e-8 -- accuracy does not depend on the sampler standing still."""
+    import gadfly_amd
+    from gadfly_amd.core import Hyperparameters
+    from gadfly_amd.synth import solar_like_hyperparameters, jitter_hyperparameters
+    from oracle import cref
+    N, J, B = 6000, 12, 6
+    base = solar_like_hyperparameters(J)
+    t = np.arange(N) * 60e-6
+    rng = np.random.default_rng(9)
+    y = np.cumsum(rng.normal(size=N)) * 5.0 + 30.0 * rng.normal(size=N)
+    kernels = [gadfly_amd.StellarOscillatorKernel(jitter_hyperparameters(base, 50 + i), texp=60.0)
+               for i in range(B)]
+    ev = gadfly_amd.BatchedLogLikelihood(kernels, t, y, yerr=30.0, tile_rows=1024)
+    ev.engine.force_streaming = True
+    ev.evaluate()
+    assert ev.engine.generator_period == 64 and ev.guard_reruns == 0
+    # next proposal: walker 3 jumps to a region with huge amplitudes
+    hot = Hyperparameters([dict(hyperparameters=dict(S0=p["hyperparameters"]["S0"] * 3e4,
+                                                     w0=p["hyperparameters"]["w0"],
+                                                     Q=p["hyperparameters"]["Q"]),
+                                metadata=dict(p["metadata"])) for p in base], name="hot")
+    kernels2 = list(kernels)
+    kernels2[3] = gadfly_amd.StellarOscillatorKernel(hot, texp=60.0)
+    ev.auto_generator_period = False                  # the period stays at 64: only the guard protects
+    out = ev.evaluate_device(ev.pack(kernels2))       # asynchronous path
+    unguarded = out.clone()
+    assert ev.resolve() == 1 and ev.guard_reruns == 1
+    got = out.cpu().numpy()
+    for i, k in enumerate(kernels2):
+        co = k.get_device_coefficients()
+        ref, info = cref.loglike(co[:6], t, np.full(N, 900.0) + co[6], y)
+        assert info == 0 and abs(got[i] - ref) <= 1e-8 * abs(ref), (i, got[i], ref)
+    # the other entries were not touched; the flagged one was replaced by the exact-row result
+    same = np.arange(B) != 3
+    assert np.array_equal(unguarded.cpu().numpy()[same], got[same])
+    ev.engine.generator_period = 1
+    exact = ev.evaluate_device(ev.pack(kernels2)).cpu().numpy()
+    assert exact[3] == got[3]

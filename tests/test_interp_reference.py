@@ -1,6 +1,6 @@
 """
 The restatement of ``interpolate_missing_data`` (oracle/interp_ref.py) against fixtures produced by
-the REFERENCE ITSELF (/root/reference/gadfly/interp.py:6-60 run by tests/golden/make_interp_golden.py
+the REFERENCE ITSELF (/root/reference/gadfly/interp.py:6-60 run by tests/golden/reference/make_interp_golden.py
 in the build container): bit-for-bit.  This is the one part of the oracle that is pinned at the
 reference level; the celerite recurrences stay "parity unpinned" (DESIGN.md 3).
 The GPU counterpart is tests/test_gpu_interp.py::test_matches_reference_fixtures.
@@ -14,7 +14,7 @@ import pytest
 from oracle import interp_ref
 from tests.interp_cases import CASES, make_case, FULL_ARRAYS_BELOW
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "interp_reference.npz")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference", "interp_reference.npz")
 
 
 def digest(*arrays):

@@ -1,8 +1,19 @@
 #!/usr/bin/env python
-"""Throughput of the batched log-likelihood path on BASELINE.json's batched configs (per GPU share):
-cfg3: 256 Kepler-cadence light curves (N=65,000, J=20)    -- own t, y and kernel per light curve
-cfg4: 512 walkers on one N=200,000, J=40 series           -- shared t, y
-Usage: python tools/configs.py [fraction]   (fraction of the full batch evaluated on this GPU, default 1)"""
+"""
+BASELINE.json's configurations beyond the headline, measured on ONE GPU (whole batch on this GPU):
+
+  cfg2  N=1e6, J=30 single series through the drop-in class: compute, log_likelihood,
+        predict(y) [conditional mean at the observed times], predict(y, t*=1000 new times)
+  cfg3  256 Kepler-cadence light curves (N=65,000, J=20), own t, y, yerr and kernel each
+  cfg4  512 MCMC walkers on one N=200,000, J=40 series (shared t, y)
+  cfg5  dot_tril of 64 normal vectors (GP.sample's arithmetic) at N=500,000, J=30
+
+Each function returns a dict of measured numbers (ms, units/s, algorithmic GB/s per SURVEY.md 8d and
+its fraction of the 8 TB/s HBM peak) plus a ``_sample``: the inputs and the GPU's answer for ONE
+entry, which bench.py checks against the oracle (this module never touches oracle/).
+
+Usage: python tools/configs.py           (prints the table; bench.py embeds the same numbers)
+"""
 import os
 import sys
 import time
@@ -10,37 +21,147 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch  # noqa: E402
-import gadfly_amd  # noqa: E402
-from gadfly_amd.synth import (solar_like_hyperparameters, jitter_hyperparameters,  # noqa: E402
-                              scale_hyperparameters)
 
-frac = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
-rng = np.random.Generator(np.random.PCG64(12345))
+HBM_PEAK_GBS = 8000.0
 
 
-def run(name, ev, B):
-    ev.evaluate_device(); torch.cuda.synchronize()
-    t0 = time.perf_counter(); out = ev.evaluate_device(); torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    assert bool(torch.isfinite(out).all())
-    print(f"{name}: B={B} in {dt*1e3:8.1f} ms -> {B/dt:9.1f} evals/s "
-          f"(kernels: {'fused' if ev.engine._fused_ok() else ('scaled' if ev.engine.scaled else ('scaled-wide' if ev.engine.scaled_wide else 'v1'))})")
+def _clock(torch, fn, reps=3, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    out = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), out
 
 
-# cfg3
-B, N, J = max(1, int(256 * frac)), 65_000, 20
-base = solar_like_hyperparameters(J)
-kernels = [gadfly_amd.StellarOscillatorKernel(scale_hyperparameters(base, f), texp=58.85)
-           for f in np.geomspace(0.3, 1.0, B)]
-t = np.tile(np.arange(N) * 58.85e-6, (B, 1))
-y = rng.normal(size=(B, N)) * 50.0
-run("cfg3 (N=65000, J=20)", gadfly_amd.BatchedLogLikelihood(kernels, t, y, yerr=30.0), B)
-# cfg4
-B, N, J = max(1, int(512 * frac)), 200_000, 40
-base = solar_like_hyperparameters(J)
-kernels = [gadfly_amd.StellarOscillatorKernel(jitter_hyperparameters(base, 1000 + i), texp=60.0)
-           for i in range(B)]
-t = np.arange(N) * 60e-6
-y = np.cumsum(rng.normal(size=N)) * 5.0 + 30.0 * rng.normal(size=N)
-run("cfg4 (N=200000, J=40)", gadfly_amd.BatchedLogLikelihood(kernels, t, y, yerr=30.0), B)
+def _path(eng):
+    if eng._fused_ok():
+        return "time-parallel fused" if getattr(eng, "_tp_used", False) else "fused"
+    if getattr(eng, "_wide_ok", lambda: False)():
+        return "fused-wide"
+    return "scaled" if eng.scaled else ("scaled-wide" if eng.scaled_wide else "v1")
+
+
+def measure_cfg3(frac=1.0):
+    import torch
+    import gadfly_amd
+    from gadfly_amd.synth import cfg3_light_curves
+    B, N, J = max(1, int(256 * frac)), 65_000, 20
+    hps, t, y, yerr, texp = cfg3_light_curves(B, N, J)
+    kernels = [gadfly_amd.StellarOscillatorKernel(hp, texp=texp) for hp in hps]
+    ev = gadfly_amd.BatchedLogLikelihood(kernels, t, y, yerr=yerr)
+    ev.evaluate()                                   # warm-up + generator calibration
+    dt, out = _clock(torch, ev.evaluate_device, reps=5, warm=1)
+    ll = out.cpu().numpy()
+    W = 2 * J
+    gb = 8.0 * N * (3 * W + 4) * B / 1e9
+    i = min(100, B - 1)
+    return {"workload": f"cfg3: {B} light curves x N={N}, J={J} (W={W}), own t/y/yerr/kernel",
+            "value": B / dt, "unit": "evals/s", "ms": 1e3 * dt, "algorithmic_GB": gb,
+            "algorithmic_GBs": gb / dt, "frac": gb / dt / HBM_PEAK_GBS, "path": _path(ev.engine),
+            "generator_period": int(ev.engine.generator_period), "all_finite": bool(np.all(np.isfinite(ll))),
+            "_sample": dict(kind="loglike", index=i, coeffs=kernels[i].get_device_coefficients(),
+                            t=t[i], diag=yerr[i] ** 2, y=y[i], got=float(ll[i]))}
+
+
+def measure_cfg4(frac=1.0):
+    import torch
+    import gadfly_amd
+    from gadfly_amd.synth import cfg4_walkers
+    B, N, J = max(1, int(512 * frac)), 200_000, 40
+    hps, t, y, texp = cfg4_walkers(B, N, J)
+    kernels = [gadfly_amd.StellarOscillatorKernel(hp, texp=texp) for hp in hps]
+    ev = gadfly_amd.BatchedLogLikelihood(kernels, t, y, yerr=30.0)
+    ev.evaluate()
+    dt, out = _clock(torch, ev.evaluate_device, reps=3, warm=0)
+    ll = out.cpu().numpy()
+    W = 2 * J
+    gb = 8.0 * N * (3 * W + 4) * B / 1e9
+    i = B - 1
+    return {"workload": f"cfg4: {B} walkers x N={N}, J={J} (W={W}), shared t, y",
+            "value": B / dt, "unit": "evals/s", "ms": 1e3 * dt, "algorithmic_GB": gb,
+            "algorithmic_GBs": gb / dt, "frac": gb / dt / HBM_PEAK_GBS, "path": _path(ev.engine),
+            "generator_period": int(ev.engine.generator_period), "all_finite": bool(np.all(np.isfinite(ll))),
+            "_sample": dict(kind="loglike", index=i, coeffs=kernels[i].get_device_coefficients(),
+                            t=t, diag=np.full(N, 900.0), y=y, got=float(ll[i]))}
+
+
+def measure_cfg5():
+    import torch
+    import gadfly_amd
+    from gadfly_amd.synth import solar_like_hyperparameters, uniform_times
+    N, J, R = 500_000, 30, 64
+    k = gadfly_amd.StellarOscillatorKernel(solar_like_hyperparameters(J), texp=60.0)
+    t = uniform_times(N, 60.0)
+    gp = gadfly_amd.GaussianProcess(k, t=t, yerr=30.0)
+    eng = gp._engine                                # stored factor (time-parallel factorisation)
+    np.random.seed(42)
+    n = np.random.randn(N, R)
+    nd = gp._to_device(n).reshape(1, N, R)
+    dt, Z = _clock(torch, lambda: eng.dot_tril(nd), reps=5, warm=1)
+    np.random.seed(42)
+    t0 = time.perf_counter()
+    draws = gp.sample(size=R)
+    t_api = time.perf_counter() - t0
+    W = 2 * J
+    gb = 8.0 * N * (2 * W + 2 + 2 * R) / 1e9
+    col = 17
+    return {"workload": f"cfg5: dot_tril of {R} normal vectors, N={N}, J={J} (W={W}); vectors resident in HBM",
+            "value": R / dt, "unit": "draws/s", "ms": 1e3 * dt, "algorithmic_GB": gb,
+            "algorithmic_GBs": gb / dt, "frac": gb / dt / HBM_PEAK_GBS,
+            "sample_api_ms": 1e3 * t_api,
+            "sample_api_note": "gp.sample(size=64) end to end: numpy legacy randn on the host (the reference's "
+                               "RNG contract) + PCIe both ways + the device work above",
+            "draws_shape": list(draws.shape),
+            "_sample": dict(kind="dot_tril", column=col, coeffs=k.get_device_coefficients(), t=t,
+                            diag=np.full(N, 900.0), n=n[:, col].copy(),
+                            got=Z[0, :, col].cpu().numpy())}
+
+
+def measure_cfg2_api():
+    import torch
+    import gadfly_amd
+    from gadfly_amd.synth import solar_like_hyperparameters, uniform_times
+    N, J = 1_000_000, 30
+    k = gadfly_amd.StellarOscillatorKernel(solar_like_hyperparameters(J), texp=60.0)
+    t = uniform_times(N, 60.0)
+    rng = np.random.Generator(np.random.PCG64(12345))
+    y = np.cumsum(rng.normal(size=N)) * 5.0 + 30.0 * rng.normal(size=N)
+    gp = gadfly_amd.GaussianProcess(k)
+    c_ms, _ = _clock(torch, lambda: gp.compute(t, yerr=30.0), reps=2, warm=1)
+    l_ms, ll = _clock(torch, lambda: gp.log_likelihood(y), reps=3, warm=1)
+    _ = gp._engine
+    p_ms, mu = _clock(torch, lambda: gp.predict(y), reps=3, warm=1)
+    ts = np.sort(rng.uniform(t[0], t[-1], 1000))
+    q_ms, mus = _clock(torch, lambda: gp.predict(y, t=ts), reps=2, warm=1)
+    W = 2 * J
+    gb_ll = 8.0 * N * (3 * W + 4) / 1e9
+    gb_ai = 8.0 * N * (4 * W + 7) / 1e9
+    idx = np.linspace(0, N - 1, 64).astype(int)
+    return {"workload": f"cfg2 through the drop-in GaussianProcess: N={N}, J={J} (W={W}), ONE series "
+                        "(latency path: exact time-parallel factorisation / sweeps); host arrays in, "
+                        "host arrays out (PCIe included)",
+            "compute_ms": 1e3 * c_ms, "log_likelihood_ms": 1e3 * l_ms,
+            "predict_mean_ms": 1e3 * p_ms, "predict_1000_new_times_ms": 1e3 * q_ms,
+            "compute_plus_loglike_algorithmic_GBs": gb_ll / (c_ms + l_ms),
+            "predict_mean_algorithmic_GBs": gb_ai / p_ms,
+            "predict_mean_frac": gb_ai / p_ms / HBM_PEAK_GBS,
+            "_sample": dict(kind="predict", coeffs=k.get_device_coefficients(), t=t, diag=np.full(N, 900.0),
+                            y=y, ts=ts, idx=idx, got_ll=float(ll), got_mu=mu[idx].copy(), got_mus=mus.copy())}
+
+
+def main():
+    import json
+    for fn in (measure_cfg2_api, measure_cfg3, measure_cfg4, measure_cfg5):
+        r = fn()
+        r.pop("_sample", None)
+        print(json.dumps(r))
+
+
+if __name__ == "__main__":
+    main()
