@@ -46,6 +46,8 @@ SIGNATURES = {
                         + [_vp, _i64, _vp, _i64] + [_vp] * 4 + [_vp]),
     "gf_factor_scaled": (_int, [_int, _i64, _i64, _int, _int] + [_vp] * 5 + [_vp, _i64]
                          + [_vp] * 5 + [_vp]),
+    "gf_fused_supported": (_int, [_int, _int]),
+    "gf_fused_state_size": (_i64, [_int, _int]),
     "gf_loglike_fused": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int] + [_vp] * 8
                          + [_vp, _i64, _vp, _i64, _vp, _i64] + [_vp] * 5 + [_vp]),
     "gf_chunk_sweep": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int, _int] + [_vp] * 8

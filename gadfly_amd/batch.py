@@ -142,7 +142,7 @@ class BatchedLogLikelihood:
         # small batches of long series are chunked in time as well (exact, see engine.evaluate)
         out = eng.evaluate()[0]
         period = int(eng.generator_period)
-        if period > 1 and eng._fused_ok():
+        if period > 1 and (eng._fused_ok() or eng._wide_ok()):
             torch = eng.torch
             acc = eng._tp["acc"] if getattr(eng, "_tp_used", False) else eng.acc
             amax = eng._pack[2] if eng.diag is None else eng._pack[2] + eng._diag_amax

@@ -1395,6 +1395,406 @@ k_phi7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const in
     }
 }
 
+// ------------------------------------------------------------------------------------
+// k_factorw: the fused sweep (build + factor + forward solve, nothing materialised) for WIDE kernels,
+// 64 <= W <= 176, complex terms only (Jr = 0): cfg4's W = 80, the 86-term solar kernel's W = 172.
+//
+// One workgroup of NW sweep waves + ONE generator wave per (problem, chunk).
+// Sweep waves: the state columns are split over the waves and, inside a wave, tiled as in k_factor7 but
+// four ways: lane = (g, c) = (lane >> 4, lane & 15) of wave w holds the column pair cb = 16 w + c
+// (columns 2cb, 2cb + 1: the cos and sin columns of complex term cb) of the row pairs 8k + 2g,
+// 8k + 2g + 1: a ds_read_b128 delivers a different operand pair to each 16-lane row group of the wave and
+// feeds 8 FMAs.  EVERY wave holds all rows of its 32 columns, so the mat-vec needs no cross-wave
+// reduction: the four row groups of a wave are folded with one v_permlane32_swap pair (reduce-scatter:
+// lower half <- column 2cb, upper half <- column 2cb + 1) and one v_permlane16_swap pair -- 6 vector
+// instructions.  Lane (g, c) then owns column own = 2cb + (lane >> 5) of the row vectors.
+// Generator wave: lane l carries the phasors of complex terms l and l + 64 (k_factor3's RowGen) and
+// writes row n + 1's u~, v~ (and, for a reset row, its span and the column decays) to LDS while the sweep
+// waves work on row n.  A sweep wave therefore holds nothing but its state, the operand ring and a few
+// scalars -- which is what lets W = 176 (T = 176 VGPRs per lane) fit the register file: with the
+// generator inside the sweep waves (as in k_factor7) the state of W > 112 spilled.
+// What crosses waves, through LDS and ONE workgroup barrier per row: the new r (every wave's next sweep
+// needs all of it as row operands), the next row's u~ / v~, and the per-wave partial of u~ . tmp (the
+// pivot) -- double-buffered by row parity.  The forward solve rides in the last padded column
+// (FCOL = 32 NW - 1) exactly as in k_factor3 / k_factor7.
+// Replaces k_build2 + k_factor2w (materialised u~, v~ rows: 2 x 8 ld bytes per row and evaluation
+// through HBM, and a sweep that waited on them) on the log-likelihood path.
+// ------------------------------------------------------------------------------------
+struct FactorWArgs {            // the scalars; the arrays are separate __restrict__ kernel parameters
+    int64_t N, n_first, chunk_len, t_bs, diag_bs, y_bs;
+    int nch, Jc, block_sub;
+    double gap;
+};
+
+struct FactorWPtrs {
+    const double *ac, *bc, *cc, *dc, *diag_add, *cmax, *t, *diag, *y;
+    double *d, *z, *r_out, *Ut_out, *Wt_out, *de_out, *S_state;
+    int32_t *info;
+};
+
+// folds the four 16-lane row groups of a wave: a, b = this lane's partial sums of columns 2cb, 2cb + 1;
+// returns the full sum of the lane's OWN column (lanes 0..31: column 2cb, lanes 32..63: 2cb + 1)
+__device__ __forceinline__ double own_column_sum4(const double a, const double b) {
+    const double h = own_column_sum(a, b);          // lanes l, l ^ 32 folded (reduce-scatter over the halves)
+    const auto l = __builtin_amdgcn_permlane16_swap(__double2loint(h), __double2loint(h), false, false);
+    const auto u = __builtin_amdgcn_permlane16_swap(__double2hiint(h), __double2hiint(h), false, false);
+    return __hiloint2double(u[0], l[0]) + __hiloint2double(u[1], l[1]);         // l, l ^ 16
+}
+
+#ifndef GF_WIDE_AHEAD
+#define GF_WIDE_AHEAD 1
+#endif
+// T[2k + s][e] is row 8k + 2g + s, column 2cb + e.  pu / pw point at this row group's first row pair.
+//   RESET = false:  T += w q^T ;  acc += u^T T         (update + mat-vec)
+//   RESET = true :  T  = (T + w q^T) * (e_row el_col)  (fold pending, decay; pu = the row decays)
+template <int TR, bool RESET>
+__device__ __forceinline__ void sweepw_run(double (&T)[TR][2], const double2 *pu, const double2 *pw,
+                                           const double q0, const double q1, const double el0,
+                                           const double el1, double &o0, double &o1) {
+    constexpr int NK = TR / 2;
+    // operand ring: AH row pairs of LDS look-ahead (one batch = 8 FMAs = ~35 cycles of issue covers
+    // nothing of the LDS latency when the partner wave is not issuing; the state of a wide kernel leaves
+    // room for a deeper ring only while TR is small)
+    constexpr int AH = (GF_WIDE_AHEAD < NK) ? GF_WIDE_AHEAD : NK;
+    double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+    double2 ub[AH + 1], wb[AH + 1];
+#pragma unroll
+    for (int k = 0; k < AH; ++k) { ub[k] = pu[4 * k]; wb[k] = pw[4 * k]; }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        if (k + AH < NK) { ub[(k + AH) % (AH + 1)] = pu[4 * (k + AH)]; wb[(k + AH) % (AH + 1)] = pw[4 * (k + AH)]; }
+        __builtin_amdgcn_sched_barrier(0);
+        const double2 u = ub[k % (AH + 1)], w = wb[k % (AH + 1)];
+        if constexpr (RESET) {
+            T[2 * k][0] = fma(w.x, q0, T[2 * k][0]) * (u.x * el0);
+            T[2 * k][1] = fma(w.x, q1, T[2 * k][1]) * (u.x * el1);
+            T[2 * k + 1][0] = fma(w.y, q0, T[2 * k + 1][0]) * (u.y * el0);
+            T[2 * k + 1][1] = fma(w.y, q1, T[2 * k + 1][1]) * (u.y * el1);
+        } else {
+            T[2 * k][0] = fma(w.x, q0, T[2 * k][0]);
+            T[2 * k][1] = fma(w.x, q1, T[2 * k][1]);
+            T[2 * k + 1][0] = fma(w.y, q0, T[2 * k + 1][0]);
+            T[2 * k + 1][1] = fma(w.y, q1, T[2 * k + 1][1]);
+            a00 = fma(u.x, T[2 * k][0], a00);
+            a01 = fma(u.x, T[2 * k][1], a01);
+            a10 = fma(u.y, T[2 * k + 1][0], a10);
+            a11 = fma(u.y, T[2 * k + 1][1], a11);
+            asm volatile("" : "+v"(a00), "+v"(a01), "+v"(a10), "+v"(a11));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    o0 = a00 + a10;
+    o1 = a01 + a11;
+}
+
+// LDS of one k_factorw workgroup.  The generator runs TWO rows ahead of the sweep (three buffers for
+// what it writes), so that everything a sweep wave needs of row n + 1 except the new r is readable before
+// row n's barrier; r and the pivot partials alternate between two buffers.
+template <int NW>
+struct WideShared {
+    static constexpr int CP = 32 * NW;
+    double w[2][CP];            // r_{n-1}: pending rank-1 update (row form)
+    double u[3][CP];            // u~_n
+    double v[3][CP];            // v~_n
+    double e[3][CP];            // column decays of a reset row
+    double f[3][4];             // per row: reset span de (>= 0, or -1 for a plain row), diagonal a_n, y_n
+    double p[2][NW][2];         // per-wave partials: u~^T T u~ share, u~ . F~
+};
+
+// the update + mat-vec sweep with the w operands (the new r: the only operands behind the row's barrier)
+// already in registers -- fetched right after the barrier, in the shadow of the pivot -- and the u~
+// operands (readable long before) through a two-deep LDS ring: the FMAs never wait on the critical path
+template <int TR>
+__device__ __forceinline__ void sweepw_regs(double (&T)[TR][2], const double2 *pu,
+                                            const double2 (&wb)[TR / 2], const double q0, const double q1,
+                                            double &o0, double &o1) {
+    constexpr int NK = TR / 2, AH = (NK > 2) ? 2 : NK;
+    double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+    double2 ub[AH + 1];
+#pragma unroll
+    for (int k = 0; k < AH; ++k) ub[k] = pu[4 * k];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        if (k + AH < NK) ub[(k + AH) % (AH + 1)] = pu[4 * (k + AH)];
+        __builtin_amdgcn_sched_barrier(0);
+        const double2 u = ub[k % (AH + 1)], w = wb[k];
+        T[2 * k][0] = fma(w.x, q0, T[2 * k][0]);
+        T[2 * k][1] = fma(w.x, q1, T[2 * k][1]);
+        T[2 * k + 1][0] = fma(w.y, q0, T[2 * k + 1][0]);
+        T[2 * k + 1][1] = fma(w.y, q1, T[2 * k + 1][1]);
+        a00 = fma(u.x, T[2 * k][0], a00);
+        a01 = fma(u.x, T[2 * k][1], a01);
+        a10 = fma(u.y, T[2 * k + 1][0], a10);
+        a11 = fma(u.y, T[2 * k + 1][1], a11);
+        asm volatile("" : "+v"(a00), "+v"(a01), "+v"(a10), "+v"(a11));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    o0 = a00 + a10;
+    o1 = a01 + a11;
+}
+
+// rows between looks at the failure flag (a non-positive pivot is recorded without a branch; the rows
+// swept after it, at most this many, are thrown away)
+constexpr int WIDE_FAIL_CHECK = 64;
+
+// (The arrays are passed as separate __restrict__ parameters, not inside FactorWArgs: only then can
+// hipcc prove the wave-uniform t loads unclobbered and issue them as scalar loads.)
+template <int TR, int NW>
+__global__ void __launch_bounds__(64 * (NW + 1), 2)
+k_factorw(const FactorWArgs A,
+          const double *__restrict__ ac_, const double *__restrict__ bc_,
+          const double *__restrict__ cc_, const double *__restrict__ dc_,
+          const double *__restrict__ diag_add_, const double *__restrict__ cmax_,
+          const double *__restrict__ t_, const double *__restrict__ diag_,
+          const double *__restrict__ y_,
+          double *__restrict__ d_, double *__restrict__ z_, double *__restrict__ r_out,
+          double *__restrict__ Ut_out, double *__restrict__ Wt_out, double *__restrict__ de_out,
+          double *__restrict__ S_state, int32_t *__restrict__ info) {
+    static_assert(TR % 2 == 0, "rows per lane come in pairs");
+    constexpr int RP = 4 * TR;                      // rows, padded (rows >= W: u~ = r = 0, T stays 0)
+    constexpr int CP = 32 * NW;                     // columns, padded; the last one carries the forward solve
+    static_assert(RP <= CP, "row operands are read from the column-indexed LDS vectors");
+    constexpr int FCOL = CP - 1;                    // forward-solve column: last sweep wave, lanes 47 and 63
+    constexpr int NK = TR / 2;
+    constexpr bool PRE = TR <= 20;                  // the w operands of a whole row fit in registers (W <= 80)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x;                       // state slot = problem * nch + chunk
+    if (info[b] != 0) return;                       // (uniform over the workgroup)
+    const int pr = b / A.nch, ch = b - pr * A.nch;
+    const int64_t c0 = (int64_t)ch * A.chunk_len;
+    const int64_t rows = (A.N - c0 < A.chunk_len) ? (A.N - c0) : A.chunk_len;
+    const int64_t g0 = A.n_first + c0;
+    const size_t pb = (size_t)pr * A.N + c0;
+    const double *__restrict__ tg = t_ + (size_t)pr * A.t_bs + g0;
+
+    __shared__ __attribute__((aligned(16))) WideShared<NW> sh;
+
+    if (wave == NW) {
+        // ------- generator wave: rows u~, v~, reset spans and decays two rows ahead; the pivots -------
+        const double *__restrict__ yg = y_ + (size_t)pr * A.y_bs + g0;
+        const bool has_g = diag_ != nullptr;
+        const double *__restrict__ gg = has_g ? diag_ + (size_t)pr * A.diag_bs + g0 : yg;
+        const double diag_add = diag_add_[pr];
+        double *__restrict__ dg = d_ + pb;
+        double *__restrict__ zg = z_ + pb;
+        constexpr int NP = (CP / 2 + 63) / 64;      // phasors per lane (1 up to W + 1 <= 128 columns, else 2)
+        RowGen gen[NP];
+        bool live[NP];
+#pragma unroll
+        for (int h = 0; h < NP; ++h) {
+            const int ph = lane + 64 * h;           // complex term (column pair) of this slot
+            live[h] = ph < CP / 2;
+            gen[h].init(2 * ph, pr, 0, A.Jc, A.block_sub, A.gap, nullptr, nullptr, ac_, bc_, cc_, dc_,
+                        cmax_, tg, g0);
+        }
+        double *__restrict__ ug = Ut_out ? Ut_out + pb * CP : nullptr;
+        double *__restrict__ eg = de_out ? de_out + pb : nullptr;
+        auto emit = [&](const double tn, const int64_t gi, const int buf, double *urow, const double an,
+                        const double yn) {
+            bool rst = false;
+            double de = -1.0;
+#pragma unroll
+            for (int h = 0; h < NP; ++h) {
+                gen[h].advance(tn, gi, rst, de);            // rst, de: the same for every phasor
+                const double uc = fma(gen[h].k1, gen[h].cu, gen[h].k2 * gen[h].su);        // a cos + b sin
+                const double us = fma(gen[h].k1, gen[h].su, -gen[h].k2 * gen[h].cu);       // a sin - b cos
+                const double vc = gen[h].sel_c * gen[h].cu * gen[h].irho2;                 // pad pairs: 0
+                const double vs = gen[h].sel_c * gen[h].su * gen[h].irho2;
+                if (live[h]) {
+                    const int j = 2 * (lane + 64 * h);
+                    *reinterpret_cast<double2 *>(&sh.u[buf][j]) = double2{uc, us};
+                    *reinterpret_cast<double2 *>(&sh.v[buf][j]) = double2{vc, vs};
+                    if (rst) {
+                        const double el = fm_exp(-gen[h].cj * de);      // pad pairs: cj = 0 -> 1
+                        *reinterpret_cast<double2 *>(&sh.e[buf][j]) = double2{el, el};
+                    }
+                    if (urow) *reinterpret_cast<double2 *>(urow + j) = double2{uc, us};
+                }
+            }
+            const double span = rst ? de : -1.0;
+            // the row's scalars for the sweep waves (every lane writes the same values: no branch)
+            *reinterpret_cast<double2 *>(&sh.f[buf][0]) = double2{span, an};
+            sh.f[buf][2] = yn;
+            return span;
+        };
+        // y, diag in the vector-load queue (opaque zero lane offset), three rows ahead: as scalar loads
+        // they share the LDS counter, and every LDS wait of the row would wait for them as well
+        const int vz = __builtin_amdgcn_mbcnt_lo(0u, 0u);
+        auto diag_of = [&](const double gv) { return (has_g ? gv : 0.0) + diag_add; };
+        // (t, y, diag) of rows n + 2 and n + 3; rows n, n + 1 keep (a, y) for the pivots
+        double t_2 = tg[2 + vz], t_3 = tg[3 + vz], y_2 = yg[2 + vz], y_3 = yg[3 + vz];
+        double g_2 = gg[2 + vz], g_3 = gg[3 + vz];
+        double a_0 = diag_of(gg[vz]), a_1 = diag_of(gg[1 + vz]), y_0 = yg[vz], y_1 = yg[1 + vz];
+        double de_0 = emit(tg[vz], g0, 0, ug, a_0, y_0);
+        double de_1 = emit(tg[1 + vz], g0 + 1, 1, (ug && rows > 1) ? ug + CP : nullptr, a_1, y_1);
+        wg_lds_barrier();
+        int b2 = 2;                                 // buffer of row n + 2
+        int32_t fail = 0;
+        double dacc = 0.0, zacc = 0.0;
+        for (int64_t n = 0; n < rows; ++n) {
+            const int nxt = (int)(n & 1) ^ 1;
+            const double a_n = a_0, yy = y_0;
+            if (eg && lane == 0) eg[n] = de_0;
+            const double a_2 = diag_of(g_2);
+            de_0 = de_1;
+            de_1 = emit(t_2, g0 + n + 2, b2, (ug && n + 2 < rows) ? ug + (size_t)(n + 2) * CP : nullptr, a_2, y_2);
+            b2 = (b2 == 2) ? 0 : b2 + 1;
+            a_0 = a_1; y_0 = y_1; a_1 = a_2; y_1 = y_2;
+            t_2 = t_3; y_2 = y_3; g_2 = g_3;
+            t_3 = tg[n + 4 + vz];
+            y_3 = yg[n + 4 + vz];
+            g_3 = gg[n + 4 + vz];
+            wg_lds_barrier();
+            double s1 = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) s1 += sh.p[nxt][w2][0];
+            const double dn = a_n - s1;
+            const double zn = yy - sh.p[nxt][NW - 1][1];
+            // d, z leave in coalesced blocks of 64 rows (lane j keeps row 64 m + j): a store per row would
+            // sit in the same in-order queue as the y / diag prefetches and make their waits wait for HBM
+            // write acknowledgements
+            dacc = (lane == (int)(n & 63)) ? dn : dacc;
+            zacc = (lane == (int)(n & 63)) ? zn : zacc;
+            if ((n & 63) == 63) { dg[n - 63 + lane] = dacc; zg[n - 63 + lane] = zacc; }
+            if (!(dn > 0.0) && fail == 0) {
+                const int64_t gf = g0 + n + 1;
+                fail = (int32_t)(gf > 0x7fffffff ? 0x7fffffff : gf);
+            }
+            if ((n & (WIDE_FAIL_CHECK - 1)) == WIDE_FAIL_CHECK - 1 && fail) break;
+        }
+        if (fail) {
+            if (lane == 0) info[b] = fail;
+        } else if (rows & 63) {                     // the last, partial block of d, z
+            const int64_t base = rows - (rows & 63);
+            if (lane < (int)(rows & 63)) { dg[base + lane] = dacc; zg[base + lane] = zacc; }
+        }
+        return;
+    }
+
+    // ---------------- sweep waves ------------------------------------------------------------------
+    const int g = lane >> 4, c = lane & 15;
+    const int cb = wave * 16 + c;                   // column pair (complex term) of this lane
+    const int own = 2 * cb + (lane >> 5);           // the column whose row-vector entries this lane carries
+    double *__restrict__ rg = r_out ? r_out + pb * CP + own : nullptr;
+    double *__restrict__ wg = Wt_out ? Wt_out + pb * CP + own : nullptr;
+    double *__restrict__ Sg = S_state + (size_t)b * ((size_t)CP * RP);      // [column][row]
+    const double notF = (own == FCOL) ? 0.0 : 1.0;
+    const double isF1 = (2 * cb + 1 == FCOL) ? 1.0 : 0.0;   // this lane's second state column is F~
+    double *__restrict__ col0 = Sg + (size_t)(2 * cb) * RP + 2 * g;
+    double *__restrict__ col1 = col0 + RP;
+    double T[TR][2];
+#pragma unroll
+    for (int m = 0; m < TR; ++m) {
+        T[m][0] = col0[8 * (m >> 1) + (m & 1)];
+        T[m][1] = col1[8 * (m >> 1) + (m & 1)];
+    }
+    double q0 = 0.0, q1 = 0.0;
+    sh.w[0][own] = 0.0;
+    wg_lds_barrier();
+    // row 0's operands, own-column entries and reset span
+    double2 wb[PRE ? NK : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) wb[k] = double2{0.0, 0.0};
+    }
+    double vt_c = sh.v[0][own];
+    double2 u01 = *reinterpret_cast<const double2 *>(&sh.u[0][2 * cb]);     // u~ of the two state columns
+    double2 fa = *reinterpret_cast<const double2 *>(&sh.f[0][0]);           // (reset span, a_n)
+    double yy = sh.f[0][2];
+    double de = read_lane(fa.x, 0);
+    int b0 = 0, b1 = 1;                             // buffers of rows n and n + 1
+    int32_t fail = 0;
+
+    // Two loops: the outer one runs once per scaling block (its first row is a reset row: fold the pending
+    // update, decay), the inner one over the block's rows has NO conditional update of T -- with the reset
+    // inside the row loop the register allocator kept T in two register sets and copied all of it twice
+    // per row (84 v_mov_b64 next to 80 FMAs).
+    int64_t n = 0;
+    bool stop = false;
+    while (n < rows && !stop) {
+    if (de >= 0.0) {                        // workgroup-uniform reset row
+        const double2 *pw = (const double2 *)sh.w[n & 1] + g;
+        double d0, d1, el0, el1;
+        both_halves(sh.e[b0][own], el0, el1);               // decays of this lane's two state columns
+        if constexpr (PRE) {                                // (the pending multipliers are in registers)
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const double2 e = ((const double2 *)sh.e[b0] + g)[4 * k], w = wb[k];
+                T[2 * k][0] = fma(w.x, q0, T[2 * k][0]) * (e.x * el0);
+                T[2 * k][1] = fma(w.x, q1, T[2 * k][1]) * (e.x * el1);
+                T[2 * k + 1][0] = fma(w.y, q0, T[2 * k + 1][0]) * (e.y * el0);
+                T[2 * k + 1][1] = fma(w.y, q1, T[2 * k + 1][1]) * (e.y * el1);
+            }
+            (void)pw; (void)d0; (void)d1;
+        } else {
+            sweepw_run<TR, true>(T, (const double2 *)sh.e[b0] + g, pw, q0, q1, el0, el1, d0, d1);
+        }
+        q0 = 0.0;
+        q1 = 0.0;
+    }
+    do {
+        const int cur = (int)(n & 1), nxt = cur ^ 1;
+        const double2 *pw = (const double2 *)sh.w[cur] + g, *pu = (const double2 *)sh.u[b0] + g;
+        __builtin_amdgcn_s_setprio(0);
+        double acc0, acc1;
+        if constexpr (PRE) sweepw_regs<TR>(T, pu, wb, q0, q1, acc0, acc1);
+        else sweepw_run<TR, false>(T, pu, pw, q0, q1, 0.0, 0.0, acc0, acc1);
+        // the serial part of the row wins the issue arbitration against the other workgroup's sweep
+        __builtin_amdgcn_s_setprio(GF_CHAIN_PRIO);
+        // what the generator wrote of row n + 1 (two rows ahead) is fetched here, in the shadow of the
+        // reductions: this lane's own-column entries, the reset span, the diagonal and y
+        const double vt_n = sh.v[b1][own];
+        const double2 u01_n = *reinterpret_cast<const double2 *>(&sh.u[b1][2 * cb]);
+        const double2 fa_n = *reinterpret_cast<const double2 *>(&sh.f[b1][0]);
+        const double yy_n = sh.f[b1][2];
+        // this lane's share of the quadratic form u~^T T u~ (its rows x its two columns): the pivot's
+        // reduction runs next to -- not after -- the column sums
+        const double p1 = wave_sum(fma(acc0, u01.x, acc1 * u01.y));
+        const double tmp = own_column_sum4(acc0, acc1);
+        const double r = (vt_c - tmp) * notF;
+        double r0, r1;
+        both_halves(r, r0, r1);                     // r of this lane's two state columns
+        sh.w[nxt][own] = r;
+        const double p2 = read_lane(tmp, 47);       // column FCOL of the last sweep wave: u~ . F~
+        *reinterpret_cast<double2 *>(sh.p[nxt][wave]) = double2{p1, p2};    // (uniform, every lane: no branch)
+        wg_lds_barrier();
+        double s1 = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) s1 += sh.p[nxt][w2][0];
+        const double s2 = sh.p[nxt][NW - 1][1];
+        if constexpr (PRE) {                        // next row's w operands: the only reads behind the barrier
+#pragma unroll
+            for (int k = 0; k < NK; ++k) wb[k] = ((const double2 *)sh.w[nxt] + g)[4 * k];
+        }
+        const double dn = fa.y - s1;                // every wave forms the pivot itself
+        const double zn = yy - s2;
+        vt_c = vt_n; u01 = u01_n; fa = fa_n; yy = yy_n;
+        de = read_lane(fa.x, 0);
+        b0 = b1; b1 = (b1 == 2) ? 0 : b1 + 1;
+        if (!(dn > 0.0)) fail = 1;                  // (the generator wave records the row)
+        const double inv = fast_rcp(dn);
+        q0 = r0 * inv;                              // multipliers of this lane's two state columns;
+        q1 = fma(zn, isF1, r1) * inv;               // column FCOL: z / d (r is 0 there)
+        const size_t ro = opaque_uniform((size_t)n * CP);
+        if (rg) rg[ro] = r;                         // r~ rows (chunk mode)
+        if (wg) wg[ro] = r * inv;
+        stop = (n & (WIDE_FAIL_CHECK - 1)) == WIDE_FAIL_CHECK - 1 && fail;
+        ++n;
+    } while (n < rows && !(de >= 0.0) && !stop);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (fail) return;                               // (the generator wave records the row)
+    const int fin = (int)(rows & 1);                // buffer written by the last row
+#pragma unroll
+    for (int m = 0; m < TR; ++m) {
+        const int ro = 8 * (m >> 1) + (m & 1);
+        const double w = sh.w[fin][2 * g + ro];
+        col0[ro] = fma(w, q0, T[m][0]);
+        col1[ro] = fma(w, q1, T[m][1]);
+    }
+}
+
 // helpers shared with the archived variants
 #define GF_MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -3367,6 +3767,35 @@ int dispatch_factor2w(const Factor2wArgs &A, int B, hipStream_t st) {      // sa
     return launch_factor2w<32, 4, 8>(A, B, st);
 }
 
+// wide fused sweep: NW = sweep waves for W + 1 columns (32 per wave, one spare column for the forward
+// solve), TR = rows per lane = W / 4 rounded up to a multiple of 4; one more wave generates the rows
+struct WideShape { int nw, tr; };
+inline WideShape wide_shape(int W) {
+    WideShape s;
+    s.nw = (W + 1 + 31) / 32;
+    s.tr = (W + 15) / 16 * 4;
+    return s;
+}
+
+template <int TR, int NW>
+int launch_factorw(const FactorWArgs &A, const FactorWPtrs &P, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((k_factorw<TR, NW>), dim3(grid), dim3(64 * (NW + 1)), 0, st, A, P.ac, P.bc, P.cc, P.dc,
+                       P.diag_add, P.cmax, P.t, P.diag, P.y, P.d, P.z, P.r_out, P.Ut_out, P.Wt_out, P.de_out,
+                       P.S_state, P.info);
+    return 0;
+}
+
+int dispatch_factorw(const FactorWArgs &A, const FactorWPtrs &P, int W, int grid, hipStream_t st) {
+    const WideShape s = wide_shape(W);
+#define GF_FW(TRv, NWv) if (s.tr == TRv && s.nw == NWv) return launch_factorw<TRv, NWv>(A, P, grid, st);
+    GF_FW(16, 3) GF_FW(20, 3) GF_FW(24, 3)
+    GF_FW(24, 4) GF_FW(28, 4) GF_FW(32, 4)
+    GF_FW(32, 5) GF_FW(36, 5) GF_FW(40, 5)
+    GF_FW(40, 6) GF_FW(44, 6)
+#undef GF_FW
+    return -1;
+}
+
 }  // namespace
 
 // ======================================================================================
@@ -3506,6 +3935,23 @@ int gf_factor_scaled(int B, int64_t N, int64_t n_first, int W, int ld, const dou
     return check_launch("gf_factor_scaled");
 }
 
+// Fused sweeps exist for W <= 63 (any mix of terms) and, for kernels of complex terms only, up to
+// W = 176 (k_factorw).  gf_fused_state_size: doubles of S_state per (problem, chunk) slot.
+int gf_fused_supported(int Jr, int Jc) {
+    const int W = Jr + 2 * Jc;
+    if (Jr < 0 || Jc < 0 || W < 1) return 0;
+    if (W <= 63) return 1;
+    return (Jr == 0 && W <= 176) ? 1 : 0;
+}
+
+int64_t gf_fused_state_size(int Jr, int Jc) {
+    if (!gf_fused_supported(Jr, Jc)) return -1;
+    const int W = Jr + 2 * Jc;
+    if (W <= 63) return 64 * 64;
+    const WideShape ws = wide_shape(W);
+    return (int64_t)(32 * ws.nw) * (4 * ws.tr);                                // [columns][rows], padded
+}
+
 // which fused sweep runs (argument `variant` of gf_loglike_fused / gf_chunk_sweep / gf_chunk_transition)
 //   GF_SWEEP_AUTO   the lane-tiled k_factor7 / k_phi7 for kernels of complex terms only (Jr = 0,
 //                   Jc <= 31: every gadfly kernel with Q >= 1/2), k_factor3 / k_phi otherwise
@@ -3542,18 +3988,32 @@ static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int6
     if (B < 1 || N < 1) return set_err("%s: empty problem (N=%lld)", who, N);
     if ((Ut_out != nullptr) != (Wt_out != nullptr) || (Ut_out != nullptr) != (de_out != nullptr))
         return set_err("%s: Ut_out, Wt_out, de_out go together%s", who);
-    if (W < 1 || W > 63) return set_err("%s: width %lld unsupported (1..63)", who, W);
+    if (!gf_fused_supported(Jr, Jc))
+        return set_err("%s: width %lld unsupported (1..63 any terms; 64..176 complex terms only)", who, W);
     if (block < 1 || block > 64 || (block & (block - 1))) return set_err("%s: block=%lld must be a power of two in 1..64", who, block);
     if (n_first < 0 || (n_first % block) != 0) return set_err("%s: n_first=%lld must be a non-negative multiple of block=%lld", who, n_first, block);
     if (nch < 1 || chunk_len < 1 || (nch > 1 && (chunk_len % block) != 0) || (int64_t)nch * chunk_len < N
         || (int64_t)(nch - 1) * chunk_len >= N)
         return set_err("%s: bad chunking (chunk_len=%lld, nch=%lld)", who, chunk_len, nch);
-    if (!t || !y || !d || !z || !S_state || !F_state || !info || !diag_add || !cmax)
+    if (!t || !y || !d || !z || !S_state || (!F_state && W <= 63) || !info || !diag_add || !cmax)
         return set_err("%s: null pointer%s", who);
-    if (check_sweep_options(who, gen_period, variant, Jr, Jc)) return -1;
+    if (check_sweep_options(who, gen_period, W > 63 ? GF_SWEEP_AUTO : variant, Jr, Jc)) return -1;
     const bool tiled = sweep_tiled(variant, Jr, Jc);
     const double gap = (block > 1) ? SC_SPAN / (double)(block - 1) : 0.0;
     hipStream_t st = (hipStream_t)stream;
+    if (W > 63) {                       // wide kernels: one workgroup per (problem, chunk), k_factorw
+        FactorWArgs A;
+        A.N = N; A.n_first = n_first; A.chunk_len = chunk_len; A.nch = nch; A.Jc = Jc;
+        A.block_sub = block | (gen_period << 8); A.gap = gap;
+        A.t_bs = t_bs; A.diag_bs = diag_bs; A.y_bs = y_bs;
+        FactorWPtrs P;
+        P.ac = ac; P.bc = bc; P.cc = cc; P.dc = dc; P.diag_add = diag_add; P.cmax = cmax;
+        P.t = t; P.diag = diag; P.y = y;
+        P.d = d; P.z = z; P.r_out = r_out; P.Ut_out = Ut_out; P.Wt_out = Wt_out; P.de_out = de_out;
+        P.S_state = S_state; P.info = info;
+        if (dispatch_factorw(A, P, W, B * nch, st)) return set_err("%s: internal dispatch error (wide)", who);
+        return check_launch(who);
+    }
     const int rows = (W + 3) / 4 * 4;
     switch (rows) {
         GF_F3_CASE(4) GF_F3_CASE(8) GF_F3_CASE(12) GF_F3_CASE(16) GF_F3_CASE(20) GF_F3_CASE(24)

@@ -465,6 +465,9 @@ class StreamingBatch:
         self.scaled_wide = bool(self.lib.gf_scaled_wide_supported(self.W)) and not force_v1
         # W <= 63 and phases inside the fused kernel's sincos range: nothing is materialised
         self.allow_fused = bool(allow_fused) and self.scaled and self.W <= 63
+        # 64 <= W <= 192, complex terms only: the fused sweep on one workgroup per problem (k_factorw)
+        self.allow_wide = (bool(allow_fused) and not force_v1 and self.W > 63
+                           and bool(self.lib.gf_fused_supported(self.Jr, self.Jc)))
         # which fused sweep runs (GF_SWEEP_AUTO: lane-tiled where the term structure allows it);
         # a call argument of the C-ABI, so engines with different settings coexist in one process
         self.sweep_variant = _lib.GF_SWEEP_AUTO
@@ -492,6 +495,8 @@ class StreamingBatch:
         self.d = torch.empty((B, T), **f64)
         self.z = torch.empty((B, T), **f64)
         nS = 64 * 64 if self.scaled else int(self.lib.gf_state_size(self.W))
+        if self.allow_wide:
+            nS = max(nS, int(self.lib.gf_fused_state_size(self.Jr, self.Jc)))
         nF = 64 if self.scaled else int(self.lib.gf_state_cols(self.W))
         self.S_state = torch.empty((B, nS), **f64)
         self.F_state = torch.empty((B, nF), **f64)
@@ -521,6 +526,10 @@ class StreamingBatch:
     def _fused_ok(self):
         """Phases d*t must stay inside fm_sincos's Cody-Waite range (|x| < 1.6e6)."""
         return self.allow_fused and self._pack[6] * self._tmax < 1.6e6
+
+    def _wide_ok(self):
+        """The fused sweep for wide kernels (same phase range; log-likelihood streaming only)."""
+        return self.allow_wide and self._pack[6] * self._tmax < 1.6e6
 
     # error of the log-likelihood ~ GEN_ERR * period * condition (measured: 1e-8 at period 16 and a
     # condition of 4e5, DESIGN.md 2.1a)
@@ -604,7 +613,7 @@ class StreamingBatch:
         self.S_state.zero_()
         self.F_state.zero_()
         self.info.zero_()
-        if self._fused_ok():
+        if self._fused_ok() or self._wide_ok():
             return self._log_likelihood_fused(main)
         if self.bufs is None:
             self._alloc_bufs()
@@ -665,7 +674,7 @@ class StreamingBatch:
         T, N, B = self.tile_rows, self.N, self.B
         real, comp, diag_add, _, cmax, block, _ = self._pack
         period, variant = int(self.generator_period), int(self.sweep_variant)
-        self.kernel_used = "fused"
+        self.kernel_used = "fused-wide" if self.W > 63 else "fused"
         for k in range((N + T - 1) // T):
             n0 = k * T
             rows = min(T, N - n0)

@@ -152,7 +152,15 @@ int gf_factor_scaled(int B, int64_t N, int64_t n_first, int W, int ld, const dou
  * 1e-8 / 10.0 ms, i.e. error ~ 1.6e-15 * gen_period * condition.  Callers pick it from the condition
  * estimate max(a) / min(d) that gf_reduce_tile returns (1 when in doubt).  Irregular spacings are
  * always generated exactly.  variant: GF_SWEEP_AUTO (see the GF_SWEEP_* constants).
+ *
+ * Wide kernels: for kernels made of complex terms only (Jr = 0: every SHO term with Q >= 1/2) the
+ * same entry points take 64 <= W <= 176 (k_factorw: one workgroup of ceil((W + 1) / 32) + 1 waves per
+ * problem; `variant` is ignored).  gf_fused_supported tells; S_state then holds
+ * gf_fused_state_size(Jr, Jc) doubles per (problem, chunk) slot instead of 64 * 64 (zeroed by the
+ * caller before the first tile; opaque layout) and F_state is not used (may be NULL).
  */
+int gf_fused_supported(int Jr, int Jc);
+int64_t gf_fused_state_size(int Jr, int Jc);
 int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int block,
                      int gen_period, int variant,
                      const double *ar, const double *cr, const double *ac,

@@ -48,9 +48,14 @@ def test_bad_arguments_are_status_codes_not_crashes():
     st = lib.gf_build_scaled(1, 16, 3, 0, 2, 16, *([None] * 8), 8, None, 0, None, 0,
                              *([None] * 4), None)
     assert st < 0 and b"n_first" in lib.gf_last_error()
-    st = lib.gf_loglike_fused(1, 16, 0, 0, 32, 8, 1, 0, *([None] * 8), None, 0, None, 0, None, 0,
+    st = lib.gf_loglike_fused(1, 16, 0, 1, 32, 8, 1, 0, *([None] * 8), None, 0, None, 0, None, 0,
                               *([None] * 5), None)
-    assert st < 0 and b"width" in lib.gf_last_error()
+    assert st < 0 and b"width" in lib.gf_last_error()        # W = 65 with a real term: no fused sweep
+    assert lib.gf_fused_supported(0, 30) == 1 and lib.gf_fused_supported(0, 40) == 1
+    assert lib.gf_fused_supported(0, 88) == 1 and lib.gf_fused_supported(0, 89) == 0
+    assert lib.gf_fused_supported(2, 31) == 0 and lib.gf_fused_supported(3, 30) == 1
+    assert lib.gf_fused_state_size(0, 30) == 64 * 64
+    assert lib.gf_fused_state_size(0, 40) == 96 * 80 and lib.gf_fused_state_size(0, 86) == 192 * 176
     # the product ABI has no process-wide switches and ships no experimental sweeps
     for gone in ("gf_set_generator_period", "gf_set_pipelined", "gf_loglike_blocked"):
         assert not hasattr(lib, gone)

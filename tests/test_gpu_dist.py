@@ -64,3 +64,20 @@ print("RCCL_OK")
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "RCCL_OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
+def test_bench_self_launch_two_ranks(hip):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment starts its two rank processes
+    itself (the parent never touches the GPU).  Both ranks share the box's one GPU here, so the
+    process group is gloo; the launch, rendezvous, barrier and MAX-reduce are the real code path."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(GADFLY_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--rows", "16384", "--evals", "64", "--no-cpu-baseline", "--no-configs"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["value"] > 0 and res["scaling"] == "weak"

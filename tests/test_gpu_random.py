@@ -148,7 +148,8 @@ def test_generator_calibration(hip):
 
 def test_accuracy_guard_reruns_an_ill_conditioned_walker(hip):
     """The generator period is calibrated on well-conditioned walkers (period 64); then ONE walker of
-    a later proposal is badly conditioned (amplitudes x 3e4: condition ~1e6).  The device-side guard
+    a later proposal is badly conditioned (amplitudes x 1e6, frequencies x 0.03: a process so smooth
+    at this cadence that its condition estimate max(a) / min(d) is 3e5).  The device-side guard
     must flag exactly that evaluation and repeat it with exact rows, so that every entry still
     matches the oracle at 1e-8 -- accuracy does not depend on the sampler standing still."""
     import gadfly_amd
@@ -166,9 +167,9 @@ def test_accuracy_guard_reruns_an_ill_conditioned_walker(hip):
     ev.engine.force_streaming = True
     ev.evaluate()
     assert ev.engine.generator_period == 64 and ev.guard_reruns == 0
-    # next proposal: walker 3 jumps to a region with huge amplitudes
-    hot = Hyperparameters([dict(hyperparameters=dict(S0=p["hyperparameters"]["S0"] * 3e4,
-                                                     w0=p["hyperparameters"]["w0"],
+    # next proposal: walker 3 jumps to a region with huge amplitudes and slow oscillations
+    hot = Hyperparameters([dict(hyperparameters=dict(S0=p["hyperparameters"]["S0"] * 1e6,
+                                                     w0=p["hyperparameters"]["w0"] * 0.03,
                                                      Q=p["hyperparameters"]["Q"]),
                                 metadata=dict(p["metadata"])) for p in base], name="hot")
     kernels2 = list(kernels)

@@ -157,7 +157,13 @@ def measure_cfg2_api():
 
 def main():
     import json
-    for fn in (measure_cfg2_api, measure_cfg3, measure_cfg4, measure_cfg5):
+    which = [a for a in sys.argv[1:] if not a.startswith("--so=")]
+    for a in sys.argv[1:]:
+        if a.startswith("--so="):               # A/B builds of the library (development)
+            from gadfly_amd import _lib
+            _lib.SO_PATH = os.path.abspath(a[5:])
+    fns = dict(cfg2=measure_cfg2_api, cfg3=measure_cfg3, cfg4=measure_cfg4, cfg5=measure_cfg5)
+    for fn in ([fns[w] for w in which] if which else fns.values()):
         r = fn()
         r.pop("_sample", None)
         print(json.dumps(r))
