@@ -52,6 +52,8 @@ SIGNATURES = {
                          + [_vp, _i64, _vp, _i64, _vp, _i64] + [_vp] * 5 + [_vp]),
     "gf_chunk_sweep": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int, _int] + [_vp] * 8
                        + [_vp, _i64, _vp, _i64, _vp, _i64] + [_vp] * 9 + [_vp]),
+    "gf_fused_row_stride": (_int, [_int, _int]),
+    "gf_scaled_propagator": (_int, [_int, _i64, _int, _int, _vp, _vp, _vp, _vp]),
     "gf_chunk_linear": (_int, [_int, _int, _i64, _i64, _int, _int, _int, _int, _int]
                         + [_vp] * 8 + [_vp]),
     "gf_chunk_linear_combine": (_int, [_int, _int, _i64, _i64, _int, _int, _int] + [_vp] * 5

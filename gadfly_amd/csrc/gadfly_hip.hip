@@ -3767,6 +3767,22 @@ int dispatch_factor2w(const Factor2wArgs &A, int B, hipStream_t st) {      // sa
     return launch_factor2w<32, 4, 8>(A, B, st);
 }
 
+// Propagator rows of a factor stored in block-scaled form (rows u~, w~ = r/d and the reset spans de of
+// gf_chunk_sweep): in scaled coordinates the row-to-row propagator is 1, and exp(-c de) at a reset row.
+// With these rows the general-width sweeps (gf_solve) run on the scaled factor unchanged.
+__global__ void __launch_bounds__(256)
+k_scaled_propagator(const int64_t N, const int W, const int ld, const double *__restrict__ c_,
+                    const double *__restrict__ de_, double *__restrict__ P_out) {
+    const int b = blockIdx.y;
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = id / ld;
+    if (n >= N) return;
+    const int j = (int)(id - n * ld);
+    const double de = de_[(size_t)b * N + n];
+    const double cj = (j < W) ? c_[(size_t)b * W + j] : 0.0;
+    P_out[((size_t)b * N + n) * ld + j] = (de > 0.0) ? exp(-cj * de) : 1.0;
+}
+
 // wide fused sweep: NW = sweep waves for W + 1 columns (32 per wave, one spare column for the forward
 // solve), TR = rows per lane = W / 4 rounded up to a multiple of 4; one more wave generates the rows
 struct WideShape { int nw, tr; };
@@ -4153,6 +4169,26 @@ int gf_chunk_combine_tree(int B, int P, double *Phi, double *G, double *m, doubl
         hipLaunchKernelGGL(k_tree_apply, dim3(B * (P / (2 * d))), dim3(256), lds, st, A);
     }
     return check_launch("gf_chunk_combine_tree");
+}
+
+// leading dimension of the rows gf_chunk_sweep stores (Ut_out, Wt_out, r_out): 64 for W <= 63, the padded
+// column count of the wide sweep beyond
+int gf_fused_row_stride(int Jr, int Jc) {
+    if (!gf_fused_supported(Jr, Jc)) return -1;
+    const int W = Jr + 2 * Jc;
+    return (W <= 63) ? 64 : 32 * wide_shape(W).nw;
+}
+
+int gf_scaled_propagator(int B, int64_t N, int W, int ld, const double *c, const double *de,
+                         double *P_out, void *stream) {
+    if (B < 1 || N < 1) return set_err("gf_scaled_propagator: empty problem (N=%s%lld)", "", N);
+    if (W < 1 || ld < W) return set_err("gf_scaled_propagator: bad width / ld (W=%s%lld, ld=%lld)", "", W, ld);
+    if (!c || !de || !P_out) return set_err("gf_scaled_propagator: null pointer%s", "");
+    const int64_t blocks = (N * ld + 255) / 256;
+    if (blocks > 0x7fffffffLL) return set_err("gf_scaled_propagator: problem too large%s", "");
+    hipLaunchKernelGGL(k_scaled_propagator, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream,
+                       N, W, ld, c, de, P_out);
+    return check_launch("gf_scaled_propagator");
 }
 
 #define GF_LINR_CASE(Rw) case Rw: hipLaunchKernelGGL((k_linR<Rw>), dim3(B * nch, (R + 63) / 64), dim3(64), 0, st, A); break;

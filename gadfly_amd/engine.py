@@ -389,6 +389,107 @@ class ScaledFactor:
         return self._unscaled().predict_at(alpha, ts, Us, Vs, other=other)
 
 
+class WideFactor:
+    """
+    The LDL^T factor of B problems with a WIDE kernel (64 <= W <= 176, complex terms), stored in
+    block-scaled form by the fused wide sweep (k_factorw: rows u~, w~ = r/d, pivots d, reset spans)
+    and swept with the general-width kernels: in scaled coordinates the row-to-row propagator is 1
+    (exp(-c de) at a reset row, ``gf_scaled_propagator``), so ``gf_solve`` runs on these rows
+    unchanged.  One sequential pass builds it (no chunk-parallel machinery at these widths yet);
+    same method surface as :class:`DeviceBatch` / :class:`ScaledFactor`.
+    """
+
+    def __init__(self, owner):
+        torch = owner.torch
+        self.owner, self.torch, self.lib, self.device = owner, torch, owner.lib, owner.device
+        self.B, self.N, self.W = owner.B, owner.N, owner.W
+        lib, p = self.lib, _lib.ptr
+        B, N = self.B, self.N
+        self.ld = int(lib.gf_fused_row_stride(owner.Jr, owner.Jc))
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self.Ut = torch.empty((B, N, self.ld), **f64)
+        self.Wt = torch.empty((B, N, self.ld), **f64)
+        self.de = torch.empty((B, N), **f64)
+        self.d = torch.zeros((B * N + 2,), **f64)[:B * N].view(B, N)
+        self.z = torch.zeros((B * N + 2,), **f64)[:B * N].view(B, N)
+        real, comp, diag_add, c, cmax, block, _ = owner._pack
+        self.c, self.t = c, owner.t
+        S = torch.zeros((B, int(lib.gf_fused_state_size(owner.Jr, owner.Jc))), **f64)
+        self.info = torch.zeros((B,), dtype=torch.int32, device=self.device)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        bs = owner._bs
+        rc = lib.gf_chunk_sweep(
+            B, N, N, 1, owner.Jr, owner.Jc, block, int(owner.generator_period), _lib.GF_SWEEP_AUTO,
+            p(real[0]), p(real[1]), p(comp[0]), p(comp[1]), p(comp[2]), p(comp[3]),
+            p(diag_add), p(cmax), p(owner.t), bs(owner.t), p(owner.diag),
+            0 if owner.diag is None else bs(owner.diag), p(owner.y), bs(owner.y),
+            p(self.d), p(self.z), None, p(self.Ut), p(self.Wt), p(self.de),
+            p(S), None, p(self.info), st)
+        _lib.check(rc, "gf_chunk_sweep")
+        self.P = torch.empty((B, N, self.ld), **f64)
+        rc = lib.gf_scaled_propagator(B, N, self.W, self.ld, p(c), p(self.de), p(self.P), st)
+        _lib.check(rc, "gf_scaled_propagator")
+        self._v1 = None
+
+    def reduce(self, with_quad):
+        """(loglike (B,), logdet (B,)) of the pass that built the factor (z = L^-1 of the owner's y)."""
+        torch = self.torch
+        lib, p = self.lib, _lib.ptr
+        B, N = self.B, self.N
+        f64 = dict(dtype=torch.float64, device=self.device)
+        work = torch.empty((B * int(lib.gf_reduce_work(N)),), **f64)
+        acc = torch.empty((B, 3), **f64)
+        out, logdet = torch.empty((B,), **f64), torch.empty((B,), **f64)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(lib.gf_reduce_tile(B, N, p(self.d), p(self.z) if with_quad else None, p(work),
+                                      p(acc), 1, st), "gf_reduce_tile")
+        _lib.check(lib.gf_loglike_finish(B, N, p(acc), p(self.info), p(out), p(logdet), st),
+                   "gf_loglike_finish")
+        return out, logdet
+
+    @_on_device
+    def _sweep(self, mode, Y, scale=None, out=None):
+        torch = self.torch
+        B, N, R = Y.shape
+        Y = Y.contiguous()
+        Z = out if out is not None else torch.empty_like(Y)
+        p = _lib.ptr
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.gf_solve(mode, B, N, self.W, self.ld, R, p(self.Ut), p(self.Wt), p(self.P),
+                               p(scale), p(Y), p(Z), st)
+        _lib.check(rc, "gf_solve")
+        return Z
+
+    def solve_lower(self, Y):
+        return self._sweep(_lib.GF_SOLVE_LOWER, Y)
+
+    def solve_upper(self, Y, scale=None):
+        return self._sweep(_lib.GF_SOLVE_UPPER, Y, scale=scale)
+
+    def apply_inverse(self, Y):
+        Z = self._sweep(_lib.GF_SOLVE_LOWER, Y)
+        return self._sweep(_lib.GF_SOLVE_UPPER, Z, scale=self.d, out=Z)
+
+    def dot_tril(self, Y):
+        return self._sweep(_lib.GF_MATMUL_LOWER, Y, scale=self.d)
+
+    # prediction at new times: short hop kernels on unscaled generator rows
+    def _unscaled(self):
+        if self._v1 is None:
+            o = self.owner
+            if o._coeffs_list is None:
+                raise RuntimeError("prediction at new times needs the construction-time "
+                                   "coefficients (use_coefficients() replaced them)")
+            self._v1 = DeviceBatch(o._coeffs_list, o.t, diag=o.diag, device=self.device)
+        return self._v1
+
+    def matrices_at(self, tstar):
+        return self._unscaled().matrices_at(tstar)
+
+    def predict_at(self, alpha, ts, Us, Vs, other=None):
+        return self._unscaled().predict_at(alpha, ts, Us, Vs, other=other)
+
+
 class StreamingBatch:
     """
     B independent log-likelihood evaluations streamed through fixed-size tile buffers.
@@ -846,7 +947,10 @@ class StreamingBatch:
 
     @_on_device
     def stored_factor(self, chunk_len=None):
-        """Factorise (time-parallel) and keep the factor for triangular sweeps."""
+        """Factorise and keep the factor for triangular sweeps (time-parallel for W <= 63; one
+        sequential pass of the fused wide sweep beyond)."""
+        if self._wide_ok() and not self._fused_ok():
+            return WideFactor(self)
         _, chunk_len, nch = self._tp_run(chunk_len, store=True)
         return ScaledFactor(self, chunk_len, nch)
 

@@ -341,10 +341,16 @@ class GaussianProcess:
         co = self.kernel.get_device_coefficients()
         W = len(co[0]) + 2 * len(co[2])
         fast = None
-        if W <= 63:
+        wide = None
+        if W <= 63 or (len(co[0]) == 0 and W <= 176):
             fast = StreamingBatch([co], self._t, np.zeros(self._size), diag=self._diag,
                                   device=self._device)
-            if not fast._fused_ok():
+            if fast._wide_ok() and not fast._fused_ok():
+                # wide kernel (e.g. the 86-term solar kernel, W = 172): ONE pass of the fused wide sweep
+                # factorises and stores the factor in scaled form; solves run on it (engine.WideFactor)
+                fast.generator_period = self.generator_period
+                wide, fast = fast.stored_factor(), None
+            elif not fast._fused_ok():
                 fast = None
             else:
                 # the drop-in class favours accuracy over the last 10 % of speed: exact generator
@@ -355,6 +361,10 @@ class GaussianProcess:
         if fast is not None:
             _, logdet = fast.evaluate()
             info = fast.info
+        elif wide is not None:
+            self._factor = wide
+            _, logdet = wide.reduce(with_quad=False)
+            info = wide.info
         else:
             eng = DeviceBatch([co], self._t, diag=self._diag, device=self._device)
             self._factor = eng

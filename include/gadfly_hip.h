@@ -215,6 +215,18 @@ int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int Jr, in
                         const double *dbar, const double *zbar, const double *rbar,
                         double *h_out, double *Phi_out, double *G_out, double *m_out,
                         void *stream);
+/*
+ * The stored rows as a factor for gf_solve (any width the fused sweeps take, in particular the wide
+ * kernels, which have no chunk-parallel sweeps): gf_fused_row_stride is the leading dimension of
+ * Ut_out / Wt_out / r_out (64, or the padded column count of the wide sweep), and
+ * gf_scaled_propagator expands the reset spans de [B][N] into the propagator rows P [B][N][ld] of
+ * the scaled coordinates (1, or exp(-c de) at a reset row; c [B][W]).  gf_solve(U = Ut, Wm = Wt,
+ * P, scale = d) then performs solve_lower / solve_upper / matmul_lower of the TRUE factor
+ * (driver.solve_lower etc. <- gp.py:350, :370, :327).
+ */
+int gf_fused_row_stride(int Jr, int Jc);
+int gf_scaled_propagator(int B, int64_t N, int W, int ld, const double *c, const double *de,
+                         double *P_out, void *stream);
 int gf_chunk_combine(int B, int nch, const double *Phi, const double *G, const double *m,
                      double *S_state, double *F_state, void *stream);
 int gf_chunk_combine_tree(int B, int P, double *Phi, double *G, double *m, double *S, double *F,

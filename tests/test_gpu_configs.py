@@ -166,3 +166,51 @@ def test_cfg5_full_size_sampled(hip):
     assert draws.shape == (R, N)
     want = Z.T - Z.T.mean(axis=0)
     assert _relmax(draws, want) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------
+# the drop-in class on wide kernels (W = 80, and the solar kernel's W = 172): fused wide sweep with
+# the factor stored in scaled form, general-width solves on it
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("J,N,kw", [(40, 2600, dict(gaps=True)), (86, 1500, dict()),
+                                    (33, 900, dict(jitter_t=True)), (64, 1100, dict(yerr=0.0))],
+                         ids=["W80-gaps", "W172", "W66-jitter", "W128-yerr0"])
+def test_gaussian_process_wide_kernel(hip, J, N, kw):
+    import gadfly_amd
+    from gadfly_amd.engine import WideFactor
+    from oracle import cref, seq
+    prob = util.solar_problem(J, N, **kw)
+    k, t, y = prob["kernel"], prob["t"], prob["y"]
+    n = len(t)
+    gp = gadfly_amd.GaussianProcess(k, t=t, diag=prob["diag_user"], mean=0.5)
+    assert isinstance(gp._factor, WideFactor) and gp._fast is None
+    c, a, U, V = util.oracle_matrices(prob, seq)
+    d_ref, W_ref, info = cref.factor(t, c, a, U, V)
+    assert info == 0
+    assert abs(gp._log_det - np.sum(np.log(d_ref))) <= 1e-10 * abs(gp._log_det)
+    assert _relmax(gp._factor.d[0].cpu().numpy(), d_ref) < 1e-9
+    co = k.get_device_coefficients()
+    ref, _ = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y - 0.5)
+    assert abs(gp.log_likelihood(y) - ref) <= RTOL_LL * abs(ref)
+    rng = np.random.default_rng(J)
+    for R in (1, 3):
+        Y = rng.normal(size=(n, R)) if R > 1 else rng.normal(size=n)
+        Y2 = Y.reshape(n, -1)
+        ref_ai = cref.solve_upper(t, c, U, W_ref, cref.solve_lower(t, c, U, W_ref, Y2) / d_ref[:, None])
+        assert _relmax(gp.apply_inverse(Y).reshape(n, -1), ref_ai) < TOL_VEC
+        ref_dt = cref.matmul_lower(t, c, U, W_ref, Y2 * np.sqrt(d_ref)[:, None])
+        assert _relmax(gp.dot_tril(Y).reshape(n, -1), ref_dt) < TOL_VEC
+    # conditional mean at the observed and at new times
+    alpha = cref.solve_upper(t, c, U, W_ref, cref.solve_lower(t, c, U, W_ref, y - 0.5) / d_ref)
+    assert _relmax(gp.predict(y), y - prob["diag_user"] * alpha) < TOL_VEC
+    ts = np.sort(rng.uniform(t[0], t[-1], 40))
+    _, _, Us, Vs = seq.celerite_matrices(co[:6], ts, 0.0)
+    mu_ref = cref.general_matmul(ts, t, c, Us, Vs, U, V, alpha) + 0.5
+    assert _relmax(gp.predict(y, t=ts), mu_ref) < TOL_VEC
+    # a failing matrix is reported at its first non-positive pivot
+    bad = prob["diag_user"].copy()
+    bad[n // 2:] = -2.0 * k.get_value(np.zeros(1))[0]
+    with pytest.raises(gadfly_amd.LinAlgError, match=f"pivot {n // 2 + 1} "):
+        gp.compute(t, diag=bad)
+    gp.compute(t, diag=bad, quiet=True)
+    assert gp.log_likelihood(y) == -np.inf

@@ -24,7 +24,7 @@ def test_bench_distributed_path_rccl(hip):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"),
            "--gpus", "1", "--steps", "1", "--warmup", "1", "--rows", "16384", "--evals", "64",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--no-configs"]
     out = subprocess.run(cmd, cwd=ROOT, env=_env(29541), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]

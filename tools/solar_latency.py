@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""The drop-in classes with gadfly's own default kernel: SolarOscillatorKernel (86 SHO terms, celerite
-width 172) -- the general-width kernels (k_build + k_factor, k_solve_*).  compute / log_likelihood /
-predict(y) / sample.  Usage: python tools/solar_latency.py [N]"""
+"""Latency of the drop-in GaussianProcess with gadfly's default kernel (SolarOscillatorKernel: 86 SHO
+terms, W = 172) -- what /root/reference/gadfly/tests/test_core.py:23-29 and
+notebooks/paper/runtime-speed.ipynb:40-42 run.  Usage: python tools/solar_latency.py [N ...]"""
 import os
 import sys
 import time
@@ -12,26 +12,35 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import gadfly_amd  # noqa: E402
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
-kernel = gadfly_amd.SolarOscillatorKernel(texp=60.0, bandpass="SOHO VIRGO")
-t = np.arange(N) * 60e-6
-rng = np.random.default_rng(0)
-y = 100 * rng.normal(size=N) + np.cumsum(rng.normal(size=N))
 
-
-def timed(label, fn, reps=2):
-    best = 1e30
+def clock(fn, reps=2):
+    fn(); torch.cuda.synchronize()
+    ts = []
     for _ in range(reps):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        out = fn()
-        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
-    print(f"SolarOscillatorKernel W={len(kernel)} N={N}: {label:28s} {best*1e3:9.1f} ms", flush=True)
-    return out
+        t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)) * 1e3, out
 
 
-gp = gadfly_amd.GaussianProcess(kernel, t=t, yerr=30.0)
-timed("compute", lambda: gp.compute(t, yerr=30.0))
-timed("log_likelihood", lambda: gp.log_likelihood(y))
-timed("predict(y)", lambda: gp.predict(y))
-np.random.seed(1)
-timed("sample()", lambda: gp.sample())
+def main():
+    k = gadfly_amd.SolarOscillatorKernel(texp=60.0, bandpass="SOHO VIRGO")
+    W = len(k.get_device_coefficients()[2]) * 2
+    for N in [int(a) for a in sys.argv[1:]] or [100_000, 1_000_000]:
+        t = np.linspace(0, 100, N) * 0.0864 * (N / 1e5)        # 100 d per 1e5 points, in 1e6 s
+        y = np.random.default_rng(0).normal(size=N) * 50
+        gp = gadfly_amd.GaussianProcess(k)
+        ms, _ = clock(lambda: gp.compute(t), reps=2)
+        print(f"SolarOscillatorKernel W={W} N={N}: compute          {ms:9.1f} ms")
+        ms, _ = clock(lambda: gp.log_likelihood(y))
+        print(f"SolarOscillatorKernel W={W} N={N}: log_likelihood   {ms:9.1f} ms")
+        ms, _ = clock(lambda: gp.predict(y))
+        print(f"SolarOscillatorKernel W={W} N={N}: predict(y)       {ms:9.1f} ms")
+        np.random.seed(1)
+        ms, _ = clock(lambda: gp.sample())
+        print(f"SolarOscillatorKernel W={W} N={N}: sample()         {ms:9.1f} ms")
+        del gp
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
