@@ -2535,6 +2535,125 @@ __global__ void __launch_bounds__(64) k_linR(const LinArgs A) {
     }
 }
 
+// k_linR in k_factor7's lane tiling.  k_linR gives every lane ONE right-hand side and all ROWS state
+// rows, so each FMA takes a wave-uniform row operand through an LDS broadcast read: 2 ROWS reads per row,
+// and with eight waves per CU the LDS array -- not the 2 ROWS FMAs -- set the pace (4 % of the HBM roofline
+// on cfg5).  The per-row update is exactly k_factor7's sweep (T += a q^T ; dot += b^T T with T = the
+// state, columns = right-hand sides, q = the carries), so it takes the same tiling: lane (g, c) holds the
+// right-hand sides 2c, 2c + 1 of half the state rows (pairs 4k + 2g, 4k + 2g + 1), one ds_read_b128
+// feeds 8 FMAs (ROWS / 2 reads per row instead of 2 ROWS), and the lane's OWN right-hand side 2c + g
+// (its y, z and carry) is connected to its two state columns by the same two v_permlane32_swap pairs.
+// NODOT: the local pass of GF_MATMUL_LOWER (dot_tril) -- its carries are the inputs themselves, so the
+// pass only accumulates the state: half the FMAs, no reduction.
+template <int ROWS, bool NODOT>
+__global__ void __launch_bounds__(64, 2) k_linR7(const LinArgs A) {
+    const int lane = threadIdx.x;
+    const int g = lane >> 5, c = lane & 31;
+    const int b = blockIdx.x;                       // (problem, chunk)
+    const int rt = blockIdx.y;                      // RHS tile of 64 columns
+    const int pr = b / A.nch, ch = b - pr * A.nch;
+    const int R = A.R;
+    const int r = rt * 64 + 2 * c + g;              // this lane's own right-hand side
+    const bool rok = r < R;
+    const int r0 = rt * 64 + 2 * c;                 // its two state columns: r0, r0 + 1
+    const int64_t c0 = (int64_t)ch * A.chunk_len;
+    const int64_t rows = (A.N - c0 < A.chunk_len) ? (A.N - c0) : A.chunk_len;
+    const size_t pb = (size_t)pr * A.N + c0;
+    const double *__restrict__ Ug = A.Ut + pb * 64 + lane;
+    const double *__restrict__ Wg = A.Wt + pb * 64 + lane;
+    const double *__restrict__ dg = A.d + pb;
+    const double *__restrict__ eg = A.de + pb;
+    const double *__restrict__ Yg = A.Y + pb * R;
+    double *__restrict__ Zg = A.Z + pb * R;
+    double *__restrict__ Fg = A.F_state + (size_t)b * 64 * R;      // [i][R]
+    const double cj = (lane < A.W) ? A.c[(size_t)pr * A.W + lane] : 0.0;
+    const bool up = A.mode == GF_SOLVE_UPPER, mm = A.mode == GF_MATMUL_LOWER;
+    __shared__ __attribute__((aligned(16))) double s_a[64], s_b[64], s_e[64];
+    const double2 *pa = (const double2 *)s_a + g, *pb2 = (const double2 *)s_b + g;
+    const double2 *pe = (const double2 *)s_e + g;
+    double T[ROWS / 2][2];
+#pragma unroll
+    for (int m2 = 0; m2 < ROWS / 2; ++m2) {
+        const int i = 4 * (m2 >> 1) + 2 * g + (m2 & 1);
+        T[m2][0] = (r0 < R) ? Fg[(size_t)i * R + r0] : 0.0;
+        T[m2][1] = (r0 + 1 < R) ? Fg[(size_t)i * R + r0 + 1] : 0.0;
+    }
+    double q0 = 0.0, q1 = 0.0, carry = 0.0;
+    s_a[lane] = 0.0;                                // pending push row (w~_{n-1} or u~_{n+1})
+    double de_cross = -1.0;
+    struct RowIn { double y, pull, push, e, d; };
+    auto fetch = [&](int64_t s) {
+        if (s > rows - 1) s = rows - 1;
+        const int64_t n = up ? (rows - 1 - s) : s;
+        RowIn q;
+        q.y = rok ? Yg[(size_t)n * R + r] : 0.0;
+        q.pull = up ? Wg[(size_t)n * 64] : Ug[(size_t)n * 64];
+        q.push = up ? Ug[(size_t)n * 64] : Wg[(size_t)n * 64];
+        q.e = eg[n];
+        q.d = A.scale ? dg[n] : 1.0;
+        return q;
+    };
+    RowIn p0 = fetch(0), p1 = fetch(1), p2 = fetch(2);
+    double2 ub[S7_AHEAD + 1], wb[S7_AHEAD + 1];
+    for (int64_t s = 0; s < rows; ++s) {
+        const int64_t n = up ? (rows - 1 - s) : s;
+        const RowIn cur = p0;
+        p0 = p1; p1 = p2; p2 = fetch(s + 3);
+        double yn = cur.y;
+        if (A.scale) yn = mm ? yn * sqrt(cur.d) : yn / cur.d;
+        const double de = up ? de_cross : cur.e;    // decay to apply before this row's dot
+        wave_lds_fence();
+        s_b[lane] = cur.pull;
+        const bool dec = de >= 0.0;
+        if (dec) s_e[lane] = fm_exp(-cj * de);
+        wave_lds_fence();
+        if (dec) {                                  // fold the pending push, decay the state rows
+            double d0, d1;
+            sweep7_preload<ROWS>(ub, wb, pe, pa);
+            sweep7_run<ROWS, true>(T, ub, wb, pe, pa, q0, q1, 1.0, 1.0, d0, d1);
+            q0 = 0.0;
+            q1 = 0.0;
+        }
+        if constexpr (NODOT) {
+#pragma unroll
+            for (int k = 0; k < ROWS / 4; ++k) {
+                const double2 w = pa[2 * k];
+                T[2 * k][0] = fma(w.x, q0, T[2 * k][0]);
+                T[2 * k][1] = fma(w.x, q1, T[2 * k][1]);
+                T[2 * k + 1][0] = fma(w.y, q0, T[2 * k + 1][0]);
+                T[2 * k + 1][1] = fma(w.y, q1, T[2 * k + 1][1]);
+            }
+            carry = yn;
+        } else {
+            double acc0, acc1;
+            __builtin_amdgcn_s_setprio(0);
+            sweep7_preload<ROWS>(ub, wb, pb2, pa);
+            sweep7_run<ROWS, false>(T, ub, wb, pb2, pa, q0, q1, 0.0, 0.0, acc0, acc1);
+            __builtin_amdgcn_s_setprio(GF_CHAIN_PRIO);
+            const double dot = own_column_sum(acc0, acc1);
+            const double zn = mm ? (yn + dot) : (yn - dot);
+            if (A.store && rok) Zg[(size_t)n * R + r] = zn;
+            carry = mm ? yn : zn;
+        }
+        both_halves(carry, q0, q1);                 // the carries of this lane's two state columns
+        wave_lds_fence();
+        s_a[lane] = cur.push;
+        if (up) de_cross = cur.e;
+    }
+    wave_lds_fence();
+    const bool dec = up && de_cross >= 0.0;
+    if (dec) s_e[lane] = fm_exp(-cj * de_cross);
+    wave_lds_fence();
+#pragma unroll
+    for (int m2 = 0; m2 < ROWS / 2; ++m2) {
+        const int i = 4 * (m2 >> 1) + 2 * g + (m2 & 1);
+        double v0 = fma(s_a[i], q0, T[m2][0]), v1 = fma(s_a[i], q1, T[m2][1]);
+        if (dec) { v0 *= s_e[i]; v1 *= s_e[i]; }
+        if (r0 < R) Fg[(size_t)i * R + r0] = v0;
+        if (r0 + 1 < R) Fg[(size_t)i * R + r0 + 1] = v1;
+    }
+}
+
 // Linear combine of the chunk states of a sweep: on entry F_state slot c holds chunk c's end
 // state from a zero start (local pass); on exit it holds the TRUE start state of chunk c.
 //   lower  : F_{c+1} = Fbar_c + Phi_c F_c            (ascending; Phi = true closed-loop transition)
@@ -2615,6 +2734,61 @@ k_lincombine(const int nch, const int /*W*/, const int mode, const int R,
     if (s < nch) step(P[0], P[3], s);
     if (s + 1 < nch) step(P[1], P[0], s + 1);
     if (s + 2 < nch) step(P[2], P[1], s + 2);
+}
+
+// Combine of GF_MATMUL_LOWER (dot_tril): the chunk transitions are DIAGONAL (D_c), so the start states are
+// a plain scan  F_{c+1} = loc_c + D_c o F_c  of 64 x R independent scalar sequences.  One workgroup of 16
+// waves per (problem, state row), lane = right-hand side (the states are stored [row][R]: coalesced rows
+// of 8 R bytes; with lane = state row every lane touched its own cache line): the chunks are cut into 16 segments that are
+// scanned concurrently (zero start; eight chunks of loads in flight per wave: the loop is otherwise one
+// dependent memory round trip per chunk), the 16 segment summaries are chained in LDS, and every wave
+// rescans its segment from its true start state, writing the start state of every chunk.
+constexpr int LCM_WAVES = 16, LCM_BATCH = 8;
+__global__ void __launch_bounds__(64 * LCM_WAVES)
+k_lincombine_mm(const int nch, const int R, const double *__restrict__ Dch_, double *__restrict__ F_state) {
+    const int pr = blockIdx.x, i = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = (lane < R) ? lane : (R - 1);      // idle lanes shadow the last right-hand side (no stores)
+    const bool rok = lane < R;
+    const int seg = (nch + LCM_WAVES - 1) / LCM_WAVES;
+    const int s0 = w * seg, s1 = (s0 + seg < nch) ? (s0 + seg) : nch;
+    __shared__ double s_end[LCM_WAVES][64], s_dec[LCM_WAVES][64];
+    auto F_at = [&](int s) { return F_state + ((size_t)pr * nch + s) * 64 * R + (size_t)i * R + r; };
+    auto D_at = [&](int s) { return Dch_[((size_t)pr * nch + s) * 64 + i]; };
+    // phase 1: segment end state from a zero start, and the segment's total decay
+    double cur = 0.0, dec = 1.0;
+    for (int s = s0; s < s1; s += LCM_BATCH) {
+        double loc[LCM_BATCH], dd[LCM_BATCH];
+#pragma unroll
+        for (int j = 0; j < LCM_BATCH; ++j) {
+            const bool ok = s + j < s1;
+            loc[j] = ok ? *F_at(s + j) : 0.0;
+            dd[j] = ok ? D_at(s + j) : 1.0;
+        }
+#pragma unroll
+        for (int j = 0; j < LCM_BATCH; ++j) { cur = fma(dd[j], cur, loc[j]); dec *= dd[j]; }
+    }
+    s_end[w][lane] = cur;
+    s_dec[w][lane] = dec;
+    __syncthreads();
+    // phase 2: this segment's true start state (chain of the summaries before it)
+    double start = 0.0;
+    for (int w2 = 0; w2 < w; ++w2) start = fma(s_dec[w2][lane], start, s_end[w2][lane]);
+    // phase 3: rescan, leaving the true start state of every chunk in its slot
+    cur = start;
+    for (int s = s0; s < s1; s += LCM_BATCH) {
+        double loc[LCM_BATCH], dd[LCM_BATCH];
+#pragma unroll
+        for (int j = 0; j < LCM_BATCH; ++j) {
+            const bool ok = s + j < s1;
+            loc[j] = ok ? *F_at(s + j) : 0.0;
+            dd[j] = ok ? D_at(s + j) : 1.0;
+        }
+#pragma unroll
+        for (int j = 0; j < LCM_BATCH; ++j) {
+            if (rok && s + j < s1) *F_at(s + j) = cur;
+            cur = fma(dd[j], cur, loc[j]);
+        }
+    }
 }
 
 // D_c[j] = exp(-c_j * (sum of the reset spans inside chunk c))   (diagonal chunk transition of
@@ -4191,7 +4365,7 @@ int gf_scaled_propagator(int B, int64_t N, int W, int ld, const double *c, const
     return check_launch("gf_scaled_propagator");
 }
 
-#define GF_LINR_CASE(Rw) case Rw: hipLaunchKernelGGL((k_linR<Rw>), dim3(B * nch, (R + 63) / 64), dim3(64), 0, st, A); break;
+#define GF_LINR_CASE(Rw) case Rw: if (mode == GF_MATMUL_LOWER && !store) hipLaunchKernelGGL((k_linR7<Rw, true>), dim3(B * nch, (R + 63) / 64), dim3(64), 0, st, A); else hipLaunchKernelGGL((k_linR7<Rw, false>), dim3(B * nch, (R + 63) / 64), dim3(64), 0, st, A); break;
 
 int gf_chunk_linear(int mode, int B, int64_t N, int64_t chunk_len, int nch, int W, int R,
                     int scale, int store, const double *c,
@@ -4229,8 +4403,11 @@ int gf_chunk_linear_combine(int mode, int B, int64_t N, int64_t chunk_len, int n
     if (!F_state || (mode == GF_MATMUL_LOWER ? (!D_work || !c || !de) : !Phi))
         return set_err("gf_chunk_linear_combine: null pointer%s", "");
     hipStream_t st = (hipStream_t)stream;
-    if (mode == GF_MATMUL_LOWER)
+    if (mode == GF_MATMUL_LOWER) {
         hipLaunchKernelGGL(k_chunk_decay, dim3(B * nch), dim3(64), 0, st, N, chunk_len, nch, W, c, de, D_work);
+        hipLaunchKernelGGL(k_lincombine_mm, dim3(B, 64), dim3(64 * LCM_WAVES), 0, st, nch, R, D_work, F_state);
+        return check_launch("gf_chunk_linear_combine");
+    }
     hipLaunchKernelGGL(k_lincombine, dim3(B, R), dim3(256), 0, st, nch, W, mode, R, Phi, D_work, F_state);
     return check_launch("gf_chunk_linear_combine");
 }

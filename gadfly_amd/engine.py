@@ -342,15 +342,21 @@ class ScaledFactor:
         Y = Y.contiguous()
         Z = torch.empty_like(Y)
         f64 = dict(dtype=torch.float64, device=self.device)
-        F = torch.zeros((B * self.nch, 64 * R), **f64)
+        chunk_len, nch = self.chunk_len, self.nch
+        if mode == _lib.GF_MATMUL_LOWER and nch > 1:
+            # dot_tril's chunk transitions are diagonal products of the reset decays, computed for ANY
+            # chunking: cut the series finer than the factorisation did (two waves per SIMD; the chunks
+            # of the factor leave half the SIMDs without a wave when there is one RHS tile)
+            chunk_len, nch = self._mm_chunking(R)
+        F = torch.zeros((B * nch, 64 * R), **f64)
         st = torch.cuda.current_stream(self.device).cuda_stream
-        args = (mode, B, N, self.chunk_len, self.nch, self.W, R)
+        args = (mode, B, N, chunk_len, nch, self.W, R)
         rows = (p(self.c), p(self.Ut), p(self.Wt), p(self.d), p(self.de))
-        if self.nch > 1:
+        if nch > 1:
             rc = lib.gf_chunk_linear(*args, int(scale), 0, *rows, p(Y), p(Z), p(F), st)
             _lib.check(rc, "gf_chunk_linear")
-            if mode == _lib.GF_MATMUL_LOWER and self._D is None:
-                self._D = torch.empty((B * self.nch, 64), **f64)
+            if mode == _lib.GF_MATMUL_LOWER and (self._D is None or self._D.shape[0] != B * nch):
+                self._D = torch.empty((B * nch, 64), **f64)
             rc = lib.gf_chunk_linear_combine(
                 *args, p(self.c), p(self.de),
                 None if mode == _lib.GF_MATMUL_LOWER else p(self.Phi),
@@ -359,6 +365,15 @@ class ScaledFactor:
         rc = lib.gf_chunk_linear(*args, int(scale), 1, *rows, p(Y), p(Z), p(F), st)
         _lib.check(rc, "gf_chunk_linear")
         return Z
+
+    def _mm_chunking(self, R):
+        """Chunks for the dot_tril sweeps: ~2048 waves (two per SIMD) over B problems and the RHS
+        tiles, at least 128 rows each, on multiples of 64 rows (every chunk starts on a reset row)."""
+        tiles = -(-R // 64) if R > 1 else 1
+        want = max(1, 2048 // (self.B * tiles))
+        chunk_len = max(128, -(-self.N // want))
+        chunk_len = (chunk_len + 63) // 64 * 64
+        return chunk_len, -(-self.N // chunk_len)
 
     def solve_lower(self, Y):
         return self._sweep(_lib.GF_SOLVE_LOWER, Y, 0)
