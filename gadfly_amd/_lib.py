@@ -60,6 +60,7 @@ SIGNATURES = {
                                 + [_vp]),
     "gf_chunk_transition": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int, _int] + [_vp] * 7
                             + [_vp, _i64] + [_vp] * 7 + [_vp]),
+    "gf_chunk_transition_wide": (_int, [_int, _i64, _i64, _int, _int] + [_vp] * 7 + [_vp]),
     "gf_chunk_combine": (_int, [_int, _int] + [_vp] * 5 + [_vp]),
     "gf_chunk_combine_tree": (_int, [_int, _int] + [_vp] * 7 + [_vp]),
     "gf_reduce_work": (_i64, [_i64]),

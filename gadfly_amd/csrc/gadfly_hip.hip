@@ -1444,10 +1444,11 @@ __device__ __forceinline__ double own_column_sum4(const double a, const double b
 #ifndef GF_WIDE_AHEAD
 #define GF_WIDE_AHEAD 1
 #endif
-// T[2k + s][e] is row 8k + 2g + s, column 2cb + e.  pu / pw point at this row group's first row pair.
+// T[2k + s][e] is row 2G k + 2g + s, column 2cb + e (G = row groups per wave: 4 in k_factorw, 8 in
+// k_phiw).  pu / pw point at this row group's first row pair.
 //   RESET = false:  T += w q^T ;  acc += u^T T         (update + mat-vec)
 //   RESET = true :  T  = (T + w q^T) * (e_row el_col)  (fold pending, decay; pu = the row decays)
-template <int TR, bool RESET>
+template <int TR, bool RESET, int G = 4>
 __device__ __forceinline__ void sweepw_run(double (&T)[TR][2], const double2 *pu, const double2 *pw,
                                            const double q0, const double q1, const double el0,
                                            const double el1, double &o0, double &o1) {
@@ -1459,10 +1460,10 @@ __device__ __forceinline__ void sweepw_run(double (&T)[TR][2], const double2 *pu
     double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
     double2 ub[AH + 1], wb[AH + 1];
 #pragma unroll
-    for (int k = 0; k < AH; ++k) { ub[k] = pu[4 * k]; wb[k] = pw[4 * k]; }
+    for (int k = 0; k < AH; ++k) { ub[k] = pu[G * k]; wb[k] = pw[G * k]; }
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        if (k + AH < NK) { ub[(k + AH) % (AH + 1)] = pu[4 * (k + AH)]; wb[(k + AH) % (AH + 1)] = pw[4 * (k + AH)]; }
+        if (k + AH < NK) { ub[(k + AH) % (AH + 1)] = pu[G * (k + AH)]; wb[(k + AH) % (AH + 1)] = pw[G * (k + AH)]; }
         __builtin_amdgcn_sched_barrier(0);
         const double2 u = ub[k % (AH + 1)], w = wb[k % (AH + 1)];
         if constexpr (RESET) {
@@ -1792,6 +1793,128 @@ k_factorw(const FactorWArgs A,
         const double w = sh.w[fin][2 * g + ro];
         col0[ro] = fma(w, q0, T[m][0]);
         col1[ro] = fma(w, q1, T[m][1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_phiw: the closed-loop transition sweep of the exact time-parallel evaluation (k_phi / k_phi7) for WIDE
+// kernels:  Phi <- (I - w~ u~^T) Phi  (rows scaled by E at reset rows),  h_n = Phi^T u~_n, on the rows the
+// nominal pass stored (u~ rows, r~ rows, pivots, reset spans).  Its columns are INDEPENDENT -- the
+// multipliers -h_j / d of a column come from that column's own mat-vec -- so every wave sweeps its 16
+// columns of Phi with no barrier and no generator: one single-wave workgroup per (problem, chunk, 16
+// columns), lane (g, c) = (lane >> 3, lane & 7) holds the column pair 8 w + c of the row pairs
+// 16k + 2g, 16k + 2g + 1 (8 row groups: 22 rows per lane at W = 172, so two waves per SIMD fit), row
+// operands staged per wave in LDS from plain coalesced row loads two rows ahead.  The Gram sums
+// G = sum h h^T / d and the W x W combines of the chunk maps are plain dense GEMMs / solves and run
+// as library calls (rocBLAS / hipSOLVER through torch) on these outputs.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double own_column_sum8(const double a, const double b) {
+    const double h = own_column_sum(a, b);          // lanes l, l ^ 32 (reduce-scatter over the halves)
+    const auto l = __builtin_amdgcn_permlane16_swap(__double2loint(h), __double2loint(h), false, false);
+    const auto u = __builtin_amdgcn_permlane16_swap(__double2hiint(h), __double2hiint(h), false, false);
+    double s = __hiloint2double(u[0], l[0]) + __hiloint2double(u[1], l[1]);     // l, l ^ 16
+    s += dpp_get<0x128, 0xf>(s);                                                  // row_ror:8: l, l ^ 8
+    return s;
+}
+
+template <int TR>
+__global__ void __launch_bounds__(64, 2)
+k_phiw(const int64_t N, const int64_t chunk_len, const int nch, const int W, const int CP,
+       const double *__restrict__ c_, const double *__restrict__ de_, const double *__restrict__ dbar_,
+       const double *__restrict__ rbar_, const double *__restrict__ ut_,
+       double *__restrict__ h_out, double *__restrict__ Phi_out) {
+    constexpr int RP = 8 * TR;                      // state rows, padded
+    constexpr int LV = 192;                         // LDS row vectors (CP, RP <= 192)
+    constexpr int NL = 3;                           // row entries per lane (lane, lane + 64, lane + 128)
+    const int lane = threadIdx.x;
+    const int nwv = CP / 16;                        // waves (16-column groups) per chunk
+    const int slot = blockIdx.x / nwv, wave = blockIdx.x - slot * nwv;
+    const int pr = slot / nch, ch = slot - pr * nch;
+    const int g = lane >> 3, c = lane & 7;
+    const int cb = wave * 8 + c;                    // column pair of this lane
+    const int own = 2 * cb + (lane >> 5);           // its own column (h, multipliers)
+    const int64_t c0 = (int64_t)ch * chunk_len;
+    const int64_t rows = (N - c0 < chunk_len) ? (N - c0) : chunk_len;
+    const size_t pb = (size_t)pr * N + c0;
+    const double *__restrict__ eg = de_ + pb;
+    const double *__restrict__ dg = dbar_ + pb;
+    const double *__restrict__ rg = rbar_ + pb * CP;
+    const double *__restrict__ ug = ut_ + pb * CP;
+    double *__restrict__ hg = h_out + pb * CP + own;
+    __shared__ __attribute__((aligned(16))) double s_w[LV], s_u[LV], s_e[LV];
+    const double2 *pw = (const double2 *)s_w + g, *pu = (const double2 *)s_u + g, *pe = (const double2 *)s_e + g;
+    int idx[NL];
+    double ci[NL];
+    bool ok[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const int i = lane + 64 * k;
+        ok[k] = i < CP;
+        idx[k] = ok[k] ? i : (CP - 1);
+        ci[k] = (i < W) ? c_[(size_t)pr * W + i] : 0.0;
+        s_w[i] = 0.0; s_u[i] = 0.0; s_e[i] = 1.0;   // (LV = 192 = 3 * 64: every entry initialised)
+    }
+    double T[TR][2];
+#pragma unroll
+    for (int m2 = 0; m2 < TR; ++m2) {               // Phi = I
+        const int row = 16 * (m2 >> 1) + 2 * g + (m2 & 1);
+        T[m2][0] = (row == 2 * cb) ? 1.0 : 0.0;
+        T[m2][1] = (row == 2 * cb + 1) ? 1.0 : 0.0;
+    }
+    double q0 = 0.0, q1 = 0.0;
+    // rows n and n + 1 of u~ and r~ in registers (the caller pads both arrays by two rows)
+    const int vz = __builtin_amdgcn_mbcnt_lo(0u, 0u);
+    double u_a[NL], u_b[NL], r_a[NL], r_b[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        u_a[k] = ug[idx[k]]; u_b[k] = ug[CP + idx[k]];
+        r_a[k] = rg[idx[k]]; r_b[k] = rg[CP + idx[k]];
+    }
+    double d_a = dg[vz], d_b = dg[1 + vz], e_a = eg[vz], e_b = eg[1 + vz];
+    for (int64_t n = 0; n < rows; ++n) {
+        const double dcur = d_a, de = read_lane(e_a, 0);
+        double rcur[NL];
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < NL; ++k) { if (ok[k]) s_u[lane + 64 * k] = u_a[k]; rcur[k] = r_a[k]; }
+        if (de >= 0.0) {                    // reset row: Phi <- E (Phi + pending): row scaling only
+#pragma unroll
+            for (int k = 0; k < NL; ++k) if (ok[k]) s_e[lane + 64 * k] = fm_exp(-ci[k] * de);
+            wave_lds_fence();
+            double d0, d1;
+            sweepw_run<TR, true, 8>(T, pe, pw, q0, q1, 1.0, 1.0, d0, d1);
+            q0 = 0.0;
+            q1 = 0.0;
+        }
+        // next rows into the register queue
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            u_a[k] = u_b[k]; r_a[k] = r_b[k];
+            u_b[k] = ug[(size_t)(n + 2) * CP + idx[k]];
+            r_b[k] = rg[(size_t)(n + 2) * CP + idx[k]];
+        }
+        d_a = d_b; e_a = e_b;
+        d_b = dg[n + 2 + vz];
+        e_b = eg[n + 2 + vz];
+        wave_lds_fence();
+        double acc0, acc1;
+        sweepw_run<TR, false, 8>(T, pu, pw, q0, q1, 0.0, 0.0, acc0, acc1);
+        const double h = own_column_sum8(acc0, acc1);
+        hg[(size_t)n * CP] = h;             // (the four owner lanes of a column write the same value)
+        both_halves(-h / dcur, q0, q1);
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < NL; ++k) if (ok[k]) s_w[lane + 64 * k] = rcur[k];   // pending: Phi_i -= (r_i / d) h_j
+    }
+    wave_lds_fence();
+    double *__restrict__ col0 = Phi_out + (size_t)slot * ((size_t)CP * RP) + (size_t)(2 * cb) * RP + 2 * g;
+    double *__restrict__ col1 = col0 + RP;
+#pragma unroll
+    for (int m2 = 0; m2 < TR; ++m2) {
+        const int ro = 16 * (m2 >> 1) + (m2 & 1);
+        const double w = s_w[2 * g + ro];
+        col0[ro] = fma(w, q0, T[m2][0]);
+        col1[ro] = fma(w, q1, T[m2][1]);
     }
 }
 
@@ -4343,6 +4466,30 @@ int gf_chunk_combine_tree(int B, int P, double *Phi, double *G, double *m, doubl
         hipLaunchKernelGGL(k_tree_apply, dim3(B * (P / (2 * d))), dim3(256), lds, st, A);
     }
     return check_launch("gf_chunk_combine_tree");
+}
+
+int gf_chunk_transition_wide(int B, int64_t N, int64_t chunk_len, int nch, int Jc,
+                             const double *c, const double *de, const double *dbar, const double *rbar,
+                             const double *Ut, double *h_out, double *Phi_out, void *stream) {
+    const int W = 2 * Jc;
+    if (B < 1 || N < 1) return set_err("gf_chunk_transition_wide: empty problem (N=%s%lld)", "", N);
+    if (W <= 63 || !gf_fused_supported(0, Jc)) return set_err("gf_chunk_transition_wide: width %s%lld unsupported (64..176)", "", W);
+    if (nch < 1 || chunk_len < 1 || (nch > 1 && (chunk_len % 64) != 0) || (int64_t)nch * chunk_len < N
+        || (int64_t)(nch - 1) * chunk_len >= N)
+        return set_err("gf_chunk_transition_wide: bad chunking (chunk_len=%s%lld, nch=%lld)", "", chunk_len, nch);
+    if (!c || !de || !dbar || !rbar || !Ut || !h_out || !Phi_out) return set_err("gf_chunk_transition_wide: null pointer%s", "");
+    const WideShape ws = wide_shape(W);
+    const int CP = 32 * ws.nw, tr8 = ws.tr / 2;     // rows per lane with 8 row groups
+    const int64_t grid = (int64_t)B * nch * (CP / 16);
+    if (grid > 0x7fffffffLL) return set_err("gf_chunk_transition_wide: problem too large%s", "");
+    hipStream_t st = (hipStream_t)stream;
+#define GF_PW(TRv) case TRv: hipLaunchKernelGGL((k_phiw<TRv>), dim3((unsigned)grid), dim3(64), 0, st, N, chunk_len, nch, W, CP, c, de, dbar, rbar, Ut, h_out, Phi_out); break;
+    switch (tr8) {
+        GF_PW(8) GF_PW(10) GF_PW(12) GF_PW(14) GF_PW(16) GF_PW(18) GF_PW(20) GF_PW(22)
+        default: return set_err("gf_chunk_transition_wide: internal dispatch error%s", "");
+    }
+#undef GF_PW
+    return check_launch("gf_chunk_transition_wide");
 }
 
 // leading dimension of the rows gf_chunk_sweep stores (Ut_out, Wt_out, r_out): 64 for W <= 63, the padded

@@ -302,6 +302,91 @@ class DeviceBatch:
 LOG_2PI = math.log(2.0 * math.pi)
 
 
+_SOLVE_BATCH = 32
+
+
+def _solve_quiet(torch, A, rhs):
+    """Batched LU solve that never raises: the maps of chunks at or after a non-positive pivot are
+    garbage (singular, NaN) by construction; they only ever feed chunks that fail anyway."""
+    if A.ndim == 3 and A.shape[0] > _SOLVE_BATCH:
+        # (hipBLAS' batched triangular solve runs out of workspace on large batches of 172 x 345
+        # systems: HIPBLAS_STATUS_ALLOC_FAILED at 256; groups of 32 are as fast)
+        return torch.cat([_solve_quiet(torch, A[i:i + _SOLVE_BATCH], rhs[i:i + _SOLVE_BATCH])
+                          for i in range(0, A.shape[0], _SOLVE_BATCH)])
+    return torch.linalg.solve_ex(A, rhs, check_errors=False)[0]
+
+
+def _lft_compose(torch, M1, M2):
+    """Chunk map M2 after M1 (batched; each map = (Phi, G, Xbar, Ybar, m)):
+    D = (I - X1 G2)^-1;  Phi = Phi2 D Phi1;  X = X2 + Phi2 D X1 Phi2^T;  G = G1 + Phi1^T G2 D Phi1;
+    v = D (Y1 - X1 m2);  Y = Y2 + Phi2 v;  m = m1 + Phi1^T (m2 - G2 v)."""
+    P1, G1, X1, Y1, m1 = M1
+    P2, G2, X2, Y2, m2 = M2
+    W = P1.shape[-1]
+    A = torch.eye(W, dtype=P1.dtype, device=P1.device) - X1 @ G2
+    rhs = torch.cat([P1, X1, (Y1 - (X1 @ m2.unsqueeze(-1)).squeeze(-1)).unsqueeze(-1)], dim=-1)
+    sol = _solve_quiet(torch, A, rhs)
+    DP1, DX1, v = sol[..., :W], sol[..., W:2 * W], sol[..., 2 * W]
+    P12 = P2 @ DP1
+    X12 = X2 + P2 @ DX1 @ P2.transpose(-1, -2)
+    G12 = G1 + P1.transpose(-1, -2) @ G2 @ DP1
+    Y12 = Y2 + (P2 @ v.unsqueeze(-1)).squeeze(-1)
+    m12 = m1 + (P1.transpose(-1, -2) @ (m2 - (G2 @ v.unsqueeze(-1)).squeeze(-1)).unsqueeze(-1)).squeeze(-1)
+    return (P12, 0.5 * (G12 + G12.transpose(-1, -2)), 0.5 * (X12 + X12.transpose(-1, -2)), Y12, m12)
+
+
+def _lft_apply(torch, M, X, Y):
+    """State (X, Y) through a chunk map: X+ = Xbar + Phi K Phi^T, K = (I - X G)^-1 X;
+    Y+ = Ybar + Phi (I - X G)^-1 (Y - X m)."""
+    Ph, G, Xb, Yb, m = M
+    W = Ph.shape[-1]
+    A = torch.eye(W, dtype=Ph.dtype, device=Ph.device) - X @ G
+    rhs = torch.cat([X, (Y - (X @ m.unsqueeze(-1)).squeeze(-1)).unsqueeze(-1)], dim=-1)
+    sol = _solve_quiet(torch, A, rhs)
+    K, v = sol[..., :W], sol[..., W]
+    K = 0.5 * (K + K.transpose(-1, -2))
+    Xn = Xb + Ph @ K @ Ph.transpose(-1, -2)
+    Yn = Yb + (Ph @ v.unsqueeze(-1)).squeeze(-1)
+    return 0.5 * (Xn + Xn.transpose(-1, -2)), Yn
+
+
+def _lft_tree_scan(torch, Ph, G, Xb, Yb, m):
+    """True start state of every chunk from the chunk maps, as a Blelloch scan (2 log2 P batched
+    levels of dense W x W GEMMs / LU solves: rocBLAS / hipSOLVER through torch).  Inputs are
+    (nch, W, W) / (nch, W); returns (Xstart (nch, W, W), Ystart (nch, W))."""
+    nch, W = Ph.shape[0], Ph.shape[-1]
+    P = 1 << max(0, (nch - 1).bit_length())
+    if P > nch:                                         # identity maps pad the scan
+        pad = P - nch
+        eye = torch.eye(W, dtype=Ph.dtype, device=Ph.device).expand(pad, W, W)
+        zW = torch.zeros((pad, W, W), dtype=Ph.dtype, device=Ph.device)
+        zv = torch.zeros((pad, W), dtype=Ph.dtype, device=Ph.device)
+        Ph, G, Xb = torch.cat([Ph, eye]), torch.cat([G, zW]), torch.cat([Xb, zW])
+        Yb, m = torch.cat([Yb, zv]), torch.cat([m, zv])
+    maps = [Ph.clone(), G.clone(), Xb.clone(), Yb.clone(), m.clone()]
+    ar = torch.arange(P, device=Ph.device)
+    d = 1
+    while d < P:                                        # up-sweep: map[right] <- map[right] o map[left]
+        right = ar[2 * d - 1::2 * d]
+        left = right - d
+        new = _lft_compose(torch, [a[left] for a in maps], [a[right] for a in maps])
+        for a, v in zip(maps, new):
+            a[right] = v
+        d *= 2
+    Xs = torch.zeros((P, W, W), dtype=Ph.dtype, device=Ph.device)
+    Ys = torch.zeros((P, W), dtype=Ph.dtype, device=Ph.device)
+    d = P // 2
+    while d >= 1:                                       # down-sweep
+        right = ar[2 * d - 1::2 * d]
+        left = right - d
+        Xin, Yin = Xs[right], Ys[right]
+        Xo, Yo = _lft_apply(torch, [a[left] for a in maps], Xin, Yin)
+        Xs[left], Ys[left] = Xin, Yin
+        Xs[right], Ys[right] = Xo, Yo
+        d //= 2
+    return Xs[:nch], Ys[:nch]
+
+
 class ScaledFactor:
     """
     The LDL^T factor of B problems stored in block-scaled form (rows u~, w~ = r/d, pivots d,
@@ -414,7 +499,7 @@ class WideFactor:
     same method surface as :class:`DeviceBatch` / :class:`ScaledFactor`.
     """
 
-    def __init__(self, owner):
+    def __init__(self, owner, time_parallel=None, chunk_len=None):
         torch = owner.torch
         self.owner, self.torch, self.lib, self.device = owner, torch, owner.lib, owner.device
         self.B, self.N, self.W = owner.B, owner.N, owner.W
@@ -422,25 +507,32 @@ class WideFactor:
         B, N = self.B, self.N
         self.ld = int(lib.gf_fused_row_stride(owner.Jr, owner.Jc))
         f64 = dict(dtype=torch.float64, device=self.device)
-        self.Ut = torch.empty((B, N, self.ld), **f64)
+        # (two spare rows: the transition sweep reads its rows two ahead, unconditionally)
+        self.Ut = torch.zeros((B * N + 2, self.ld), **f64)[:B * N].view(B, N, self.ld)
         self.Wt = torch.empty((B, N, self.ld), **f64)
-        self.de = torch.empty((B, N), **f64)
+        self.de = torch.zeros((B * N + 2,), **f64)[:B * N].view(B, N)
         self.d = torch.zeros((B * N + 2,), **f64)[:B * N].view(B, N)
         self.z = torch.zeros((B * N + 2,), **f64)[:B * N].view(B, N)
         real, comp, diag_add, c, cmax, block, _ = owner._pack
         self.c, self.t = c, owner.t
-        S = torch.zeros((B, int(lib.gf_fused_state_size(owner.Jr, owner.Jc))), **f64)
         self.info = torch.zeros((B,), dtype=torch.int32, device=self.device)
         st = torch.cuda.current_stream(self.device).cuda_stream
-        bs = owner._bs
-        rc = lib.gf_chunk_sweep(
-            B, N, N, 1, owner.Jr, owner.Jc, block, int(owner.generator_period), _lib.GF_SWEEP_AUTO,
-            p(real[0]), p(real[1]), p(comp[0]), p(comp[1]), p(comp[2]), p(comp[3]),
-            p(diag_add), p(cmax), p(owner.t), bs(owner.t), p(owner.diag),
-            0 if owner.diag is None else bs(owner.diag), p(owner.y), bs(owner.y),
-            p(self.d), p(self.z), None, p(self.Ut), p(self.Wt), p(self.de),
-            p(S), None, p(self.info), st)
-        _lib.check(rc, "gf_chunk_sweep")
+        self.time_parallel = owner._wide_tp_ok() if time_parallel is None else bool(time_parallel)
+        if self.time_parallel:
+            # exact time-parallel factorisation: chunks swept concurrently, stitched by the LFT combine
+            owner._tp_run_wide(chunk_len, stores=(self.Ut, self.Wt, self.de), d=self.d, z=self.z,
+                               info=self.info)
+        else:
+            S = torch.zeros((B, int(lib.gf_fused_state_size(owner.Jr, owner.Jc))), **f64)
+            bs = owner._bs
+            rc = lib.gf_chunk_sweep(
+                B, N, N, 1, owner.Jr, owner.Jc, block, int(owner.generator_period), _lib.GF_SWEEP_AUTO,
+                p(real[0]), p(real[1]), p(comp[0]), p(comp[1]), p(comp[2]), p(comp[3]),
+                p(diag_add), p(cmax), p(owner.t), bs(owner.t), p(owner.diag),
+                0 if owner.diag is None else bs(owner.diag), p(owner.y), bs(owner.y),
+                p(self.d), p(self.z), None, p(self.Ut), p(self.Wt), p(self.de),
+                p(S), None, p(self.info), st)
+            _lib.check(rc, "gf_chunk_sweep")
         self.P = torch.empty((B, N, self.ld), **f64)
         rc = lib.gf_scaled_propagator(B, N, self.W, self.ld, p(c), p(self.de), p(self.P), st)
         _lib.check(rc, "gf_scaled_propagator")
@@ -945,6 +1037,111 @@ class StreamingBatch:
         w["S"].view(B, nch, 4096).copy_(tr["X"][:, :nch])
         w["F"].view(B, nch, 64).copy_(tr["Y"][:, :nch])
 
+    # -- exact time-parallel evaluation of ONE series with a wide kernel -----------------------------
+    #: shortest series for which the wide time-parallel run replaces the sequential sweep
+    wide_tp_min_rows = 16384
+
+    def _wide_tp_ok(self):
+        return self._wide_ok() and self.B == 1 and self.N >= self.wide_tp_min_rows
+
+    def _wide_chunking(self, chunk_len):
+        if chunk_len is None:
+            # three sweeps of N / nch rows (~1.4 us per row at W = 172) against ~0.36 ms per chunk map in
+            # the dense combine (library GEMMs / LU solves of W x W blocks, launch-bound): the optimum is
+            # nch ~ sqrt(0.012 N) -- 32 chunks at N = 1e5, 128 at N = 1e6 -- rounded to a power of two
+            # (the scan pads to one anyway)
+            want = max(2.0, math.sqrt(0.012 * self.N))
+            nch = 1 << int(round(math.log2(want)))
+            chunk_len = -(-self.N // min(nch, 512))
+        chunk_len = max(64, (int(chunk_len) + 63) // 64 * 64)
+        return chunk_len, -(-self.N // chunk_len)
+
+    @_on_device
+    def _tp_run_wide(self, chunk_len=None, stores=None, d=None, z=None, info=None):
+        """Chunk-parallel factor + forward solve of ONE series with a wide kernel (64 <= W <= 176):
+        nominal pass (k_factorw, zero start states, rows stored) -> closed-loop transitions (k_phiw)
+        -> Gram sums and the LFT tree combine of the W x W chunk maps (dense GEMMs / solves: library
+        calls through torch.bmm / torch.linalg.solve) -> final pass from the true start states.
+        Fills d, z (and the stored factor rows); returns (loglike (1,), logdet (1,), chunk_len, nch)."""
+        if not self._wide_tp_ok() and not (self._wide_ok() and self.B == 1):
+            raise ValueError("wide time-parallel evaluation needs ONE series and a wide fused kernel")
+        torch = self.torch
+        lib, p = self.lib, _lib.ptr
+        N, W = self.N, self.W
+        real, comp, diag_add, c, cmax, block, _ = self._pack
+        L, nch = self._wide_chunking(chunk_len)
+        ld = int(lib.gf_fused_row_stride(self.Jr, self.Jc))
+        nS = int(lib.gf_fused_state_size(self.Jr, self.Jc))
+        RP = nS // ld
+        f64 = dict(dtype=torch.float64, device=self.device)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        NP = nch * L                                    # rows padded to whole chunks (zeros)
+
+        def rows_buf(cols=None):
+            shape = (NP + 2, cols) if cols else (NP + 2,)
+            return torch.zeros(shape, **f64)
+
+        if stores is None:
+            Ut, Wt, de = rows_buf(ld), rows_buf(ld), rows_buf()
+        else:
+            Ut, Wt, de = stores
+        dbar, zbar, rbar, h = rows_buf(), rows_buf(), rows_buf(ld), rows_buf(ld)
+        S = torch.zeros((nch, nS), **f64)
+        Phi = torch.empty((nch, nS), **f64)
+        cinfo = torch.zeros((nch,), dtype=torch.int32, device=self.device)
+        opts = (int(self.generator_period), _lib.GF_SWEEP_AUTO)
+        coeffs = (p(real[0]), p(real[1]), p(comp[0]), p(comp[1]), p(comp[2]), p(comp[3]))
+        tyd = (p(self.t), self._bs(self.t), p(self.diag),
+               0 if self.diag is None else self._bs(self.diag), p(self.y), self._bs(self.y))
+
+        def sweep(dd, zz, r_out, st_rows):
+            rc = lib.gf_chunk_sweep(1, N, L, nch, self.Jr, self.Jc, block, *opts, *coeffs,
+                                    p(diag_add), p(cmax), *tyd, p(dd), p(zz), r_out, *st_rows,
+                                    p(S), None, p(cinfo), st)
+            _lib.check(rc, "gf_chunk_sweep")
+
+        if nch > 1:
+            # 1. nominal pass: zero start states; d-bar, z-bar, r-bar, u~ rows, reset spans
+            sweep(dbar, zbar, p(rbar), (p(Ut), p(Wt), p(de)))
+            # 2. closed-loop transitions and the rows h
+            rc = lib.gf_chunk_transition_wide(1, N, L, nch, self.Jc, p(c), p(de), p(dbar), p(rbar),
+                                              p(Ut), p(h), p(Phi), st)
+            _lib.check(rc, "gf_chunk_transition_wide")
+            # 3. chunk maps (Phi, G, Xbar, Ybar, m) and their tree combine
+            S3, P3 = S.view(nch, ld, RP), Phi.view(nch, ld, RP)
+            Xb = S3[:, :W, :W].transpose(1, 2).contiguous()
+            Yb = S3[:, ld - 1, :W].contiguous()
+            Ph = P3[:, :W, :W].transpose(1, 2).contiguous()
+            Hc = h[:NP].view(nch, L, ld)[:, :, :W]
+            dinv = torch.where(dbar[:NP] > 0, 1.0 / dbar[:NP], torch.zeros_like(dbar[:NP])).view(nch, L, 1)
+            Hd = (Hc * dinv).transpose(1, 2)            # (nch, W, L)
+            G = torch.bmm(Hd, Hc)
+            mm = torch.bmm(Hd, zbar[:NP].view(nch, L, 1)).squeeze(-1)
+            Xs, Ys = _lft_tree_scan(torch, Ph, 0.5 * (G + G.transpose(1, 2)),
+                                    0.5 * (Xb + Xb.transpose(1, 2)), Yb, mm)
+            S.zero_()
+            S3[:, :W, :W] = Xs.transpose(1, 2)
+            S3[:, ld - 1, :W] = Ys
+            cinfo.zero_()       # (a nominal pass can only fail at or after the true failing row)
+        # 4. final pass from the true start states
+        dd = d.reshape(-1) if d is not None else rows_buf()
+        zz = z.reshape(-1) if z is not None else rows_buf()
+        sweep(dd, zz, None, (p(Ut), p(Wt), p(de)) if stores is not None else (None, None, None))
+        big = torch.iinfo(torch.int32).max
+        first = torch.where(cinfo != 0, cinfo, torch.full_like(cinfo, big)).min()
+        flag = torch.where(first == big, torch.zeros_like(first), first).reshape(1)
+        if info is not None:
+            info.copy_(flag)
+        self.info.copy_(flag)
+        work = torch.empty((int(lib.gf_reduce_work(N)),), **f64)
+        acc = torch.empty((1, 3), **f64)
+        out, logdet = torch.empty((1,), **f64), torch.empty((1,), **f64)
+        _lib.check(lib.gf_reduce_tile(1, N, p(dd), p(zz), p(work), p(acc), 1, st), "gf_reduce_tile")
+        _lib.check(lib.gf_loglike_finish(1, N, p(acc), p(self.info), p(out), p(logdet), st),
+                   "gf_loglike_finish")
+        self._wide_tp = dict(d=dd, z=zz, acc=acc, chunk_len=L, nch=nch)
+        return out, logdet, L, nch
+
     @_on_device
     def log_likelihood_time_parallel(self, chunk_len=None):
         """
@@ -953,6 +1150,9 @@ class StreamingBatch:
         Same result as :meth:`log_likelihood` to rounding; ~3.5x the flops but O(N / nch)
         sequential depth -- the latency path for B = 1.  Needs the fused kernel's conditions.
         """
+        if self._wide_ok() and not self._fused_ok() and self.B == 1:
+            self._tp_used = False
+            return self._tp_run_wide(chunk_len)[0]
         if not self._fused_ok():
             raise ValueError("time-parallel evaluation needs W <= 63 and |d t| < 1.6e6")
         if self._tp_chunking(chunk_len)[1] == 1:
@@ -965,7 +1165,7 @@ class StreamingBatch:
         """Factorise and keep the factor for triangular sweeps (time-parallel for W <= 63; one
         sequential pass of the fused wide sweep beyond)."""
         if self._wide_ok() and not self._fused_ok():
-            return WideFactor(self)
+            return WideFactor(self, chunk_len=chunk_len)
         _, chunk_len, nch = self._tp_run(chunk_len, store=True)
         return ScaledFactor(self, chunk_len, nch)
 

@@ -227,6 +227,18 @@ int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int Jr, in
 int gf_fused_row_stride(int Jr, int Jc);
 int gf_scaled_propagator(int B, int64_t N, int W, int ld, const double *c, const double *de,
                          double *P_out, void *stream);
+/*
+ * Wide kernels (64 <= W <= 176, complex terms): the closed-loop transition sweep of step 2 on the rows
+ * the nominal pass stored -- Ut [B][N][ld] (u~ rows), rbar [B][N][ld], dbar [B][N], de [B][N] (reset
+ * spans), ld = gf_fused_row_stride; c [B][W] decay rates; every array readable two rows past the
+ * end.  Outputs the rows h [B][N][ld] and Phi [B*nch][gf_fused_state_size] in the layout of S_state
+ * ([column][row], padded).  The Gram sums G = sum h h^T / dbar, m = sum h zbar / dbar and the
+ * combines of the W x W chunk maps are plain dense GEMMs / solves on these outputs: the caller runs
+ * them as library calls (rocBLAS / hipSOLVER; the Python side uses torch.bmm / torch.linalg.solve).
+ */
+int gf_chunk_transition_wide(int B, int64_t N, int64_t chunk_len, int nch, int Jc,
+                             const double *c, const double *de, const double *dbar, const double *rbar,
+                             const double *Ut, double *h_out, double *Phi_out, void *stream);
 int gf_chunk_combine(int B, int nch, const double *Phi, const double *G, const double *m,
                      double *S_state, double *F_state, void *stream);
 int gf_chunk_combine_tree(int B, int P, double *Phi, double *G, double *m, double *S, double *F,

@@ -214,3 +214,49 @@ def test_gaussian_process_wide_kernel(hip, J, N, kw):
         gp.compute(t, diag=bad)
     gp.compute(t, diag=bad, quiet=True)
     assert gp.log_likelihood(y) == -np.inf
+
+
+@pytest.mark.parametrize("J,N,L,kw", [(40, 3000, 256, dict()), (86, 2600, 192, dict(gaps=True)),
+                                      (33, 2100, 128, dict(jitter_t=True)), (64, 1500, 512, dict(yerr=0.0)),
+                                      (86, 20000, None, dict())],
+                         ids=["W80", "W172-gaps", "W66-jitter", "W128-yerr0", "W172-auto"])
+def test_wide_time_parallel(hip, J, N, L, kw):
+    """Exact time-parallel factorisation of ONE series with a wide kernel (nominal pass, k_phiw
+    transitions, dense LFT tree combine, final pass) against the sequential wide sweep and the oracle:
+    log-likelihood, every pivot d_n and z_n, and the stored factor through a solve."""
+    import torch
+    from gadfly_amd.engine import StreamingBatch, WideFactor
+    from oracle import cref, seq
+    prob = util.solar_problem(J, N, **kw)
+    k, t, y = prob["kernel"], prob["t"], prob["y"]
+    n = len(t)
+    co = k.get_device_coefficients()
+    eng = StreamingBatch([co], t, y, diag=prob["diag_user"])
+    eng.generator_period = 1
+    assert eng._wide_ok() and not eng._fused_ok()
+    ll_seq = float(eng.log_likelihood()[0])
+    ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y)
+    assert info == 0 and abs(ll_seq - ref) <= RTOL_LL * abs(ref)
+    ll_tp = float(eng.log_likelihood_time_parallel(chunk_len=L)[0])
+    assert eng._wide_tp["nch"] > 1
+    assert abs(ll_tp - ref) <= RTOL_LL * abs(ref), (ll_tp, ref)
+    assert abs(ll_tp - ll_seq) <= 1e-10 * abs(ref)
+    c, a, U, V = util.oracle_matrices(prob, seq)
+    d_ref, W_ref, _ = cref.factor(t, c, a, U, V)
+    z_ref = cref.solve_lower(t, c, U, W_ref, y)
+    assert _relmax(eng._wide_tp["d"][:n].cpu().numpy(), d_ref) < 1e-9
+    assert _relmax(eng._wide_tp["z"][:n].cpu().numpy(), z_ref) < 1e-8
+    # the factor stored by the time-parallel run, through the general-width solves
+    fac = WideFactor(eng, time_parallel=True, chunk_len=L)
+    assert fac.time_parallel and _relmax(fac.d[0].cpu().numpy(), d_ref) < 1e-9
+    Y = np.random.default_rng(J).normal(size=(n, 2))
+    ref_ai = cref.solve_upper(t, c, U, W_ref, cref.solve_lower(t, c, U, W_ref, Y) / d_ref[:, None])
+    got = fac.apply_inverse(torch.as_tensor(Y).cuda().reshape(1, n, 2))[0].cpu().numpy()
+    assert _relmax(got, ref_ai) < TOL_VEC
+    # failing matrix: the first non-positive pivot, although later chunks fail as well
+    bad = prob["diag_user"].copy()
+    bad[n // 2:] = -2.0 * k.get_value(np.zeros(1))[0]
+    engb = StreamingBatch([co], t, y, diag=bad)
+    engb.generator_period = 1
+    assert engb.log_likelihood_time_parallel(chunk_len=L).cpu().numpy()[0] == -np.inf
+    assert int(engb.info[0]) == n // 2 + 1
