@@ -2,23 +2,35 @@
 #ifndef FM_INLINE
 #define FM_INLINE static inline
 #endif
-// Cody-Waite reduction by pi/2 in three 33-bit pieces (each n * piece is exact for |n| < 2^20),
-// three rounds unconditionally (151 bits of pi/2), then the classic minimax kernels on
-// [-pi/4, pi/4] with the double-double remainder.  Valid for |x| < 2^20 * pi/2 ~ 1.647e6.
+// Argument reduction by pi/2 with FMA: fn = rint(x 2/pi); x - fn P1 is formed EXACTLY inside one fma
+// (P1 = pi/2 rounded to 53 bits), the remaining fn (P2 + P3) -- pi/2 to 159 bits -- is taken off in
+// double-double arithmetic (fn P2 split exactly by a second fma), so the remainder y0 + y1 carries no
+// cancellation error for any |x| < 2^31 pi/2 ~ 3.37e9 (beyond, the quadrant no longer fits an int).
+// Then the classic minimax kernels on [-pi/4, pi/4].  <= 1 ulp against long-double libm over +-3e9,
+// including the doubles closest to multiples of pi/2 (oracle/fastmath_check.c).  (The previous
+// three-round Cody-Waite scheme with 33-bit pieces was exact without FMA but stopped at 2^20 pi/2 =
+// 1.6e6 -- a 1e6-point series at one-minute cadence already exceeds it with the solar p-modes -- and
+// cost five more operations.)
+#define FM_SINCOS_RANGE 3.0e9
 FM_INLINE void fm_sincos(double x, double *sn, double *cs) {
     const double invpio2 = 6.36619772367581382433e-01;
-    const double p1 = 1.57079632673412561417e+00, p1t = 6.07710050650619224932e-11;
-    const double p2 = 6.07710050630396597660e-11, p2t = 2.02226624879595063154e-21;
-    const double p3 = 2.02226624871116645580e-21, p3t = 8.47842766036889956997e-32;
-    const double fn = rint(x * invpio2);
-    double r = x - fn * p1;                  // exact product, one rounding
-    double w = fn * p1t;
-    double t = r;
-    w = fn * p2;  r = t - w;  w = fn * p2t - ((t - r) - w);
-    t = r;
-    w = fn * p3;  r = t - w;  w = fn * p3t - ((t - r) - w);
-    const double y0 = r - w;
-    const double y1 = (r - y0) - w;
+    const double P1 = 1.5707963267948966e+00;       // 0x3FF921FB54442D18
+    const double P2 = 6.123233995736766e-17;        // 0x3C91A62633145C07
+    const double P3 = -1.4973849048591698e-33;      // 0xB91F1976B7ED8FBC
+    double y0, y1, fn;
+    {
+#ifdef __clang__
+#pragma clang fp contract(off)                      // the error terms below rely on every rounding as written
+#endif
+        fn = rint(x * invpio2);
+        const double r0 = fma(-fn, P1, x);          // exact difference, one rounding
+        const double h = fn * P2;
+        const double l = fma(fn, P2, -h);           // fn P2 = h + l exactly
+        const double y0a = r0 - h;
+        const double e = (((r0 - y0a) - h) - l) - fn * P3;      // what y0a misses
+        y0 = y0a + e;
+        y1 = (y0a - y0) + e;
+    }
     const double z = y0 * y0;
     // sin kernel
     const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,

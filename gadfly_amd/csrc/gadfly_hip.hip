@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(256) k_build2(const Build2Args A) {
             const double ac = A.ac[ck], bc = A.bc[ck], cc = A.cc[ck], dc = A.dc[ck];
             const double arg = dc * tn;              // ONE rounded multiply (parity hazard i)
             double si, co;
-            if (fabs(arg) < 1.6e6) fm_sincos(arg, &si, &co);   // Cody-Waite range
+            if (fabs(arg) < FM_SINCOS_RANGE) fm_sincos(arg, &si, &co);
             else sincos(arg, &si, &co);                        // e.g. JD-based time axes
             const double rho = fm_exp(-cc * ds), irho = 1.0 / rho;
             const int j = A.Jr + 2 * k;
@@ -746,7 +746,7 @@ k_factor2(const int64_t N, const int64_t n_first, const int ld, const int W,
 //   real column: d = 0 (cos = 1), uA = a_r, uB = 0.
 // Between reset rows (anchors: exact fm_sincos, rho = 1) the rho-scaled phasor advances by a cached
 // one-cadence rotation with a second-order correction for cadence jitter (RowGen::next).
-// Valid while |d t| < 1.6e6 (fm_sincos's Cody-Waite range): the caller checks and otherwise
+// Valid while |d t| < 3e9 (fm_sincos's range, FM_SINCOS_RANGE): the caller checks and otherwise
 // uses the k_build2 + k_factor2 pair.
 //
 // Chunk mode (time-parallel evaluation of one series, see k_phi / k_combine): the grid is
@@ -3584,7 +3584,7 @@ k_cross(const int64_t N, const int R, const int Jr, const int Jc,
             const double *p = co + 2 * Jr + 4 * i;
             double si, cs;
             const double x = p[3] * tau;
-            if (fabs(x) < 1.6e6) fm_sincos(x, &si, &cs); else sincos(x, &si, &cs);
+            if (fabs(x) < FM_SINCOS_RANGE) fm_sincos(x, &si, &cs); else sincos(x, &si, &cs);
             k = fma(fma(p[0], cs, p[1] * si), fm_exp(-p[2] * tau), k);
         }
         out[(size_t)b * total + e] = k;

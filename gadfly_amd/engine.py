@@ -300,6 +300,8 @@ class DeviceBatch:
 
 
 LOG_2PI = math.log(2.0 * math.pi)
+#: largest phase |d t| the in-kernel sincos takes (FM_SINCOS_RANGE in csrc/fastmath.h)
+SINCOS_RANGE = 3.0e9
 
 
 _SOLVE_BATCH = 32
@@ -732,12 +734,12 @@ class StreamingBatch:
                      for _ in range(self._nbuf)]
 
     def _fused_ok(self):
-        """Phases d*t must stay inside fm_sincos's Cody-Waite range (|x| < 1.6e6)."""
-        return self.allow_fused and self._pack[6] * self._tmax < 1.6e6
+        """Phases d*t must stay inside fm_sincos's range (|x| < 3e9: FM_SINCOS_RANGE of fastmath.h)."""
+        return self.allow_fused and self._pack[6] * self._tmax < SINCOS_RANGE
 
     def _wide_ok(self):
         """The fused sweep for wide kernels (same phase range; log-likelihood streaming only)."""
-        return self.allow_wide and self._pack[6] * self._tmax < 1.6e6
+        return self.allow_wide and self._pack[6] * self._tmax < SINCOS_RANGE
 
     # error of the log-likelihood ~ GEN_ERR * period * condition (measured: 1e-8 at period 16 and a
     # condition of 4e5, DESIGN.md 2.1a)
@@ -928,7 +930,7 @@ class StreamingBatch:
         """Chunk-parallel factor + forward solve.  store=True also keeps the factor in scaled
         form (u~, w~ rows, reset spans, per-chunk true transitions) for :class:`ScaledFactor`."""
         if not self._fused_ok():
-            raise ValueError("time-parallel evaluation needs W <= 63 and |d t| < 1.6e6")
+            raise ValueError("time-parallel evaluation needs W <= 63 and |d t| < 3e9")
         torch = self.torch
         lib, p = self.lib, _lib.ptr
         N, B = self.N, self.B
@@ -1154,7 +1156,7 @@ class StreamingBatch:
             self._tp_used = False
             return self._tp_run_wide(chunk_len)[0]
         if not self._fused_ok():
-            raise ValueError("time-parallel evaluation needs W <= 63 and |d t| < 1.6e6")
+            raise ValueError("time-parallel evaluation needs W <= 63 and |d t| < 3e9")
         if self._tp_chunking(chunk_len)[1] == 1:
             self._tp_used = False
             return self.log_likelihood()

@@ -139,8 +139,8 @@ int gf_factor_scaled(int B, int64_t N, int64_t n_first, int W, int ld, const dou
  * Fully fused log-likelihood sweep (W <= 63): matrix build + factor + forward solve of N
  * consecutive rows in one kernel, generator rows produced in registers (nothing but t, y, diag
  * is read: 24 B/row).  Replaces gf_build_scaled + gf_factor_scaled on the log-likelihood path
- * (gp.py:202 + gp.py:350) whenever max|d_c| * max|t| < 1.6e6 (the range of the kernel's
- * Cody-Waite sincos; the caller checks).  Arguments as in gf_build_scaled / gf_factor_scaled;
+ * (gp.py:202 + gp.py:350) whenever max|d_c| * max|t| < 3e9 (the range of the kernel's
+ * FMA-reduced sincos; the caller checks).  Arguments as in gf_build_scaled / gf_factor_scaled;
  * t, diag (NULL = 0), y are the WHOLE series (global row index, batch strides t_bs, diag_bs,
  * y_bs) and must be readable three elements past row n_first + N - 1.
  *
@@ -195,7 +195,7 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
  *                          gf_chunk_linear.
  * Same argument conventions (gen_period and variant included: pass the SAME values to all
  * calls of one evaluation) and padding rules as gf_loglike_fused; dbar and rbar must be
- * readable two rows past the end.  Width 1..63, phases |d t| < 1.6e6.
+ * readable two rows past the end.  Width 1..63, phases |d t| < 3e9.
  */
 int gf_chunk_sweep(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc, int block,
                    int gen_period, int variant,

@@ -312,6 +312,28 @@ def test_streaming_large_phases_fall_back(hip):
     assert info == 0 and abs(ll - ref) <= RTOL_LL * abs(ref), (ll, ref)
 
 
+def test_fused_kernels_take_large_phases(hip):
+    """Time axes far from zero (phases d t up to ~1e9 rad, e.g. mission days or a 1e6-point series at one
+    minute cadence): the in-kernel sincos reduces its argument with FMA over |x| < 3e9, so the fused
+    sweeps -- streamed, time-parallel, and the wide kernel -- keep running and still match the oracle
+    (both form theta = d t as ONE rounded product)."""
+    from gadfly_amd.engine import StreamingBatch
+    from oracle import cref
+    for J, off in ((20, 4.0e4), (30, 9.0e4), (40, 4.0e4)):
+        prob = util.solar_problem(J, 1500)
+        t = prob["t"] + off
+        co = prob["kernel"].get_device_coefficients()
+        eng = StreamingBatch([co], t, prob["y"], diag=prob["diag_user"], tile_rows=512)
+        eng.generator_period = 1
+        assert 1.6e6 < eng._pack[6] * eng._tmax < 3e9
+        assert eng._fused_ok() or eng._wide_ok()
+        ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], prob["y"])
+        ll = float(eng.log_likelihood()[0])
+        assert info == 0 and abs(ll - ref) <= RTOL_LL * abs(ref), (J, ll, ref)
+        ll_tp = float(eng.log_likelihood_time_parallel(chunk_len=256)[0])
+        assert abs(ll_tp - ref) <= RTOL_LL * abs(ref), (J, ll_tp, ref)
+
+
 def test_streaming_irregular_cadence_fused(hip):
     """Irregular sampling: the fused kernel re-evaluates its cached exp(-c dt) on every row."""
     from gadfly_amd.engine import StreamingBatch
