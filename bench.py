@@ -410,7 +410,8 @@ def main():
             timed = range(args.warmup, nsteps + extra)
             worst = np.unravel_index(np.argmin(dmin[args.warmup:]), dmin[args.warmup:].shape)
             picks = [(args.warmup + int(worst[0]), int(worst[1]))]
-            ng = max(args.gate, 1)
+            # (at least one evaluation per host thread, so that the gate doubles as the all-cores baseline)
+            ng = max(args.gate, threads, 1)
             for i in range(ng - 1):
                 s = list(timed)[i % len(timed)]
                 e = (i * 977 + 1) % E
