@@ -1119,6 +1119,8 @@ class StreamingBatch:
             Hd = (Hc * dinv).transpose(1, 2)            # (nch, W, L)
             G = torch.bmm(Hd, Hc)
             mm = torch.bmm(Hd, zbar[:NP].view(nch, L, 1)).squeeze(-1)
+            # (replaying this scan from a captured HIP graph would cut its launch overhead, but hipSOLVER's
+            # batched LU invalidates stream capture here: tried, refused)
             Xs, Ys = _lft_tree_scan(torch, Ph, 0.5 * (G + G.transpose(1, 2)),
                                     0.5 * (Xb + Xb.transpose(1, 2)), Yb, mm)
             S.zero_()
