@@ -2868,15 +2868,16 @@ k_lincombine(const int nch, const int /*W*/, const int mode, const int R,
 // rescans its segment from its true start state, writing the start state of every chunk.
 constexpr int LCM_WAVES = 16, LCM_BATCH = 8;
 __global__ void __launch_bounds__(64 * LCM_WAVES)
-k_lincombine_mm(const int nch, const int R, const double *__restrict__ Dch_, double *__restrict__ F_state) {
+k_lincombine_mm(const int nch, const int R, const int rows, const double *__restrict__ Dch_,
+                double *__restrict__ F_state) {
     const int pr = blockIdx.x, i = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = (lane < R) ? lane : (R - 1);      // idle lanes shadow the last right-hand side (no stores)
     const bool rok = lane < R;
     const int seg = (nch + LCM_WAVES - 1) / LCM_WAVES;
     const int s0 = w * seg, s1 = (s0 + seg < nch) ? (s0 + seg) : nch;
     __shared__ double s_end[LCM_WAVES][64], s_dec[LCM_WAVES][64];
-    auto F_at = [&](int s) { return F_state + ((size_t)pr * nch + s) * 64 * R + (size_t)i * R + r; };
-    auto D_at = [&](int s) { return Dch_[((size_t)pr * nch + s) * 64 + i]; };
+    auto F_at = [&](int s) { return F_state + ((size_t)pr * nch + s) * rows * R + (size_t)i * R + r; };
+    auto D_at = [&](int s) { return Dch_[((size_t)pr * nch + s) * rows + i]; };
     // phase 1: segment end state from a zero start, and the segment's total decay
     double cur = 0.0, dec = 1.0;
     for (int s = s0; s < s1; s += LCM_BATCH) {
@@ -3012,16 +3013,25 @@ struct SolveArgs {
     int W, ld, R, mode;
     const double *U, *Wm, *P, *scale, *Y;
     double *Z;
+    // chunk mode of k_solve_vec (gf_solve_chunk): the grid is (problem, chunk); chunk c sweeps its rows
+    // from the state in F_state slot (problem * nch + c) -- [ld] doubles, pending push folded, the decay
+    // of the boundary left to the receiving chunk -- and leaves its end state there; store = 0: no Z
+    int64_t chunk_len;
+    int nch, store;
+    double *F_state;
 };
 
 // MODE and SCALED are compile-time (the three sweeps x with / without the per-row scale): no
 // branches on the chain.  CT = 3 covers the full solar kernel (W = 172, ld = 176).
 template <int CT, int MODE, bool SCALED>
 __global__ void __launch_bounds__(64) k_solve_vec(const SolveArgs A) {
-    const int lane = threadIdx.x, b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x / A.nch, ch = blockIdx.x - b * A.nch;     // (problem, chunk); nch = 1: whole series
     const int64_t N = A.N;
     const int ld = A.ld;
     const size_t pb = (size_t)b * N;
+    const int64_t c0 = (int64_t)ch * A.chunk_len;
+    const int64_t L = (N - c0 < A.chunk_len) ? (N - c0) : A.chunk_len;         // rows of this chunk
     constexpr bool up = (MODE == GF_SOLVE_UPPER);
     constexpr bool mm = (MODE == GF_MATMUL_LOWER);
     // "push" rows multiply the carried value into F; "pull" rows are dotted with F
@@ -3043,38 +3053,39 @@ __global__ void __launch_bounds__(64) k_solve_vec(const SolveArgs A) {
     const int vz = __builtin_amdgcn_mbcnt_lo(0u, 0u);      // 0 in every lane, not known to be uniform
     int col[CT];
     double okf[CT], F[CT];
+    double *__restrict__ Fs = A.F_state ? A.F_state + (size_t)blockIdx.x * ld : nullptr;
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const int j = c * 64 + lane;
         col[c] = j < ld ? j : ld - 1;
         okf[c] = j < ld ? 1.0 : 0.0;
-        F[c] = 0.0;
+        F[c] = Fs ? Fs[col[c]] * okf[c] : 0.0;
     }
-    auto row_of = [&](const int64_t s) { return up ? (N - 1 - s) : s; };
+    auto row_of = [&](const int64_t s) { return up ? (c0 + L - 1 - s) : (c0 + s); };
     auto scaled = [&](const double yv, const double sv) {
         if constexpr (SCALED) return mm ? yv * sqrt(sv) : yv / sv;
         else return yv;
     };
 
-    // row 0 of the sweep: nothing carried yet
-    double carry;
-    {
-        const int64_t n = row_of(0);
-        const double yn = scaled(Y[n], SCALED ? sc[n] : 1.0);
-        if (lane == 0) Z[n] = yn;
-        carry = yn;
-    }
+    // the first row of the sweep carries nothing itself (carry = 0): the state handed over already holds
+    // the pending push of the row before it (F = 0 at the very start).  The decay of a chunk boundary is
+    // applied by the chunk that OWNS the boundary row -- its first row: ascending sweeps apply it on entry
+    // (the first processed row), the descending sweep on exit, so that the homogeneous part of a chunk is
+    // exactly its closed-loop transition Phi_c (Phi_c^T going down), as in k_lin1.
+    double carry = 0.0;
     double rp[DEPTH][CT], ra[DEPTH][CT], rb[DEPTH][CT], ry[DEPTH], rs[DEPTH];
+    auto clampN = [&](const int64_t n) { return n < 0 ? (int64_t)0 : (n > N - 1 ? N - 1 : n); };
     auto fetch = [&](const int slot, int64_t s) {
-        s = s < N ? s : N - 1;                      // past the end: re-read the last row, never used
+        s = s < L ? s : L - 1;                      // past the end: re-read the last row, never used
         const int64_t n = row_of(s);
-        const int64_t prev = up ? (n + 1) : (n - 1);
-        const int64_t prow = up ? (n + 1) : n;
+        const int64_t prev = clampN(up ? (n + 1) : (n - 1));    // (rows outside the series: multiplied by 0)
+        const int64_t prow = clampN(up ? (n + 1) : n);
         ry[slot] = Y[n + vz];
         rs[slot] = SCALED ? sc[n + vz] : 1.0;
+        const bool entry = up && Fs != nullptr && s == 0;      // descending chunk entry: no decay here
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-            rp[slot][c] = Pg[(size_t)prow * ld + col[c]];
+            rp[slot][c] = entry ? 1.0 : Pg[(size_t)prow * ld + col[c]];
             ra[slot][c] = push[(size_t)prev * ld + col[c]];
             rb[slot][c] = pull[(size_t)n * ld + col[c]];
         }
@@ -3091,14 +3102,14 @@ __global__ void __launch_bounds__(64) k_solve_vec(const SolveArgs A) {
         }
         dot = wave_sum(dot);
         const double zn = mm ? (yn + dot) : (yn - dot);
-        if (lane == 0) Z[n] = zn;
+        if (A.store && lane == 0) Z[n] = zn;
         carry = mm ? yn : zn;
     };
-    int64_t s0 = 1;
-    if (N - 1 >= DEPTH) {
+    int64_t s0 = 0;
+    if (L >= DEPTH) {
 #pragma unroll
-        for (int k = 0; k < DEPTH; ++k) fetch(k, 1 + k);
-        for (; s0 + DEPTH <= N; s0 += DEPTH) {
+        for (int k = 0; k < DEPTH; ++k) fetch(k, k);
+        for (; s0 + DEPTH <= L; s0 += DEPTH) {
 #pragma unroll
             for (int k = 0; k < DEPTH; ++k) {
                 process(s0 + k, rp[k], ra[k], rb[k], ry[k], rs[k]);
@@ -3106,9 +3117,19 @@ __global__ void __launch_bounds__(64) k_solve_vec(const SolveArgs A) {
             }
         }
     }
-    for (; s0 < N; ++s0) {                          // fewer than DEPTH rows left
+    for (; s0 < L; ++s0) {                          // fewer than DEPTH rows left
         fetch(0, s0);
         process(s0, rp[0], ra[0], rb[0], ry[0], rs[0]);
+    }
+    if (Fs) {                                       // end state: pending push folded, no decay
+        const int64_t last = row_of(L - 1);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const double a = push[(size_t)last * ld + col[c]];
+            double v = fma(a, carry, F[c]);
+            if (up) v *= Pg[(size_t)last * ld + col[c]];       // cross the chunk's first-row boundary
+            if (c * 64 + lane < ld) Fs[c * 64 + lane] = v;
+        }
     }
 }
 
@@ -4552,7 +4573,7 @@ int gf_chunk_linear_combine(int mode, int B, int64_t N, int64_t chunk_len, int n
     hipStream_t st = (hipStream_t)stream;
     if (mode == GF_MATMUL_LOWER) {
         hipLaunchKernelGGL(k_chunk_decay, dim3(B * nch), dim3(64), 0, st, N, chunk_len, nch, W, c, de, D_work);
-        hipLaunchKernelGGL(k_lincombine_mm, dim3(B, 64), dim3(64 * LCM_WAVES), 0, st, nch, R, D_work, F_state);
+        hipLaunchKernelGGL(k_lincombine_mm, dim3(B, 64), dim3(64 * LCM_WAVES), 0, st, nch, R, 64, D_work, F_state);
         return check_launch("gf_chunk_linear_combine");
     }
     hipLaunchKernelGGL(k_lincombine, dim3(B, R), dim3(256), 0, st, nch, W, mode, R, Phi, D_work, F_state);
@@ -4579,6 +4600,57 @@ int gf_loglike_finish(int B, int64_t N, const double *acc, const int32_t *info,
     return check_launch("gf_loglike_finish");
 }
 
+// one-right-hand-side sweeps: `grid` single-wave workgroups (problems x chunks)
+static void launch_solve_vec(const SolveArgs &A, int grid, hipStream_t st) {
+    const int mode = A.mode;
+#define GF_SV(CT, M, S) hipLaunchKernelGGL((k_solve_vec<CT, M, S>), dim3(grid), dim3(64), 0, st, A)
+#define GF_SV_MODE(CT) do { const bool sd = A.scale != nullptr; \
+        if (mode == GF_SOLVE_LOWER) { if (sd) GF_SV(CT, GF_SOLVE_LOWER, true); else GF_SV(CT, GF_SOLVE_LOWER, false); } \
+        else if (mode == GF_SOLVE_UPPER) { if (sd) GF_SV(CT, GF_SOLVE_UPPER, true); else GF_SV(CT, GF_SOLVE_UPPER, false); } \
+        else { if (sd) GF_SV(CT, GF_MATMUL_LOWER, true); else GF_SV(CT, GF_MATMUL_LOWER, false); } } while (0)
+    if (A.ld <= 64)       GF_SV_MODE(1);
+    else if (A.ld <= 128) GF_SV_MODE(2);
+    else if (A.ld <= 192) GF_SV_MODE(3);
+    else                  GF_SV_MODE(4);
+#undef GF_SV_MODE
+#undef GF_SV
+}
+
+// Chunk-parallel form of the one-right-hand-side sweeps of gf_solve (any width; what the wide stored
+// factor uses): local pass (F_state zeroed by the caller, store = 0) -> combine of the chunk states on the
+// caller's side (GF_MATMUL_LOWER: diagonal decays, gf_chunk_diag_scan; the solves: the chunks' closed-loop
+// transitions) -> final pass from the true start states (store = 1).  F_state: [B * nch][ld].
+int gf_solve_chunk(int mode, int B, int64_t N, int64_t chunk_len, int nch, int W, int ld,
+                   const double *U, const double *Wm, const double *P, const double *scale,
+                   const double *Y, double *Z, double *F_state, int store, void *stream) {
+    if (mode < 0 || mode > 2) return set_err("gf_solve_chunk: bad mode %s%lld", "", mode);
+    if (B < 1 || N < 1) return set_err("gf_solve_chunk: empty problem (N=%s%lld)", "", N);
+    if (W < 1 || W > GF_MAX_WIDTH) return set_err("gf_solve_chunk: width %s%lld unsupported (max %lld)", "", W, GF_MAX_WIDTH);
+    if (ld < W || (ld & 15)) return set_err("gf_solve_chunk: ld=%s%lld must be a multiple of 16 and >= W=%lld", "", ld, W);
+    if (nch < 1 || chunk_len < 1 || (int64_t)nch * chunk_len < N || (int64_t)(nch - 1) * chunk_len >= N)
+        return set_err("gf_solve_chunk: bad chunking (chunk_len=%s%lld, nch=%lld)", "", chunk_len, nch);
+    if (!U || !Wm || !P || !Y || !Z || !F_state) return set_err("gf_solve_chunk: null pointer%s", "");
+    if ((int64_t)B * nch > 0x7fffffffLL) return set_err("gf_solve_chunk: problem too large%s", "");
+    SolveArgs A;
+    A.N = N; A.W = W; A.ld = ld; A.R = 1; A.mode = mode;
+    A.U = U; A.Wm = Wm; A.P = P; A.scale = scale; A.Y = Y; A.Z = Z;
+    A.chunk_len = chunk_len; A.nch = nch; A.store = store; A.F_state = F_state;
+    launch_solve_vec(A, B * nch, (hipStream_t)stream);
+    return check_launch("gf_solve_chunk");
+}
+
+// Scan of chunk states with DIAGONAL transitions: F_state slot c [rows][R] <- true start state of chunk c
+// from the local end states, F_{c+1} = loc_c + D_c o F_c (D [B * nch][rows]); gf_chunk_linear_combine's
+// GF_MATMUL_LOWER branch for any number of state rows.
+int gf_chunk_diag_scan(int B, int nch, int rows, int R, const double *D, double *F_state, void *stream) {
+    if (B < 1 || nch < 1 || rows < 1 || R < 1 || R > 64)
+        return set_err("gf_chunk_diag_scan: bad shape (rows=%s%lld, R=%lld)", "", rows, R);
+    if (!D || !F_state) return set_err("gf_chunk_diag_scan: null pointer%s", "");
+    hipLaunchKernelGGL(k_lincombine_mm, dim3(B, rows), dim3(64 * LCM_WAVES), 0, (hipStream_t)stream,
+                       nch, R, rows, D, F_state);
+    return check_launch("gf_chunk_diag_scan");
+}
+
 int gf_solve(int mode, int B, int64_t N, int W, int ld, int R,
              const double *U, const double *Wm, const double *P, const double *scale,
              const double *Y, double *Z, void *stream) {
@@ -4591,19 +4663,10 @@ int gf_solve(int mode, int B, int64_t N, int W, int ld, int R,
     SolveArgs A;
     A.N = N; A.W = W; A.ld = ld; A.R = R; A.mode = mode;
     A.U = U; A.Wm = Wm; A.P = P; A.scale = scale; A.Y = Y; A.Z = Z;
+    A.chunk_len = N; A.nch = 1; A.store = 1; A.F_state = nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (R == 1) {
-#define GF_SV(CT, M, S) hipLaunchKernelGGL((k_solve_vec<CT, M, S>), dim3(B), dim3(64), 0, st, A)
-#define GF_SV_MODE(CT) do { const bool sd = scale != nullptr; \
-        if (mode == GF_SOLVE_LOWER) { if (sd) GF_SV(CT, GF_SOLVE_LOWER, true); else GF_SV(CT, GF_SOLVE_LOWER, false); } \
-        else if (mode == GF_SOLVE_UPPER) { if (sd) GF_SV(CT, GF_SOLVE_UPPER, true); else GF_SV(CT, GF_SOLVE_UPPER, false); } \
-        else { if (sd) GF_SV(CT, GF_MATMUL_LOWER, true); else GF_SV(CT, GF_MATMUL_LOWER, false); } } while (0)
-        if (ld <= 64)       GF_SV_MODE(1);
-        else if (ld <= 128) GF_SV_MODE(2);
-        else if (ld <= 192) GF_SV_MODE(3);
-        else                GF_SV_MODE(4);
-#undef GF_SV_MODE
-#undef GF_SV
+        launch_solve_vec(A, B, st);
     } else {
         const dim3 grid((R + 63) / 64, B);
         if (ld <= 16)       hipLaunchKernelGGL((k_solve_rhs<16, 1>), grid, dim3(64), 0, st, A);

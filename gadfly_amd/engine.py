@@ -520,10 +520,13 @@ class WideFactor:
         self.info = torch.zeros((B,), dtype=torch.int32, device=self.device)
         st = torch.cuda.current_stream(self.device).cuda_stream
         self.time_parallel = owner._wide_tp_ok() if time_parallel is None else bool(time_parallel)
+        self.chunk_len, self.nch = N, 1
+        self._tp_bufs = None
         if self.time_parallel:
             # exact time-parallel factorisation: chunks swept concurrently, stitched by the LFT combine
-            owner._tp_run_wide(chunk_len, stores=(self.Ut, self.Wt, self.de), d=self.d, z=self.z,
-                               info=self.info)
+            _, _, self.chunk_len, self.nch = owner._tp_run_wide(
+                chunk_len, stores=(self.Ut, self.Wt, self.de), d=self.d, z=self.z, info=self.info)
+            self._tp_bufs = owner._wide_tp_bufs          # r rows of the TRUE factor, h / Phi scratch
         else:
             S = torch.zeros((B, int(lib.gf_fused_state_size(owner.Jr, owner.Jc))), **f64)
             bs = owner._bs
@@ -539,6 +542,7 @@ class WideFactor:
         rc = lib.gf_scaled_propagator(B, N, self.W, self.ld, p(c), p(self.de), p(self.P), st)
         _lib.check(rc, "gf_scaled_propagator")
         self._v1 = None
+        self._Phi = None
 
     def reduce(self, with_quad):
         """(loglike (B,), logdet (B,)) of the pass that built the factor (z = L^-1 of the owner's y)."""
@@ -556,6 +560,64 @@ class WideFactor:
                    "gf_loglike_finish")
         return out, logdet
 
+    def _true_transitions(self):
+        """Closed-loop transitions Phi_c of the TRUE factor's chunks (k_phiw on the rows the final pass
+        stored), computed on first use: what the chunk-parallel solves chain their states with."""
+        if self._Phi is None:
+            torch, lib, p = self.torch, self.lib, _lib.ptr
+            w = self._tp_bufs
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            rc = lib.gf_chunk_transition_wide(1, self.N, self.chunk_len, self.nch, self.owner.Jc, p(self.c),
+                                              p(self.de), p(self.d), p(w["r"]), p(self.Ut), p(w["h"]),
+                                              p(w["Phi"]), st)
+            _lib.check(rc, "gf_chunk_transition_wide")
+            nS = w["Phi"].shape[1]
+            P3 = w["Phi"].view(self.nch, self.ld, nS // self.ld)
+            self._Phi = P3[:, :self.W, :self.W].transpose(1, 2).contiguous()      # Phi_c(i, j)
+            self._tp_bufs = None                        # the row scratch is no longer needed
+        return self._Phi
+
+    def _mm_chunking(self):
+        chunk_len = max(128, -(-self.N // 2048))
+        chunk_len = (chunk_len + 63) // 64 * 64
+        return chunk_len, -(-self.N // chunk_len)
+
+    def _sweep_chunked(self, mode, Y, scale, Z):
+        """ONE right-hand side, chunk-parallel (gf_solve_chunk): local pass, combine of the chunk states,
+        final pass.  dot_tril's transitions are diagonal (any chunking, scanned on the device); the
+        solves chain the chunks' closed-loop transitions (W x W mat-vecs, sequential over the chunks)."""
+        torch, lib, p = self.torch, self.lib, _lib.ptr
+        N, W, ld = self.N, self.W, self.ld
+        f64 = dict(dtype=torch.float64, device=self.device)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        mm = mode == _lib.GF_MATMUL_LOWER
+        L, nch = self._mm_chunking() if mm else (self.chunk_len, self.nch)
+        F = torch.zeros((nch, ld), **f64)
+        rows = (p(self.Ut), p(self.Wt), p(self.P), p(scale), p(Y), p(Z))
+        _lib.check(lib.gf_solve_chunk(mode, 1, N, L, nch, W, ld, *rows, p(F), 0, st), "gf_solve_chunk")
+        if mm:
+            span = torch.zeros((nch * L,), **f64)
+            span[:N] = self.de.reshape(-1).clamp(min=0.0)           # reset spans inside each chunk
+            D = torch.ones((nch, ld), **f64)
+            D[:, :W] = torch.exp(-span.view(nch, L).sum(dim=1)[:, None] * self.c.reshape(1, W))
+            _lib.check(lib.gf_chunk_diag_scan(1, nch, ld, 1, p(D), p(F), st), "gf_chunk_diag_scan")
+        else:
+            Phi = self._true_transitions()
+            loc = F[:, :W].clone()
+            cur = torch.zeros((W,), **f64)
+            if mode == _lib.GF_SOLVE_LOWER:
+                for c in range(nch):
+                    F[c, :W] = cur
+                    if c + 1 < nch:
+                        cur = torch.addmv(loc[c], Phi[c], cur)
+            else:
+                for c in range(nch - 1, -1, -1):
+                    F[c, :W] = cur
+                    if c > 0:
+                        cur = torch.addmv(loc[c], Phi[c].T, cur)
+        _lib.check(lib.gf_solve_chunk(mode, 1, N, L, nch, W, ld, *rows, p(F), 1, st), "gf_solve_chunk")
+        return Z
+
     @_on_device
     def _sweep(self, mode, Y, scale=None, out=None):
         torch = self.torch
@@ -564,6 +626,8 @@ class WideFactor:
         Z = out if out is not None else torch.empty_like(Y)
         p = _lib.ptr
         st = torch.cuda.current_stream(self.device).cuda_stream
+        if R == 1 and B == 1 and self.time_parallel and self.nch > 1:
+            return self._sweep_chunked(mode, Y, scale, Z)
         rc = self.lib.gf_solve(mode, B, N, self.W, self.ld, R, p(self.Ut), p(self.Wt), p(self.P),
                                p(scale), p(Y), p(Z), st)
         _lib.check(rc, "gf_solve")
@@ -1130,7 +1194,10 @@ class StreamingBatch:
         # 4. final pass from the true start states
         dd = d.reshape(-1) if d is not None else rows_buf()
         zz = z.reshape(-1) if z is not None else rows_buf()
-        sweep(dd, zz, None, (p(Ut), p(Wt), p(de)) if stores is not None else (None, None, None))
+        keep = stores is not None and nch > 1
+        sweep(dd, zz, p(rbar) if keep else None,     # (the TRUE factor's r rows replace the nominal ones)
+              (p(Ut), p(Wt), p(de)) if stores is not None else (None, None, None))
+        self._wide_tp_bufs = dict(r=rbar, h=h, Phi=Phi) if keep else None
         big = torch.iinfo(torch.int32).max
         first = torch.where(cinfo != 0, cinfo, torch.full_like(cinfo, big)).min()
         flag = torch.where(first == big, torch.zeros_like(first), first).reshape(1)

@@ -296,6 +296,23 @@ int gf_solve(int mode, int B, int64_t N, int W, int ld, int R,
              const double *Y, double *Z, void *stream);
 
 /*
+ * Chunk-parallel form of gf_solve for ONE right-hand side (any width; the wide stored factor's sweeps):
+ *   gf_solve_chunk(store=0)  local pass: chunk c of nch sweeps its rows from F_state slot
+ *                            (b * nch + c) [ld] (zeroed by the caller) and leaves its end state
+ *                            there (pending push folded, the boundary's decay left to the receiver);
+ *   combine                  on the caller's side: GF_MATMUL_LOWER has diagonal transitions
+ *                            D_c = product of the chunk's propagator rows -> gf_chunk_diag_scan; the
+ *                            solves chain F_{c+1} = loc_c + Phi_c F_c (G_{c-1} = loc_c + Phi_c^T G_c)
+ *                            with the chunk transitions of the TRUE factor (gf_chunk_transition[_wide]);
+ *   gf_solve_chunk(store=1)  final pass from the true start states: Z rows.
+ * Y, Z [B][N] (Z may alias Y for the solves); scale as in gf_solve.
+ */
+int gf_solve_chunk(int mode, int B, int64_t N, int64_t chunk_len, int nch, int W, int ld,
+                   const double *U, const double *Wm, const double *P, const double *scale,
+                   const double *Y, double *Z, double *F_state, int store, void *stream);
+int gf_chunk_diag_scan(int B, int nch, int rows, int R, const double *D, double *F_state, void *stream);
+
+/*
  * Cross-covariance block for the conditional variance / covariance (celerite2's
  * ConditionalDistribution.variance builds it densely on the host; gp.py:295-304 is gadfly's use):
  *   out[b][n][r] = k(|t[n] - ts[r]|) from the celerite coefficients, layout [B][N][R] = the

@@ -253,6 +253,17 @@ def test_wide_time_parallel(hip, J, N, L, kw):
     ref_ai = cref.solve_upper(t, c, U, W_ref, cref.solve_lower(t, c, U, W_ref, Y) / d_ref[:, None])
     got = fac.apply_inverse(torch.as_tensor(Y).cuda().reshape(1, n, 2))[0].cpu().numpy()
     assert _relmax(got, ref_ai) < TOL_VEC
+    # ONE right-hand side takes the chunk-parallel sweeps (gf_solve_chunk): local pass, combine through the
+    # TRUE factor's chunk transitions (the solves) / the diagonal decays (dot_tril), final pass
+    assert fac.nch > 1
+    y1 = torch.as_tensor(Y[:, 0].copy()).cuda().reshape(1, n, 1)
+    zl = cref.solve_lower(t, c, U, W_ref, Y[:, 0])
+    assert _relmax(fac.solve_lower(y1)[0, :, 0].cpu().numpy(), zl) < TOL_VEC
+    assert _relmax(fac.solve_upper(y1)[0, :, 0].cpu().numpy(), cref.solve_upper(t, c, U, W_ref, Y[:, 0])) < TOL_VEC
+    assert _relmax(fac.apply_inverse(y1)[0, :, 0].cpu().numpy(), ref_ai[:, 0]) < TOL_VEC
+    ref_dt = cref.matmul_lower(t, c, U, W_ref, Y[:, 0] * np.sqrt(d_ref))
+    assert _relmax(fac.dot_tril(y1)[0, :, 0].cpu().numpy(), ref_dt) < TOL_VEC
+    assert fac._Phi is not None and fac._tp_bufs is None
     # failing matrix: the first non-positive pivot, although later chunks fail as well
     bad = prob["diag_user"].copy()
     bad[n // 2:] = -2.0 * k.get_value(np.zeros(1))[0]
