@@ -462,13 +462,34 @@ class GaussianProcess:
             return self._ppm_to_flux(result)
         return result
 
-    def sample_device(self, *, size=None, include_mean=True):
+    def sample_device(self, *, size=None, include_mean=True, rng="numpy", seed=None):
         """:meth:`sample` with the draws left on the GPU: a float64 tensor of shape (N,) or
-        (size, N) [ppm], same normal vectors (numpy's legacy global RNG), same arithmetic and
-        mean-subtraction quirk -- for pipelines that continue on the device
-        (:meth:`gadfly_amd.PowerSpectrum.from_flux`).  Extension; not in the reference."""
+        (size, N) [ppm], same arithmetic and mean-subtraction quirk -- for pipelines that continue on
+        the device (:meth:`gadfly_amd.PowerSpectrum.from_flux`).  Extension; not in the reference.
+
+        ``rng="numpy"`` (default) draws the normal vectors from numpy's legacy global RNG exactly as
+        :meth:`sample` / celerite2 do (same draws for a given ``np.random.seed``), which costs a host
+        ``randn`` and a PCIe copy (~0.4 s for 64 x 5e5).  ``rng="device"`` draws them on the GPU
+        (``torch.randn``, optional ``seed``): statistically equivalent draws in milliseconds, but NOT the
+        reference's random stream."""
         if self._t is None:
             raise RuntimeError("The process must be initialized with compute")
+        if rng == "device":
+            import torch
+            dev = self._device_of()
+            gen = None
+            if seed is not None:
+                gen = torch.Generator(device=dev)
+                gen.manual_seed(int(seed))
+            shape = (self._size,) if size is None else (self._size, int(size))
+            nd = torch.randn(shape, dtype=torch.float64, device=dev, generator=gen)
+            Z = self._engine.dot_tril(nd.reshape(1, self._size, -1))
+            result = Z.reshape(shape).T.contiguous() if len(shape) == 2 else Z.reshape(-1)
+            if include_mean:
+                result = result + self._to_device(np.broadcast_to(self._mean_value, (self._size,)).copy())
+            return result - (result.mean(dim=0) if result.ndim == 2 else result.mean())
+        if rng != "numpy":
+            raise ValueError("rng must be 'numpy' or 'device'")
         n = np.random.randn(self._size) if size is None else np.random.randn(self._size, size)
         Z = self._engine.dot_tril(self._to_device(n).reshape(1, self._size, -1))
         result = Z.reshape(n.shape).T.contiguous() if n.ndim == 2 else Z.reshape(-1)

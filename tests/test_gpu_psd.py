@@ -130,3 +130,33 @@ def test_round_trip_on_device(hip, n_trials=4, nbins=15):
     for r in range(n_trials):
         dev = np.abs((model[ok] - ps.power[r][ok]) / np.nanmax(ps.error[r]))
         assert np.nanmax(dev) < 5
+
+
+def test_sample_device_with_device_rng(hip):
+    """``sample_device(rng="device")``: normal vectors drawn on the GPU (an opt-in extension: not the
+    reference's random stream).  Reproducible for a seed, unit-variance inputs (the draws' sample variance
+    matches the kernel's variance), and the default path still reproduces numpy's legacy stream."""
+    import torch
+    import gadfly_amd
+    from gadfly_amd.synth import solar_like_hyperparameters, uniform_times
+    k = gadfly_amd.StellarOscillatorKernel(solar_like_hyperparameters(6), texp=60.0)
+    N = 20000
+    gp = gadfly_amd.GaussianProcess(k, t=uniform_times(N, 60.0))
+    a = gp.sample_device(size=16, rng="device", seed=7)
+    b = gp.sample_device(size=16, rng="device", seed=7)
+    c = gp.sample_device(size=16, rng="device", seed=8)
+    assert a.is_cuda and a.shape == (16, N) and torch.equal(a, b) and not torch.equal(a, c)
+    # variance ACROSS the 16 realisations at a fixed time (averaged over the times) = the kernel's variance
+    # (a draw's own sample variance over a finite window is smaller: the granulation terms are red)
+    var = float(a.var(dim=0).mean())
+    k0 = float(k.get_value(np.zeros(1))[0])
+    assert 0.8 * k0 < var < 1.2 * k0, (var, k0)
+    one = gp.sample_device(rng="device", seed=1)
+    assert one.shape == (N,) and abs(float(one.mean())) < 1e-9 * (1 + float(one.abs().max()))
+    np.random.seed(3)
+    ref = gp.sample(size=2)
+    np.random.seed(3)
+    dev = gp.sample_device(size=2).cpu().numpy()
+    assert np.max(np.abs(dev - ref)) <= 1e-12 * np.max(np.abs(ref))
+    with pytest.raises(ValueError):
+        gp.sample_device(rng="philox")
