@@ -145,6 +145,8 @@ class BatchedLogLikelihood:
         if period > 1 and (eng._fused_ok() or eng._wide_ok()):
             torch = eng.torch
             acc = eng._tp["acc"] if getattr(eng, "_tp_used", False) else eng.acc
+            if getattr(eng, "_last_wide_tp", False):
+                acc = eng._wide_tp["acc"]
             amax = eng._pack[2] if eng.diag is None else eng._pack[2] + eng._diag_amax
             # a non-positive pivot (failed factorisation: -inf either way) is not an accuracy case
             flag = (eng.GEN_ERR * period * amax > self.generator_target * acc[:, 2]) & (acc[:, 2] > 0)

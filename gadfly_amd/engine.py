@@ -813,6 +813,8 @@ class StreamingBatch:
         """max(a) / min(d) over all problems of the LAST evaluation (synchronises): the factor by
         which rounding in the generator rows shows up in the log-likelihood."""
         acc = self._tp["acc"] if getattr(self, "_tp_used", False) else self.acc
+        if getattr(self, "_last_wide_tp", False):
+            acc = self._wide_tp["acc"]
         dmin = float(acc[:, 2].min().item())
         amax = float(self._pack[2].max().item())
         if self.diag is not None:
@@ -1258,11 +1260,20 @@ class StreamingBatch:
             # ~1/8 of the 2048 wave slots (``force_streaming``: benchmarks of the streamed sweep)
             time_parallel = (self._fused_ok() and self.B <= 256 and self.N >= 8192
                              and not getattr(self, "force_streaming", False))
+        wide_tp = (self._wide_tp_ok() and not self._fused_ok()
+                   and (time_parallel or (time_parallel is None
+                                          and not getattr(self, "force_streaming", False))))
         if time_parallel and self._fused_ok():
             out = self.log_likelihood_time_parallel()
             acc = self._tp["acc"] if getattr(self, "_tp_key", None) and self._tp_used else self.acc
+        elif wide_tp:               # ONE long series with a wide kernel: exact time-parallel evaluation
+            self._tp_used = False
+            out = self._tp_run_wide()[0]
+            acc = self._wide_tp["acc"]
+            self._last_wide_tp = True
         else:
             self._tp_used = False
+            self._last_wide_tp = False
             out = self.log_likelihood()
             acc = self.acc
         torch = self.torch

@@ -207,6 +207,16 @@ def test_gaussian_process_wide_kernel(hip, J, N, kw):
     _, _, Us, Vs = seq.celerite_matrices(co[:6], ts, 0.0)
     mu_ref = cref.general_matmul(ts, t, c, Us, Vs, U, V, alpha) + 0.5
     assert _relmax(gp.predict(y, t=ts), mu_ref) < TOL_VEC
+    # conditional variance at a few new times (multi-right-hand-side sweeps on the wide factor) against the
+    # dense formulation k(0) - K*^T K^-1 K*
+    if n <= 1600:
+        from oracle import dense
+        tv = ts[::8]
+        _, var = gp.predict(y, t=tv, return_var=True)
+        K = dense.dense_K(co[:6], t, prob["diag_user"] + co[6])
+        Ks = k.get_value(t[:, None] - tv[None, :])
+        var_ref = k.get_value(np.zeros(1))[0] - np.sum(Ks * np.linalg.solve(K, Ks), axis=0)
+        assert _relmax(var, var_ref) < 1e-5
     # a failing matrix is reported at its first non-positive pivot
     bad = prob["diag_user"].copy()
     bad[n // 2:] = -2.0 * k.get_value(np.zeros(1))[0]
