@@ -2783,24 +2783,38 @@ __global__ void __launch_bounds__(64, 2) k_linR7(const LinArgs A) {
 //   upper  : G_{c-1} = Gbar_c + Phi_c^T G_c          (descending)
 //   matmul : F_{c+1} = Fbar_c + D_c o F_c            (D = product of the chunk's reset decays)
 // One workgroup of 64 x RT threads per (problem, RHS tile); Phi is stored [j][i].
+//
+// Two-level form (PHASE 1 / 2; PHASE 0 is the plain scan over all chunks): the chunks are cut into
+// segments of seg_len whose composed transitions Psi_s = Phi_{e-1} ... Phi_b are part of the factor
+// (k_segment_transition, once per factor; the backward solve uses Psi_s^T).  PHASE 1 scans every
+// segment concurrently from a zero start and leaves its end state in Vseg; a PHASE 0 scan of
+// (Psi, Vseg) turns those into the segments' true start states; PHASE 2 rescans every segment from
+// there and writes the chunks' start states.  Sequential depth 2 seg_len + nch / seg_len chunks
+// instead of nch.
+template <int PHASE>
 __global__ void __launch_bounds__(256)
-k_lincombine(const int nch, const int /*W*/, const int mode, const int R,
+k_lincombine(const int nch, const int seg_len, const int mode, const int R,
              const double *__restrict__ Phi_, const double *__restrict__ Dch_,
-             double *__restrict__ F_state) {
+             double *__restrict__ F_state, double *__restrict__ Vseg) {
     // One workgroup of four waves per (problem, right-hand side): the scan is sequential over the
     // chunks only.  Lane i owns state row i; wave w multiplies columns 16w..16w+15 of the chunk's
     // 64 x 64 transition (rows of Phi^T for the backward solve), which it holds in registers and
     // fetches THREE chunks ahead (a ring of four 16-double buffers: the 32 KB per chunk come from
     // L2 with ~2 us latency, which a single buffer exposed on every step: 2.3 us per chunk, now
     // ~0.4); the four partial sums meet in LDS, one barrier per chunk.
-    const int pr = blockIdx.x, r = blockIdx.y, i = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = blockIdx.y, i = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool up = mode == GF_SOLVE_UPPER, mm = mode == GF_MATMUL_LOWER;
+    const int nseg = PHASE ? (nch + seg_len - 1) / seg_len : 1;
+    const int pr = blockIdx.x / nseg, sg = blockIdx.x - pr * nseg;
+    const int c_lo = PHASE ? sg * seg_len : 0;
+    const int c_hi = PHASE ? ((c_lo + seg_len < nch) ? c_lo + seg_len : nch) : nch;
+    const int len = c_hi - c_lo;
     __shared__ __attribute__((aligned(16))) double s_cur[64];
     __shared__ double s_part[2][4][64];
     double P[4][16];
-    auto chunk_of = [&](int s) { return up ? (nch - 1 - s) : s; };
+    auto chunk_of = [&](int s) { return up ? (c_hi - 1 - s) : (c_lo + s); };
     auto load_phi = [&](double (&buf)[16], int s) {
-        if (s >= nch) return;
+        if (s >= len) return;
         const double *Pg = Phi_ + ((size_t)pr * nch + chunk_of(s)) * 4096;
         if (!up) {
 #pragma unroll
@@ -2812,7 +2826,9 @@ k_lincombine(const int nch, const int /*W*/, const int mode, const int R,
         }
     };
     double cur = 0.0;                               // state row i (carried by wave 0)
-    if (mm) {                                       // diagonal transitions: one wave does it all
+    double *Vg = PHASE ? Vseg + ((size_t)pr * nseg + sg) * 64 * R + (size_t)i * R + r : nullptr;
+    if (PHASE == 2 && w == 0) cur = *Vg;
+    if (PHASE == 0 && mm) {                         // diagonal transitions: one wave does it all
         if (w != 0) return;
         for (int s = 0; s < nch; ++s) {
             const size_t slot = (size_t)pr * nch + s;
@@ -2824,13 +2840,13 @@ k_lincombine(const int nch, const int /*W*/, const int mode, const int R,
         return;
     }
     load_phi(P[0], 0); load_phi(P[1], 1); load_phi(P[2], 2);
-    if (threadIdx.x < 64) s_cur[i] = 0.0;
+    if (threadIdx.x < 64) s_cur[i] = cur;
     __syncthreads();
     auto step = [&](double (&buf)[16], double (&next)[16], int s) {
         const size_t slot = (size_t)pr * nch + chunk_of(s);
         double *Fg = F_state + slot * 64 * R + (size_t)i * R + r;
         double loc = 0.0;
-        if (w == 0) { loc = *Fg; *Fg = cur; }       // local end state in, true start state out
+        if (w == 0) { loc = *Fg; if (PHASE != 1) *Fg = cur; }   // local end state in, true start state out
         load_phi(next, s + 3);
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
@@ -2848,15 +2864,47 @@ k_lincombine(const int nch, const int /*W*/, const int mode, const int R,
         __syncthreads();
     };
     int s = 0;
-    for (; s + 4 <= nch; s += 4) {
+    for (; s + 4 <= len; s += 4) {
         step(P[0], P[3], s);
         step(P[1], P[0], s + 1);
         step(P[2], P[1], s + 2);
         step(P[3], P[2], s + 3);
     }
-    if (s < nch) step(P[0], P[3], s);
-    if (s + 1 < nch) step(P[1], P[0], s + 1);
-    if (s + 2 < nch) step(P[2], P[1], s + 2);
+    if (s < len) step(P[0], P[3], s);
+    if (s + 1 < len) step(P[1], P[0], s + 1);
+    if (s + 2 < len) step(P[2], P[1], s + 2);
+    if (PHASE == 1 && w == 0) *Vg = cur;            // the segment's end state from a zero start
+}
+
+// Composed transition of every segment of seg_len chunks:  Psi_s = Phi_{e-1} ... Phi_{b+1} Phi_b
+// (stored [j][i] like Phi).  One workgroup per segment: the running product lives in LDS (B operand
+// of the MFMA tiles), the next chunk's Phi is the A operand straight from global (lanes = rows of a
+// column: coalesced).
+__global__ void __launch_bounds__(256)
+k_segment_transition(const int nch, const int seg_len, const double *__restrict__ Phi_,
+                     double *__restrict__ Psi_) {
+    const int nseg = (nch + seg_len - 1) / seg_len;
+    const int pr = blockIdx.x / nseg, sg = blockIdx.x - pr * nseg;
+    const int c_lo = sg * seg_len, c_hi = (c_lo + seg_len < nch) ? c_lo + seg_len : nch;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    __shared__ __attribute__((aligned(16))) double Ps[64 * 64];     // row-major
+    {
+        const double *Pg = Phi_ + ((size_t)pr * nch + c_lo) * 4096;
+        for (int e = tid; e < 4096; e += 256) Ps[(e & 63) * 64 + (e >> 6)] = Pg[e];
+    }
+    __syncthreads();
+    for (int c = c_lo + 1; c < c_hi; ++c) {
+        const double *Pg = Phi_ + ((size_t)pr * nch + c) * 4096;
+        double acc[4][4];
+        cb_mm(acc,
+              [&](int row, int k) { return Pg[k * 64 + row]; },
+              [&](int k, int col) { return Ps[k * 64 + col]; }, tx, ty);
+        __syncthreads();
+        cb_store_lds(Ps, 64, acc, tx, ty);
+        __syncthreads();
+    }
+    double *Og = Psi_ + ((size_t)pr * nseg + sg) * 4096;
+    for (int e = tid; e < 4096; e += 256) Og[e] = Ps[(e & 63) * 64 + (e >> 6)];
 }
 
 // Combine of GF_MATMUL_LOWER (dot_tril): the chunk transitions are DIAGONAL (D_c), so the start states are
@@ -4576,8 +4624,34 @@ int gf_chunk_linear_combine(int mode, int B, int64_t N, int64_t chunk_len, int n
         hipLaunchKernelGGL(k_lincombine_mm, dim3(B, 64), dim3(64 * LCM_WAVES), 0, st, nch, R, 64, D_work, F_state);
         return check_launch("gf_chunk_linear_combine");
     }
-    hipLaunchKernelGGL(k_lincombine, dim3(B, R), dim3(256), 0, st, nch, W, mode, R, Phi, D_work, F_state);
+    hipLaunchKernelGGL(k_lincombine<0>, dim3(B, R), dim3(256), 0, st, nch, nch, mode, R, Phi, D_work, F_state,
+                       (double *)nullptr);
     return check_launch("gf_chunk_linear_combine");
+}
+
+int gf_chunk_segment_transitions(int B, int nch, int seg_len, const double *Phi, double *Psi_out, void *stream) {
+    if (B < 1 || nch < 1 || seg_len < 1) return set_err("gf_chunk_segment_transitions: empty problem%s", "");
+    if (!Phi || !Psi_out) return set_err("gf_chunk_segment_transitions: null pointer%s", "");
+    const int nseg = (nch + seg_len - 1) / seg_len;
+    hipLaunchKernelGGL(k_segment_transition, dim3(B * nseg), dim3(256), 0, (hipStream_t)stream, nch, seg_len, Phi, Psi_out);
+    return check_launch("gf_chunk_segment_transitions");
+}
+
+int gf_chunk_linear_combine_seg(int mode, int B, int nch, int seg_len, int R, const double *Phi,
+                                const double *Psi, double *F_state, double *V_work, void *stream) {
+    if (mode != GF_SOLVE_LOWER && mode != GF_SOLVE_UPPER)
+        return set_err("gf_chunk_linear_combine_seg: bad mode %s%lld (the solves only)", "", mode);
+    if (B < 1 || nch < 1 || R < 1 || seg_len < 1) return set_err("gf_chunk_linear_combine_seg: empty problem%s", "");
+    if (!Phi || !Psi || !F_state || !V_work) return set_err("gf_chunk_linear_combine_seg: null pointer%s", "");
+    const int nseg = (nch + seg_len - 1) / seg_len;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_lincombine<1>, dim3(B * nseg, R), dim3(256), 0, st, nch, seg_len, mode, R, Phi,
+                       (const double *)nullptr, F_state, V_work);
+    hipLaunchKernelGGL(k_lincombine<0>, dim3(B, R), dim3(256), 0, st, nseg, nseg, mode, R, Psi,
+                       (const double *)nullptr, V_work, (double *)nullptr);
+    hipLaunchKernelGGL(k_lincombine<2>, dim3(B * nseg, R), dim3(256), 0, st, nch, seg_len, mode, R, Phi,
+                       (const double *)nullptr, F_state, V_work);
+    return check_launch("gf_chunk_linear_combine_seg");
 }
 
 int64_t gf_reduce_work(int64_t N) { return RED_NACC * (int64_t)red_groups(N); }

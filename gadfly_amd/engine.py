@@ -417,6 +417,7 @@ class ScaledFactor:
         self.info = owner.info
         self._v1 = None
         self._D = None
+        self._Psi = None
 
     @_on_device
     def _sweep(self, mode, Y, scale):
@@ -444,14 +445,41 @@ class ScaledFactor:
             _lib.check(rc, "gf_chunk_linear")
             if mode == _lib.GF_MATMUL_LOWER and (self._D is None or self._D.shape[0] != B * nch):
                 self._D = torch.empty((B * nch, 64), **f64)
-            rc = lib.gf_chunk_linear_combine(
-                *args, p(self.c), p(self.de),
-                None if mode == _lib.GF_MATMUL_LOWER else p(self.Phi),
-                p(self._D) if mode == _lib.GF_MATMUL_LOWER else None, p(F), st)
-            _lib.check(rc, "gf_chunk_linear_combine")
+            seg = self._segments() if mode != _lib.GF_MATMUL_LOWER else None
+            if seg is not None:         # long series: two-level combine on the composed transitions
+                seg_len, Psi = seg
+                V = torch.empty((B * (-(-nch // seg_len)), 64 * R), **f64)
+                rc = lib.gf_chunk_linear_combine_seg(mode, B, nch, seg_len, R, p(self.Phi), p(Psi),
+                                                     p(F), p(V), st)
+                _lib.check(rc, "gf_chunk_linear_combine_seg")
+            else:
+                rc = lib.gf_chunk_linear_combine(
+                    *args, p(self.c), p(self.de),
+                    None if mode == _lib.GF_MATMUL_LOWER else p(self.Phi),
+                    p(self._D) if mode == _lib.GF_MATMUL_LOWER else None, p(F), st)
+                _lib.check(rc, "gf_chunk_linear_combine")
         rc = lib.gf_chunk_linear(*args, int(scale), 1, *rows, p(Y), p(Z), p(F), st)
         _lib.check(rc, "gf_chunk_linear")
         return Z
+
+    SEG_MIN_CHUNKS = 32                 # below this the plain sequential combine is as fast
+
+    def _segments(self):
+        """(seg_len, Psi) of the two-level combine of the solves, or None for short chains.  The
+        composed segment transitions are part of the factor: built on first use, then kept.
+        Sequential depth 2 seg_len + nch / seg_len chunks -> seg_len = sqrt(nch / 2)."""
+        if self.nch < self.SEG_MIN_CHUNKS:
+            return None
+        if self._Psi is None:
+            seg_len = max(2, int(round(math.sqrt(self.nch / 2.0))))
+            nseg = -(-self.nch // seg_len)
+            Psi = self.torch.empty((self.B * nseg, 4096), dtype=self.torch.float64, device=self.device)
+            st = self.torch.cuda.current_stream(self.device).cuda_stream
+            rc = self.lib.gf_chunk_segment_transitions(self.B, self.nch, seg_len, _lib.ptr(self.Phi),
+                                                       _lib.ptr(Psi), st)
+            _lib.check(rc, "gf_chunk_segment_transitions")
+            self._Psi = (seg_len, Psi)
+        return self._Psi
 
     def _mm_chunking(self, R):
         """Chunks for the dot_tril sweeps: ~2048 waves (two per SIMD) over B problems and the RHS

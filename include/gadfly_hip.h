@@ -264,6 +264,17 @@ int gf_chunk_linear(int mode, int B, int64_t N, int64_t chunk_len, int nch, int 
 int gf_chunk_linear_combine(int mode, int B, int64_t N, int64_t chunk_len, int nch, int W, int R,
                             const double *c, const double *de, const double *Phi,
                             double *D_work, double *F_state, void *stream);
+/*
+ * Two-level form of the solves' combine (long single series: the plain combine is one 64 x 64
+ * mat-vec per chunk in sequence).  gf_chunk_segment_transitions composes, once per factor, the
+ * transitions of every segment of seg_len chunks: Psi_out [B*nseg][64*64], nseg = ceil(nch / seg_len).
+ * gf_chunk_linear_combine_seg then does what gf_chunk_linear_combine does with a sequential depth of
+ * 2 seg_len + nseg chunks; V_work is [B*nseg][64*R] scratch.
+ */
+int gf_chunk_segment_transitions(int B, int nch, int seg_len, const double *Phi, double *Psi_out,
+                                 void *stream);
+int gf_chunk_linear_combine_seg(int mode, int B, int nch, int seg_len, int R, const double *Phi,
+                                const double *Psi, double *F_state, double *V_work, void *stream);
 
 /*
  * Log-likelihood reductions (fixed-shape tree, deterministic):

@@ -592,6 +592,51 @@ def test_scaled_factor_sweeps(hip, case):
     assert _relmax(fac1.apply_inverse(Yd)[0].cpu().numpy(), ref) < TOL_VEC
 
 
+@pytest.mark.parametrize("case,L", [(("solar", dict(J=30, N=9000)), 128), (("generic", dict(kind="mixed", N=2900)), 64),
+                                    (("solar", dict(J=12, N=6000, gaps=True)), 64)],
+                         ids=["solar30-71chunks", "mixed-46chunks", "solar12gaps-94chunks"])
+def test_scaled_factor_two_level_combine(hip, case, L):
+    """Long chains of chunks: the solves' combine runs in two levels on the composed segment
+    transitions (gf_chunk_segment_transitions / gf_chunk_linear_combine_seg).  Same answers as the
+    oracle and as the plain sequential combine, for ragged segment counts, 1 and several RHS."""
+    import torch
+    from gadfly_amd.engine import StreamingBatch
+    from oracle import cref, seq
+    prob = _make(case)
+    t = prob["t"]
+    N = len(t)
+    eng = StreamingBatch([prob["kernel"].get_device_coefficients()], t, prob["y"], diag=prob["diag_user"])
+    fac = eng.stored_factor(chunk_len=L)
+    assert fac.nch >= fac.SEG_MIN_CHUNKS
+    c, a, U, V = util.oracle_matrices(prob, seq)
+    d_ref, W_ref, info = cref.factor(t, c, a, U, V)
+    assert info == 0
+    rng = np.random.default_rng(5)
+    for R in (1, 4):
+        Y = rng.normal(size=(N, R))
+        Yd = torch.as_tensor(Y).cuda().reshape(1, N, R)
+        lo = fac.solve_lower(Yd)[0].cpu().numpy()
+        up = fac.solve_upper(Yd)[0].cpu().numpy()
+        assert fac._Psi is not None and fac._Psi[1].shape[0] == -(-fac.nch // fac._Psi[0])
+        assert _relmax(lo, cref.solve_lower(t, c, U, W_ref, Y)) < TOL_VEC
+        assert _relmax(up, cref.solve_upper(t, c, U, W_ref, Y)) < TOL_VEC
+        ref = cref.solve_upper(t, c, U, W_ref, cref.solve_lower(t, c, U, W_ref, Y) / d_ref[:, None])
+        assert _relmax(fac.apply_inverse(Yd)[0].cpu().numpy(), ref) < TOL_VEC
+        # the plain combine on the same factor
+        fac.SEG_MIN_CHUNKS = 10 ** 9
+        assert _relmax(fac.solve_lower(Yd)[0].cpu().numpy(), lo) < 1e-11
+        assert _relmax(fac.solve_upper(Yd)[0].cpu().numpy(), up) < 1e-11
+        del fac.SEG_MIN_CHUNKS
+    # other segment lengths, including one that leaves a single chunk in the last segment
+    for seg_len in (2, 5, fac.nch - 1):
+        Psi = torch.empty((-(-fac.nch // seg_len), 4096), dtype=torch.float64, device="cuda")
+        rc = hip.load().gf_chunk_segment_transitions(1, fac.nch, seg_len, hip.ptr(fac.Phi), hip.ptr(Psi), None)
+        hip.check(rc, "gf_chunk_segment_transitions")
+        fac._Psi = (seg_len, Psi)
+        assert _relmax(fac.solve_lower(Yd)[0].cpu().numpy(), lo) < 1e-11
+        assert _relmax(fac.solve_upper(Yd)[0].cpu().numpy(), up) < 1e-11
+
+
 def test_recompute_refactorises_everything(hip):
     """celerite2's recompute() after a kernel change refactorises: apply_inverse / predict / dot_tril
     must use the NEW kernel's factor (a stored factor of the old kernel survived)."""
