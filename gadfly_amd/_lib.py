@@ -58,6 +58,7 @@ SIGNATURES = {
                         + [_vp] * 8 + [_vp]),
     "gf_chunk_linear_combine": (_int, [_int, _int, _i64, _i64, _int, _int, _int] + [_vp] * 5
                                 + [_vp]),
+    "gf_dense_solve": (_int, [_int, _int, _int] + [_vp] * 2 + [_vp]),
     "gf_chunk_segment_transitions": (_int, [_int, _int, _int] + [_vp] * 2 + [_vp]),
     "gf_chunk_linear_combine_seg": (_int, [_int, _int, _int, _int, _int] + [_vp] * 4 + [_vp]),
     "gf_chunk_transition": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int, _int] + [_vp] * 7

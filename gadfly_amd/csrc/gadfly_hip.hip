@@ -2907,6 +2907,212 @@ k_segment_transition(const int nch, const int seg_len, const double *__restrict_
     for (int e = tid; e < 4096; e += 256) Og[e] = Ps[(e & 63) * 64 + (e >> 6)];
 }
 
+// ---- dense batched solve for the chunk maps of WIDE kernels --------------------------------------
+// The time-parallel combine of a W > 63 kernel composes dense W x W maps (W <= 192): GEMMs and one
+// LU solve per tree level and pair.  The GEMMs go to rocBLAS; the solves do not: hipSOLVER's blocked
+// getrf / getrs is ~300 tiny launches per call at this size (3 ms per tree level, all of it launch
+// latency -- two thirds of `compute` with gadfly's 86-term solar kernel at N = 1e5).  This kernel does
+// one batched solve in ONE launch: Gauss-Jordan with implicit partial pivoting (rows are never
+// swapped) on [A | B], held in registers.
+//   16 waves per system, every wave holds ALL rows (lane l: rows l, l + 64, l + 128) of its columns:
+//   column j of A belongs to wave j mod 16 (slot j / 16), the right-hand sides are dealt the same
+//   way; blockIdx.y cuts B into slices of 64 columns, each slice eliminates its own copy of A.
+//   Step k: the pivot search is local to the wave that owns column k; it publishes the multipliers
+//   f_i = a_ik / a_pk (f_p = 0), the pivot's lane and row set through LDS.  After ONE barrier every
+//   wave updates its slots; the pivot row's entry of a column is a readlane of the wave's own
+//   registers (an SGPR operand of the FMAs: no LDS traffic in the update).  The owner of column
+//   k + 1 forms that column first and runs the next search before its update, so the search overlaps
+//   the other waves' FMAs.
+//   The k loop is cut into phases of 16 steps, unrolled at compile time: in phase q the slots below q
+//   hold eliminated columns and are left alone, and the owner's slot index is a constant.  All
+//   register updates are unconditional straight-line code: alternatives that merge (one per row set
+//   of the pivot, say) cost a copy of the whole register array per step, so the row set only selects
+//   which registers the readlanes read.
+//   A, B and X move through an LDS tile of 32 rows so that global accesses are contiguous (lanes
+//   along a row); lane = row gathers of a row-major matrix cost more than the elimination.
+// Singular systems (maps of chunks after a failed pivot) produce garbage, never a fault.
+constexpr int DS_WAVES = 16, DS_NR = 4;             // 64 right-hand sides per workgroup
+constexpr int DS_TROWS = 32, DS_LDT = 193;          // LDS tile: 32 rows, odd leading dimension
+
+template <int RS>
+struct DenseSolveShared {
+    double tile[DS_TROWS * DS_LDT];
+    double f[2][RS][64];                            // multipliers of step k, buffer k & 1
+    double rowpinv[64 * RS];
+    int pl[2], rs[2], rowk[64 * RS];
+};
+
+// pivot search on column k (values C of this wave's rows) by its owner; publishes into buffer k & 1
+template <int RS>
+__device__ __forceinline__ void ds_search(DenseSolveShared<RS> &sh, const double (&C)[RS], const unsigned used,
+                                          const int k, const int lane) {
+    const int buf = k & 1;
+    double bx = 0.0, bc = -2.0;
+    int br = 0;
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        double a = fabs(C[r]);
+        a = (a == a) ? a : 0.0;
+        const double cnd = ((used >> r) & 1u) ? -1.0 : a;
+        if (cnd > bc) { bc = cnd; bx = C[r]; br = r; }
+    }
+    const double vm = wave_max(bc);
+    const unsigned long long hit = __ballot(bc == vm);
+    const int pl = __builtin_amdgcn_readfirstlane(hit ? (int)__ffsll((long long)hit) - 1 : 0);
+    const int rsel = __builtin_amdgcn_readlane(br, pl);
+    const double pinv = fast_rcp(read_lane(bx, pl));
+#pragma unroll
+    for (int r = 0; r < RS; ++r)
+        sh.f[buf][r][lane] = (lane == pl && r == rsel) ? 0.0 : C[r] * pinv;
+    if (lane == 0) {
+        sh.pl[buf] = pl; sh.rs[buf] = rsel;
+        sh.rowk[64 * rsel + pl] = k; sh.rowpinv[64 * rsel + pl] = pinv;
+    }
+}
+
+// entry (lane pl, row set RSEL) of slots [Q, NS) as wave-uniform values; the empty asm keeps the three
+// instances apart (merged, the compiler selects among the register sets with per-step copies)
+template <int RS, int NS, int RSEL, int Q>
+__device__ __forceinline__ void ds_pivot_row(double (&pe)[NS], const double (&R)[RS][NS], const int pl) {
+#pragma unroll
+    for (int c = Q; c < NS; ++c) {
+        int lo = __builtin_amdgcn_readlane(__double2loint(R[RSEL][c]), pl);
+        int hi = __builtin_amdgcn_readlane(__double2hiint(R[RSEL][c]), pl);
+        if (RSEL == 0) asm volatile("; row set 0" : "+s"(lo), "+s"(hi));
+        else if (RSEL == 1) asm volatile("; row set 1" : "+s"(lo), "+s"(hi));
+        else asm volatile("; row set 2" : "+s"(lo), "+s"(hi));
+        pe[c] = __hiloint2double(hi, lo);
+    }
+}
+
+// phase Q of the elimination: steps k = 16 Q ... 16 Q + 15 (< n), slots [Q, NA + DS_NR)
+template <int RS, int NA, int Q>
+__device__ __forceinline__ void ds_phase(DenseSolveShared<RS> &sh, double (&R)[RS][NA + DS_NR], unsigned &used,
+                                         const int n, const int wave, const int lane) {
+    constexpr int NS = NA + DS_NR;
+    const int kend = (n - DS_WAVES * Q < DS_WAVES) ? n - DS_WAVES * Q : DS_WAVES;
+    for (int kk = 0; kk < kend; ++kk) {
+        const int k = DS_WAVES * Q + kk, buf = k & 1;
+        // the owner of the next column is the critical path of the step: it outranks the three waves
+        // that share its SIMD until its search is published
+        const bool owner = k + 1 < n && wave == ((k + 1) & (DS_WAVES - 1));
+        if (owner) __builtin_amdgcn_s_setprio(3);
+        wg_lds_barrier();
+        double f[RS];
+#pragma unroll
+        for (int r = 0; r < RS; ++r) f[r] = sh.f[buf][r][lane];
+        const int pl = __builtin_amdgcn_readfirstlane(sh.pl[buf]);
+        const int rsel = __builtin_amdgcn_readfirstlane(sh.rs[buf]);
+        if (lane == pl) used |= 1u << rsel;
+        double pe[NS];                              // the pivot row's entries of this wave's slots
+        if (RS == 1 || rsel == 0) ds_pivot_row<RS, NS, 0, Q>(pe, R, pl);
+        else if (RS == 2 || rsel == 1) ds_pivot_row<RS, NS, (RS > 1 ? 1 : 0), Q>(pe, R, pl);
+        else ds_pivot_row<RS, NS, (RS > 2 ? 2 : 0), Q>(pe, R, pl);
+        if (owner) {
+            // column k + 1 sits in slot Q, or in slot Q + 1 when this is the last step of the phase (both
+            // formed, then selected: an index that depends on kk would make the register arrays dynamic)
+            constexpr int Q1 = (Q + 1 < NA) ? Q + 1 : Q;
+            const bool same = kk + 1 < DS_WAVES;
+            double C[RS];
+#pragma unroll
+            for (int r = 0; r < RS; ++r) {
+                const double ca = fma(-f[r], pe[Q], R[r][Q]), cb = fma(-f[r], pe[Q1], R[r][Q1]);
+                C[r] = same ? ca : cb;
+            }
+            ds_search<RS>(sh, C, used, k + 1, lane);
+            __builtin_amdgcn_s_setprio(0);
+        }
+#pragma unroll
+        for (int c = Q; c < NS; ++c)
+#pragma unroll
+            for (int r = 0; r < RS; ++r) R[r][c] = fma(-f[r], pe[c], R[r][c]);
+    }
+}
+
+template <int RS, int NA>
+__global__ void __launch_bounds__(64 * DS_WAVES)
+k_dense_solve(const int n, const int nrhs, const double *__restrict__ A_, double *__restrict__ B_) {
+    constexpr int NS = NA + DS_NR, NT = 64 * DS_WAVES, BC = DS_WAVES * DS_NR;
+    const int b = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double *Ab = A_ + (size_t)b * n * n;
+    double *Bb = B_ + (size_t)b * n * nrhs + (size_t)sl * BC;
+    const int ncol = (nrhs - sl * BC < BC) ? nrhs - sl * BC : BC;      // columns of this slice
+    __shared__ __attribute__((aligned(16))) DenseSolveShared<RS> sh;
+    double R[RS][NS];                               // [0, NA): columns wave + 16 slot of A; then B
+    const int half = lane >> 5, l32 = lane & 31;
+    static_for([&](auto tt) {                       // A: 32 rows at a time, as a flat contiguous copy
+        constexpr int t = decltype(tt)::value, r = t >> 1;
+        const int row0 = DS_TROWS * t;
+        for (int e = tid; e < DS_TROWS * n; e += NT) {
+            const int rr = e / n, cc = e - rr * n;
+            sh.tile[rr * DS_LDT + cc] = (row0 + rr < n) ? Ab[(size_t)row0 * n + e] : 0.0;
+        }
+        __syncthreads();
+        if (half == (t & 1)) {
+#pragma unroll
+            for (int la = 0; la < NA; ++la) {
+                const int j = wave + DS_WAVES * la;
+                R[r][la] = (j < n) ? sh.tile[l32 * DS_LDT + j] : 0.0;
+            }
+        }
+        __syncthreads();
+    }, std::make_integer_sequence<int, 2 * RS>{});
+    static_for([&](auto tt) {                       // this slice of B
+        constexpr int t = decltype(tt)::value, r = t >> 1;
+        const int row0 = DS_TROWS * t;
+        for (int e = tid; e < DS_TROWS * BC; e += NT) {
+            const int rr = e / BC, cc = e - rr * BC;
+            sh.tile[rr * DS_LDT + cc] = (row0 + rr < n && cc < ncol) ? Bb[(size_t)(row0 + rr) * nrhs + cc] : 0.0;
+        }
+        __syncthreads();
+        if (half == (t & 1)) {
+#pragma unroll
+            for (int lr = 0; lr < DS_NR; ++lr) R[r][NA + lr] = sh.tile[l32 * DS_LDT + wave + DS_WAVES * lr];
+        }
+        __syncthreads();
+    }, std::make_integer_sequence<int, 2 * RS>{});
+    unsigned used = 0;                              // bit r: row 64 r + lane already served as a pivot
+#pragma unroll
+    for (int r = 0; r < RS; ++r) if (64 * r + lane >= n) used |= 1u << r;
+    for (int e = tid; e < 64 * RS; e += NT) { sh.rowk[e] = -1; sh.rowpinv[e] = 0.0; }
+    __syncthreads();
+    if (wave == 0) {
+        double C[RS];
+#pragma unroll
+        for (int r = 0; r < RS; ++r) C[r] = R[r][0];
+        ds_search<RS>(sh, C, used, 0, lane);
+    }
+    static_for([&](auto q) { ds_phase<RS, NA, decltype(q)::value>(sh, R, used, n, wave, lane); },
+               std::make_integer_sequence<int, NA>{});
+    __syncthreads();
+    // row 64 r + lane solved variable rowk[...]: X(rowk, :) = its B slots / pivot, through the tile
+    int myk[RS];
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        myk[r] = sh.rowk[64 * r + lane];
+        const double pinv = sh.rowpinv[64 * r + lane];
+#pragma unroll
+        for (int lr = 0; lr < DS_NR; ++lr) R[r][NA + lr] *= pinv;
+    }
+    for (int row0 = 0; row0 < n; row0 += DS_TROWS) {
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const int rel = myk[r] - row0;
+            if (rel >= 0 && rel < DS_TROWS) {
+#pragma unroll
+                for (int lr = 0; lr < DS_NR; ++lr) sh.tile[rel * DS_LDT + wave + DS_WAVES * lr] = R[r][NA + lr];
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < DS_TROWS * BC; e += NT) {
+            const int rr = e / BC, cc = e - rr * BC;
+            if (row0 + rr < n && cc < ncol) Bb[(size_t)(row0 + rr) * nrhs + cc] = sh.tile[rr * DS_LDT + cc];
+        }
+        __syncthreads();
+    }
+}
+
 // Combine of GF_MATMUL_LOWER (dot_tril): the chunk transitions are DIAGONAL (D_c), so the start states are
 // a plain scan  F_{c+1} = loc_c + D_c o F_c  of 64 x R independent scalar sequences.  One workgroup of 16
 // waves per (problem, state row), lane = right-hand side (the states are stored [row][R]: coalesced rows
@@ -4652,6 +4858,22 @@ int gf_chunk_linear_combine_seg(int mode, int B, int nch, int seg_len, int R, co
     hipLaunchKernelGGL(k_lincombine<2>, dim3(B * nseg, R), dim3(256), 0, st, nch, seg_len, mode, R, Phi,
                        (const double *)nullptr, F_state, V_work);
     return check_launch("gf_chunk_linear_combine_seg");
+}
+
+int gf_dense_solve(int batch, int n, int nrhs, const double *A, double *B, void *stream) {
+    if (batch < 1 || n < 1 || nrhs < 1) return set_err("gf_dense_solve: empty problem (n=%s%lld, nrhs=%lld)", "", n, nrhs);
+    if (n > 192) return set_err("gf_dense_solve: n=%s%lld unsupported (max %lld)", "", n, 192);
+    if (!A || !B) return set_err("gf_dense_solve: null pointer%s", "");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(batch, (nrhs + DS_WAVES * DS_NR - 1) / (DS_WAVES * DS_NR));
+#define GF_DS(RSv, NAv) hipLaunchKernelGGL((k_dense_solve<RSv, NAv>), grid, dim3(64 * DS_WAVES), 0, st, n, nrhs, A, B)
+    if (n <= 64) GF_DS(1, 4);
+    else if (n <= 96) GF_DS(2, 6);
+    else if (n <= 128) GF_DS(2, 8);
+    else if (n <= 176) GF_DS(3, 11);
+    else GF_DS(3, 12);
+#undef GF_DS
+    return check_launch("gf_dense_solve");
 }
 
 int64_t gf_reduce_work(int64_t N) { return RED_NACC * (int64_t)red_groups(N); }

@@ -304,18 +304,20 @@ LOG_2PI = math.log(2.0 * math.pi)
 SINCOS_RANGE = 3.0e9
 
 
-_SOLVE_BATCH = 32
 
 
 def _solve_quiet(torch, A, rhs):
-    """Batched LU solve that never raises: the maps of chunks at or after a non-positive pivot are
-    garbage (singular, NaN) by construction; they only ever feed chunks that fail anyway."""
-    if A.ndim == 3 and A.shape[0] > _SOLVE_BATCH:
-        # (hipBLAS' batched triangular solve runs out of workspace on large batches of 172 x 345
-        # systems: HIPBLAS_STATUS_ALLOC_FAILED at 256; groups of 32 are as fast)
-        return torch.cat([_solve_quiet(torch, A[i:i + _SOLVE_BATCH], rhs[i:i + _SOLVE_BATCH])
-                          for i in range(0, A.shape[0], _SOLVE_BATCH)])
-    return torch.linalg.solve_ex(A, rhs, check_errors=False)[0]
+    """Batched dense solve that never raises (gf_dense_solve: Gauss-Jordan with partial pivoting in ONE
+    launch; hipSOLVER's blocked LU is ~300 launches per call at these sizes).  The maps of chunks at
+    or after a non-positive pivot are garbage (singular, NaN) by construction; they only ever feed
+    chunks that fail anyway."""
+    A = A.contiguous()
+    X = rhs.contiguous().clone()
+    batch, n, nrhs = X.shape
+    st = torch.cuda.current_stream(A.device).cuda_stream
+    rc = _lib.load().gf_dense_solve(batch, n, nrhs, _lib.ptr(A), _lib.ptr(X), st)
+    _lib.check(rc, "gf_dense_solve")
+    return X
 
 
 def _lft_compose(torch, M1, M2):
@@ -354,39 +356,89 @@ def _lft_apply(torch, M, X, Y):
 
 def _lft_tree_scan(torch, Ph, G, Xb, Yb, m):
     """True start state of every chunk from the chunk maps, as a Blelloch scan (2 log2 P batched
-    levels of dense W x W GEMMs / LU solves: rocBLAS / hipSOLVER through torch).  Inputs are
-    (nch, W, W) / (nch, W); returns (Xstart (nch, W, W), Ystart (nch, W))."""
+    levels of dense W x W GEMMs through rocBLAS and one gf_dense_solve each).  Inputs are
+    (nch, W, W) / (nch, W); returns (Xstart (nch, W, W), Ystart (nch, W)).  The pairs of a level are
+    strided views of the map arrays (no gathers); no host synchronisation anywhere, so the whole scan
+    can be replayed from a captured HIP graph (:class:`_TreeScanGraph`)."""
     nch, W = Ph.shape[0], Ph.shape[-1]
     P = 1 << max(0, (nch - 1).bit_length())
+    kw = dict(dtype=Ph.dtype, device=Ph.device)
+    maps = [torch.zeros((P, W, W), **kw), torch.zeros((P, W, W), **kw), torch.zeros((P, W, W), **kw),
+            torch.zeros((P, W), **kw), torch.zeros((P, W), **kw)]
+    for a, v in zip(maps, (Ph, G, Xb, Yb, m)):
+        a[:nch] = v
     if P > nch:                                         # identity maps pad the scan
-        pad = P - nch
-        eye = torch.eye(W, dtype=Ph.dtype, device=Ph.device).expand(pad, W, W)
-        zW = torch.zeros((pad, W, W), dtype=Ph.dtype, device=Ph.device)
-        zv = torch.zeros((pad, W), dtype=Ph.dtype, device=Ph.device)
-        Ph, G, Xb = torch.cat([Ph, eye]), torch.cat([G, zW]), torch.cat([Xb, zW])
-        Yb, m = torch.cat([Yb, zv]), torch.cat([m, zv])
-    maps = [Ph.clone(), G.clone(), Xb.clone(), Yb.clone(), m.clone()]
-    ar = torch.arange(P, device=Ph.device)
+        maps[0][nch:] = torch.eye(W, **kw)
     d = 1
     while d < P:                                        # up-sweep: map[right] <- map[right] o map[left]
-        right = ar[2 * d - 1::2 * d]
-        left = right - d
-        new = _lft_compose(torch, [a[left] for a in maps], [a[right] for a in maps])
+        new = _lft_compose(torch, [a[d - 1::2 * d] for a in maps], [a[2 * d - 1::2 * d] for a in maps])
         for a, v in zip(maps, new):
-            a[right] = v
+            a[2 * d - 1::2 * d] = v
         d *= 2
-    Xs = torch.zeros((P, W, W), dtype=Ph.dtype, device=Ph.device)
-    Ys = torch.zeros((P, W), dtype=Ph.dtype, device=Ph.device)
+    Xs = torch.zeros((P, W, W), **kw)
+    Ys = torch.zeros((P, W), **kw)
     d = P // 2
     while d >= 1:                                       # down-sweep
-        right = ar[2 * d - 1::2 * d]
-        left = right - d
-        Xin, Yin = Xs[right], Ys[right]
-        Xo, Yo = _lft_apply(torch, [a[left] for a in maps], Xin, Yin)
-        Xs[left], Ys[left] = Xin, Yin
-        Xs[right], Ys[right] = Xo, Yo
+        Xin, Yin = Xs[2 * d - 1::2 * d].clone(), Ys[2 * d - 1::2 * d].clone()
+        Xo, Yo = _lft_apply(torch, [a[d - 1::2 * d] for a in maps], Xin, Yin)
+        Xs[d - 1::2 * d], Ys[d - 1::2 * d] = Xin, Yin
+        Xs[2 * d - 1::2 * d], Ys[2 * d - 1::2 * d] = Xo, Yo
         d //= 2
     return Xs[:nch], Ys[:nch]
+
+
+class _TreeScanGraph:
+    """:func:`_lft_tree_scan` for one (nch, W) captured in a HIP graph: the scan is ~1 500 small
+    launches (batched GEMMs, copies, one solve per level) whose host-side launch cost exceeds their
+    GPU time several times over; replaying the captured graph leaves the GPU time.  Inputs are copied
+    into fixed buffers, the outputs are views of fixed buffers (consumed before the next replay: both
+    happen on the caller's stream)."""
+
+    _cache = {}
+    MAX_ENTRIES = 4
+    disabled = False
+
+    def __init__(self, torch, nch, W, device):
+        kw = dict(dtype=torch.float64, device=device)
+        self.ins = [torch.zeros((nch, W, W), **kw) for _ in range(3)] + [torch.zeros((nch, W), **kw)
+                                                                         for _ in range(2)]
+        for a in self.ins[:3]:
+            a.copy_(torch.eye(W, **kw))                 # harmless maps for the warm-up
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):                   # library handles / workspaces exist before capture
+            _lft_tree_scan(torch, self.ins[0], self.ins[1], self.ins[2], self.ins[3], self.ins[4])
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outs = _lft_tree_scan(torch, self.ins[0], self.ins[1], self.ins[2], self.ins[3],
+                                       self.ins[4])
+
+    def __call__(self, Ph, G, Xb, Yb, m):
+        for a, v in zip(self.ins, (Ph, G, Xb, Yb, m)):
+            a.copy_(v)
+        self.graph.replay()
+        return self.outs
+
+    @classmethod
+    def run(cls, torch, Ph, G, Xb, Yb, m):
+        """The scan through a cached graph; eager when capture is unavailable."""
+        if cls.disabled:
+            return _lft_tree_scan(torch, Ph, G, Xb, Yb, m)
+        key = (Ph.device.index, Ph.shape[0], Ph.shape[-1])
+        ent = cls._cache.pop(key, None)
+        if ent is None:
+            try:
+                ent = cls(torch, Ph.shape[0], Ph.shape[-1], Ph.device)
+            except RuntimeError:                        # capture refused: keep the eager scan
+                cls.disabled = True
+                torch.cuda.synchronize(Ph.device)
+                return _lft_tree_scan(torch, Ph, G, Xb, Yb, m)
+            while len(cls._cache) >= cls.MAX_ENTRIES:
+                cls._cache.pop(next(iter(cls._cache)))
+        cls._cache[key] = ent                           # most recently used last
+        return ent(Ph, G, Xb, Yb, m)
 
 
 class ScaledFactor:
@@ -1137,16 +1189,18 @@ class StreamingBatch:
     #: shortest series for which the wide time-parallel run replaces the sequential sweep
     wide_tp_min_rows = 16384
 
+    WIDE_TP_COEF = 0.1
+
     def _wide_tp_ok(self):
         return self._wide_ok() and self.B == 1 and self.N >= self.wide_tp_min_rows
 
     def _wide_chunking(self, chunk_len):
         if chunk_len is None:
-            # three sweeps of N / nch rows (~1.4 us per row at W = 172) against ~0.36 ms per chunk map in
-            # the dense combine (library GEMMs / LU solves of W x W blocks, launch-bound): the optimum is
-            # nch ~ sqrt(0.012 N) -- 32 chunks at N = 1e5, 128 at N = 1e6 -- rounded to a power of two
+            # three sweeps of N / nch rows (~1.4 us per row at W = 172) against the dense combine's
+            # 2 log2(nch) levels (~0.4 ms each: one gf_dense_solve + batched GEMMs): measured optimum
+            # nch ~ sqrt(0.1 N) -- 128 chunks at N = 1e5, 256 at N = 1e6 -- rounded to a power of two
             # (the scan pads to one anyway)
-            want = max(2.0, math.sqrt(0.012 * self.N))
+            want = max(2.0, math.sqrt(self.WIDE_TP_COEF * self.N))
             nch = 1 << int(round(math.log2(want)))
             chunk_len = -(-self.N // min(nch, 512))
         chunk_len = max(64, (int(chunk_len) + 63) // 64 * 64)
@@ -1213,10 +1267,8 @@ class StreamingBatch:
             Hd = (Hc * dinv).transpose(1, 2)            # (nch, W, L)
             G = torch.bmm(Hd, Hc)
             mm = torch.bmm(Hd, zbar[:NP].view(nch, L, 1)).squeeze(-1)
-            # (replaying this scan from a captured HIP graph would cut its launch overhead, but hipSOLVER's
-            # batched LU invalidates stream capture here: tried, refused)
-            Xs, Ys = _lft_tree_scan(torch, Ph, 0.5 * (G + G.transpose(1, 2)),
-                                    0.5 * (Xb + Xb.transpose(1, 2)), Yb, mm)
+            Xs, Ys = _TreeScanGraph.run(torch, Ph, 0.5 * (G + G.transpose(1, 2)),
+                                        0.5 * (Xb + Xb.transpose(1, 2)), Yb, mm)
             S.zero_()
             S3[:, :W, :W] = Xs.transpose(1, 2)
             S3[:, ld - 1, :W] = Ys

@@ -277,6 +277,16 @@ int gf_chunk_linear_combine_seg(int mode, int B, int nch, int seg_len, int R, co
                                 const double *Psi, double *F_state, double *V_work, void *stream);
 
 /*
+ * Batched dense solve A X = B (Gauss-Jordan with partial pivoting, one launch): A [batch][n][n] row-major
+ * (read only), B [batch][n][nrhs] row-major, overwritten with X; n <= 192.  What the time-parallel combine
+ * of a wide kernel uses for its W x W chunk maps instead of a blocked LAPACK LU (hundreds of launches per
+ * call at this size).  A singular A gives garbage in X, never an error: the maps of chunks after a failed
+ * pivot are singular by construction and are not used.  celerite2 has no counterpart (its factorisation
+ * is sequential: celerite2.driver.factor, /root/reference/gadfly/gp.py:202).
+ */
+int gf_dense_solve(int batch, int n, int nrhs, const double *A, double *B, void *stream);
+
+/*
  * Log-likelihood reductions (fixed-shape tree, deterministic):
  *   gf_reduce_tile   : acc[b] = {sum log d, sum z^2/d, min d} (THREE doubles per problem) over N
  *                      rows; init != 0 overwrites acc, init == 0 accumulates (tiles in order).
