@@ -501,15 +501,21 @@ def test_time_parallel_tree_combine(hip, case):
     assert float((eng._tp["z"][:B * N] - z_lin).abs().max()) < 1e-8 * zs
 
 
-def test_gaussian_process_fast_path_long_series(hip):
+@pytest.mark.parametrize("keep", [True, False], ids=["factor-kept-by-compute", "factor-built-on-demand"])
+def test_gaussian_process_fast_path_long_series(hip, keep):
     """compute + log_likelihood of the drop-in class on a series long enough to take the
-    time-parallel engine, against the oracle; then a predict() that builds the stored factor."""
+    time-parallel engine, against the oracle.  compute() keeps the factor of a long series
+    (log_likelihood is then one forward sweep on it); beyond STORE_MAX_ROWS it does not, log_likelihood
+    is the fused evaluation and the first predict() builds the stored factor."""
     import gadfly_amd
     from oracle import cref
     prob = util.solar_problem(12, 40000)
     k, t, y = prob["kernel"], prob["t"], prob["y"]
-    gp = gadfly_amd.GaussianProcess(k, t=t, yerr=30.0, mean=1.5)
-    assert gp._fast is not None and gp._factor is None and gp._fast._tp_used
+    gp = gadfly_amd.GaussianProcess(k, mean=1.5)
+    if not keep:
+        gp.STORE_MAX_ROWS = 1000
+    gp.compute(t, yerr=30.0)
+    assert gp._fast is not None and gp._fast._tp_used and (gp._factor is not None) == keep
     co = k.get_device_coefficients()
     ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y - 1.5)
     ll = gp.log_likelihood(y)
