@@ -2777,6 +2777,188 @@ __global__ void __launch_bounds__(64, 2) k_linR7(const LinArgs A) {
     }
 }
 
+// GF_MATMUL_LOWER (dot_tril, GP.sample) with many right-hand sides on the matrix pipe.  The sweep has no
+// feedback in this mode (the carries are the inputs), so 16 rows at a time are plain products:
+//     Z_b = Y_b + U_b F + strict_lower(U_b W_b^T) Y_b ,     F <- F + W_b^T Y_b
+// (U_b, W_b: the block's 16 rows of u~, w~; F: W x R state; decay E o F first when the block starts on a
+// reset row; a reset inside a block cuts it there, rows past the cut are masked).  k_linR7 does the same
+// arithmetic row by row and runs at the pace of its LDS broadcasts (30 ds_read_b128 per row and wave: 14.9 %
+// of the HBM roofline on cfg5).  Here one wave owns 64 right-hand sides of one chunk; everything is
+// v_mfma_f64_16x16x4 (lane (i, k) = (lane & 15, lane >> 4) supplies A[i][4 s + k], B[4 s + k][i] of slice s
+// and receives D[k + 4 r][i], r = 0..3), laid out so that no result ever changes lanes:
+//   * the accumulators of  F += W_b^T Y_b  (tile mt, register r = state 16 mt + k + 4 r) ARE the B
+//     operands of  U_b F  (slice s = 4 mt + r <-> state 4 s + k);
+//   * the C layout of  G^T = W_b U_b^T  is the A layout of  strict_lower(G) Y_b  (entry (i, k + 4 r));
+//   * the B operand rows of Y_b (4 s + k) are the C rows of Z_b (k + 4 r): one load serves both.
+// 16 + 36 T MFMAs per block and wave (T = 4 tiles of 16 right-hand sides: the rows are read once), 16 T for
+// the local pass; one wave per SIMD (the state alone is 128 accumulator registers).
+// The block's u~ / w~ rows (2 x 8 KB, contiguous in memory) come in as flat 16-byte loads issued one block
+// ahead, go through an LDS tile (row stride 66: the A-operand reads are conflict-free) and are read slice by
+// slice at their point of use.  Taking the operands from global in their MFMA layout instead cost more than
+// the MFMAs: a lane-per-row pattern is 64 separate sectors per load instruction (the texture addresser
+// serialises them), and a masked load in a branch of its own gets its own s_waitcnt (30 round trips per block).
+template <int MT, bool NODOT>
+__global__ void __launch_bounds__(64, 1) k_mmR_mfma(const LinArgs A) {
+    constexpr int KS = 4 * MT, T = 4, LDT = 66;
+    const int lane = threadIdx.x, i = lane & 15, k = lane >> 4;
+    const int b = blockIdx.x, rt = blockIdx.y;
+    const int pr = b / A.nch, ch = b - pr * A.nch;
+    const int R = A.R;
+    const int64_t c0 = (int64_t)ch * A.chunk_len;
+    const int rows = (int)((A.N - c0 < A.chunk_len) ? (A.N - c0) : A.chunk_len);
+    const size_t pb = (size_t)pr * A.N + c0;
+    const double *__restrict__ Ug = A.Ut + pb * 64;
+    const double *__restrict__ Wg = A.Wt + pb * 64;
+    const double *__restrict__ dg = A.d + pb;
+    const double *__restrict__ eg = A.de + pb;
+    const double *__restrict__ Yg = A.Y + pb * R;
+    double *__restrict__ Zg = A.Z + pb * R;
+    double *__restrict__ Fg = A.F_state + (size_t)b * 64 * R;      // [state][R]
+    __shared__ double s_c[64];                      // decay rates (read at reset rows only; 0 beyond W)
+    __shared__ __attribute__((aligned(16))) double s_u[NODOT ? 2 : 16 * LDT], s_w[16 * LDT];
+    s_c[lane] = (lane < A.W) ? A.c[(size_t)pr * A.W + lane] : 0.0;
+    int rhs[T], rhc[T];                             // (rhc: clamped, loads are unconditional; masks come after)
+    bool rok[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        rhs[t] = rt * 16 * T + 16 * t + i; rok[t] = rhs[t] < R; rhc[t] = rok[t] ? rhs[t] : R - 1;
+    }
+    d4 F[T][MT];                                    // F[t][mt][r] = state 16 mt + k + 4 r, rhs[t]
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                F[t][mt][r] = Fg[(size_t)(16 * mt + k + 4 * r) * R + rhc[t]];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) F[t][mt][r] = rok[t] ? F[t][mt][r] : 0.0;
+    // one block of inputs, as loaded (rows clamped to the chunk; no branch around any load)
+    double pux[NODOT ? 1 : 8], puy[NODOT ? 1 : 8], pwx[8], pwy[8];
+    double e_raw, yraw[T][4], draw[4];
+#define GF_MM_FETCH(N0)                                                                             \
+    do {                                                                                            \
+        const int f_n0 = (N0);                                                                      \
+        const int f_lim = (rows - f_n0 < 16) ? rows - f_n0 : 16;                                    \
+        e_raw = eg[f_n0 + ((lane < f_lim) ? lane : f_lim - 1)];                                     \
+        _Pragma("unroll")                                                                           \
+        for (int s4 = 0; s4 < 4; ++s4) {                                                            \
+            const int f_row = 4 * s4 + k;                                                           \
+            const size_t f_n = (size_t)(f_n0 + ((f_row < f_lim) ? f_row : f_lim - 1));              \
+            draw[s4] = dg[f_n];                                                                     \
+            _Pragma("unroll")                                                                       \
+            for (int t = 0; t < T; ++t) yraw[t][s4] = Yg[f_n * R + rhc[t]];                         \
+        }                                                                                           \
+        _Pragma("unroll")                                                                           \
+        for (int q = 0; q < 8; ++q) {   /* flat copy: element 2 lane + 128 q of the 16 x 64 tile */ \
+            const int f_row = 2 * q + (lane >> 5);                                                  \
+            const size_t f_off = (size_t)(f_n0 + ((f_row < f_lim) ? f_row : f_lim - 1)) * 64 + 2 * (lane & 31); \
+            const double2 f_w = *reinterpret_cast<const double2 *>(Wg + f_off);                     \
+            pwx[q] = f_w.x; pwy[q] = f_w.y;                                                         \
+            if constexpr (!NODOT) {                                                                 \
+                const double2 f_u = *reinterpret_cast<const double2 *>(Ug + f_off);                 \
+                pux[q] = f_u.x; puy[q] = f_u.y;                                                     \
+            }                                                                                       \
+        }                                                                                           \
+    } while (0)
+    GF_MM_FETCH(0);
+    for (int n0 = 0; n0 < rows;) {
+        const int lim = (rows - n0 < 16) ? rows - n0 : 16;
+        wave_lds_fence();                           // (the previous block's operand reads are done)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int at = (2 * q + (lane >> 5)) * LDT + 2 * (lane & 31);
+            *reinterpret_cast<double2 *>(&s_w[at]) = double2{pwx[q], pwy[q]};
+            if constexpr (!NODOT) *reinterpret_cast<double2 *>(&s_u[at]) = double2{pux[q], puy[q]};
+        }
+        // the block: rows n0 .. n0 + cnt - 1, cut at the first reset row after n0
+        const double e_l = (lane < lim) ? e_raw : -1.0;
+        const unsigned long long inner = __ballot(e_l >= 0.0 && lane >= 1);
+        const int cnt = inner ? (int)__ffsll((long long)inner) - 1 : lim;
+        const double de0 = read_lane(e_l, 0);
+        const bool rowA = i < cnt;                  // this lane's row as an A operand (row n0 + i)
+        double yv[T][4];                            // rows n0 + 4 s + k (B operand of slice s; C rows of Z_b)
+        bool okK[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            okK[s4] = 4 * s4 + k < cnt;
+            const double sc = A.scale ? sqrt(draw[s4]) : 1.0;
+#pragma unroll
+            for (int t = 0; t < T; ++t) yv[t][s4] = (okK[s4] && rok[t]) ? yraw[t][s4] * sc : 0.0;
+        }
+        wave_lds_fence();
+        // the next block's loads fly under this block's MFMAs (past the chunk's end: the last row again,
+        // never used -- an unconditional fetch keeps the staging registers out of scratch)
+        GF_MM_FETCH((n0 + cnt < rows) ? n0 + cnt : rows - 1);
+        if (de0 >= 0.0) {
+            // reset row: F <- E o F before the block's products -- as diag(E) F on the matrix pipe too (a
+            // vector multiply would pull the 128 accumulator registers of F into the vector file at every
+            // reset: the allocator then keeps them there and spills the rest)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const double e = fm_exp(-s_c[16 * mt + i] * de0);
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    d4 Fn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)      // A[i][4 s + k] = E_i [i == 4 s + k]
+                        Fn = GF_MFMA64((i == 4 * s4 + k) ? e : 0.0, F[t][mt][s4], Fn);
+                    F[t][mt] = Fn;
+                }
+            }
+        }
+        if constexpr (!NODOT) {
+            d4 G = {0.0, 0.0, 0.0, 0.0};            // G^T = W_b U_b^T: lane (i, k) gets u~_i . w~_{k + 4 r}
+            d4 Z[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) Z[t] = d4{yv[t][0], yv[t][1], yv[t][2], yv[t][3]};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {          // u~, w~[n0 + i][4 s + k]
+                const double uv = s_u[i * LDT + 4 * s + k], wv = s_w[i * LDT + 4 * s + k];
+                const double ua = rowA ? uv : 0.0, wa = rowA ? wv : 0.0;
+                G = GF_MFMA64(wa, ua, G);
+#pragma unroll
+                for (int t = 0; t < T; ++t) Z[t] = GF_MFMA64(ua, F[t][s >> 2][s & 3], Z[t]);
+                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);    // (operand reads stay near their use)
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (k + 4 * r >= i) G[r] = 0.0;        // strictly lower
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) Z[t] = GF_MFMA64(G[s4], yv[t][s4], Z[t]);
+                if (A.store && rok[t]) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (k + 4 * r < cnt) Zg[(size_t)(n0 + k + 4 * r) * R + rhs[t]] = Z[t][r];
+                }
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {        // w~[n0 + 4 s + k][16 mt + i]
+                const double wv = s_w[(4 * s4 + k) * LDT + 16 * mt + i];
+                const double wt = okK[s4] ? wv : 0.0;
+#pragma unroll
+                for (int t = 0; t < T; ++t) F[t][mt] = GF_MFMA64(wt, yv[t][s4], F[t][mt]);
+            }
+        n0 += cnt;
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (rok[t]) Fg[(size_t)(16 * mt + k + 4 * r) * R + rhs[t]] = F[t][mt][r];
+}
+#undef GF_MM_FETCH
+
 // Linear combine of the chunk states of a sweep: on entry F_state slot c holds chunk c's end
 // state from a zero start (local pass); on exit it holds the TRUE start state of chunk c.
 //   lower  : F_{c+1} = Fbar_c + Phi_c F_c            (ascending; Phi = true closed-loop transition)
@@ -4805,6 +4987,16 @@ int gf_chunk_linear(int mode, int B, int64_t N, int64_t chunk_len, int nch, int 
     hipStream_t st = (hipStream_t)stream;
     if (R == 1) {
         hipLaunchKernelGGL(k_lin1, dim3(B * nch), dim3(64), 0, st, A);
+    } else if (mode == GF_MATMUL_LOWER && R >= 16) {
+        // no feedback in this mode: blocks of 16 rows as matrix products (k_mmR_mfma)
+        const dim3 grid(B * nch, (R + 63) / 64);
+#define GF_MM_CASE(MTv) case MTv: if (store) hipLaunchKernelGGL((k_mmR_mfma<MTv, false>), grid, dim3(64), 0, st, A); \
+                                  else hipLaunchKernelGGL((k_mmR_mfma<MTv, true>), grid, dim3(64), 0, st, A); break;
+        switch ((W + 15) / 16) {
+            GF_MM_CASE(1) GF_MM_CASE(2) GF_MM_CASE(3) GF_MM_CASE(4)
+            default: return set_err("gf_chunk_linear: internal dispatch error%s", "");
+        }
+#undef GF_MM_CASE
     } else {
         const int rows = (W + 3) / 4 * 4;
         switch (rows) {

@@ -536,8 +536,9 @@ class ScaledFactor:
     def _mm_chunking(self, R):
         """Chunks for the dot_tril sweeps: ~2048 waves (two per SIMD) over B problems and the RHS
         tiles, at least 128 rows each, on multiples of 64 rows (every chunk starts on a reset row)."""
+        # (R >= 16 runs on the matrix pipe, one wave per SIMD: k_mmR_mfma)
         tiles = -(-R // 64) if R > 1 else 1
-        want = max(1, 2048 // (self.B * tiles))
+        want = max(1, (1024 if R >= 16 else 2048) // (self.B * tiles))
         chunk_len = max(128, -(-self.N // want))
         chunk_len = (chunk_len + 63) // 64 * 64
         return chunk_len, -(-self.N // chunk_len)

@@ -579,8 +579,9 @@ def test_scaled_factor_sweeps(hip, case):
     c, a, U, V = util.oracle_matrices(prob, seq)
     d_ref, W_ref, info = cref.factor(t, c, a, U, V)
     assert info == 0 and _relmax(fac.d[0].cpu().numpy(), d_ref) < 1e-9
+    assert float(fac.Ut[:, fac.W:].abs().max()) == 0.0 and float(fac.Wt[:, fac.W:].abs().max()) == 0.0
     rng = np.random.default_rng(3)
-    for R in (1, 5, 70):
+    for R in (1, 5, 16, 33, 70):        # (dot_tril: R >= 16 runs on the matrix pipe, k_mmR_mfma)
         Y = rng.normal(size=(N, R))
         Yd = torch.as_tensor(Y).cuda().reshape(1, N, R)
         assert _relmax(fac.solve_lower(Yd)[0].cpu().numpy(), cref.solve_lower(t, c, U, W_ref, Y)) < TOL_VEC
