@@ -2511,6 +2511,7 @@ struct LinArgs {
     int R;
 };
 
+constexpr int LIN1_AHEAD = 8;
 __global__ void __launch_bounds__(64) k_lin1(const LinArgs A) {
     const int lane = threadIdx.x, b = blockIdx.x;
     const int pr = b / A.nch, ch = b - pr * A.nch;
@@ -2527,35 +2528,73 @@ __global__ void __launch_bounds__(64) k_lin1(const LinArgs A) {
     const double cj = (lane < A.W) ? A.c[(size_t)pr * A.W + lane] : 0.0;
     const bool up = A.mode == GF_SOLVE_UPPER, mm = A.mode == GF_MATMUL_LOWER;
     double F = Fg[lane];
+    // Rows are fetched LIN1_AHEAD rows ahead of their use, LIN1_AHEAD at a time (the loads used to sit at
+    // their point of use: one memory round trip per row, 1.1 us -- the sweep itself is a DPP reduction and
+    // two FMAs per row).
+    constexpr int G = LIN1_AHEAD;
+    struct RowIn { double y, u, w, e, d; };
+    RowIn cur[G], nxt[G];
+    auto fetch = [&](RowIn (&q)[G], const int64_t s0) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            int64_t s = s0 + j;
+            if (s > rows - 1) s = rows - 1;
+            const int64_t n = up ? (rows - 1 - s) : s;
+            q[j].y = Yg[n];
+            q[j].u = Ug[(size_t)n * 64];
+            q[j].w = Wg[(size_t)n * 64];
+            q[j].e = eg[n];
+            q[j].d = A.scale ? dg[n] : 1.0;
+        }
+    };
+    fetch(nxt, 0);
     if (!up) {
         double carry = 0.0, wprev = 0.0;            // pending F += w~_{n-1} * carry
-        for (int64_t n = 0; n < rows; ++n) {
-            double yn = Yg[n];
-            if (A.scale) yn = mm ? yn * sqrt(dg[n]) : yn / dg[n];
-            const double de = eg[n];
-            F = fma(wprev, carry, F);
-            if (de >= 0.0) F *= fm_exp(-cj * de);
-            const double dot = wave_sum(Ug[(size_t)n * 64] * F);
-            const double zn = mm ? (yn + dot) : (yn - dot);
-            if (A.store && lane == 0) Zg[n] = zn;
-            carry = mm ? yn : zn;
-            wprev = Wg[(size_t)n * 64];
+        for (int64_t s0 = 0; s0 < rows; s0 += G) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) cur[j] = nxt[j];
+            fetch(nxt, s0 + G);
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int64_t n = s0 + j;
+                if (n < rows) {
+                    double yn = cur[j].y;
+                    if (A.scale) yn = mm ? yn * sqrt(cur[j].d) : yn / cur[j].d;
+                    const double de = cur[j].e;
+                    F = fma(wprev, carry, F);
+                    if (de >= 0.0) F *= fm_exp(-cj * de);
+                    const double dot = wave_sum(cur[j].u * F);
+                    const double zn = mm ? (yn + dot) : (yn - dot);
+                    if (A.store && lane == 0) Zg[n] = zn;
+                    carry = mm ? yn : zn;
+                    wprev = cur[j].w;
+                }
+            }
         }
         Fg[lane] = fma(wprev, carry, F);            // pending folded, decay left to the next chunk
     } else {
         // the state handed DOWN to this chunk already carries the decay of the boundary it crossed
         double carry = 0.0, uprev = 0.0, de_up = -1.0;      // row n+1's quantities
-        for (int64_t n = rows - 1; n >= 0; --n) {
-            double yn = Yg[n];
-            if (A.scale) yn = yn / dg[n];
-            F = fma(uprev, carry, F);
-            if (de_up >= 0.0) F *= fm_exp(-cj * de_up);
-            const double dot = wave_sum(Wg[(size_t)n * 64] * F);
-            const double zn = yn - dot;
-            if (A.store && lane == 0) Zg[n] = zn;
-            carry = zn;
-            uprev = Ug[(size_t)n * 64];
-            de_up = eg[n];
+        for (int64_t s0 = 0; s0 < rows; s0 += G) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) cur[j] = nxt[j];
+            fetch(nxt, s0 + G);
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int64_t n = rows - 1 - (s0 + j);
+                if (n >= 0) {
+                    double yn = cur[j].y;
+                    if (A.scale) yn = yn / cur[j].d;
+                    F = fma(uprev, carry, F);
+                    if (de_up >= 0.0) F *= fm_exp(-cj * de_up);
+                    const double dot = wave_sum(cur[j].w * F);
+                    const double zn = yn - dot;
+                    if (A.store && lane == 0) Zg[n] = zn;
+                    carry = zn;
+                    uprev = cur[j].u;
+                    de_up = cur[j].e;
+                }
+            }
         }
         F = fma(uprev, carry, F);
         if (de_up >= 0.0) F *= fm_exp(-cj * de_up);     // cross the chunk's first-row boundary

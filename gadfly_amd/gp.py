@@ -299,12 +299,15 @@ class GaussianProcess:
         self._size = N
         self._mean_value = self._mean(t)
         self._diag = np.zeros(N, dtype=np.float64)
+        self._diag_const = 0.0              # a scalar diagonal is made on the device, not uploaded
         if yerr is not None:
             if diag is not None:
                 raise ValueError("only one of 'diag' and 'yerr' can be provided")
             self._diag += np.broadcast_to(np.asarray(yerr, dtype=np.float64), (N,)) ** 2
+            self._diag_const = float(np.asarray(yerr, dtype=np.float64)) ** 2 if np.ndim(yerr) == 0 else None
         elif diag is not None:
             self._diag += np.broadcast_to(np.asarray(diag, dtype=np.float64), (N,))
+            self._diag_const = float(np.asarray(diag, dtype=np.float64)) if np.ndim(diag) == 0 else None
 
         self._do_compute(quiet)
 
@@ -348,7 +351,12 @@ class GaussianProcess:
         fast = None
         wide = None
         if W <= 63 or (len(co[0]) == 0 and W <= 176):
-            fast = StreamingBatch([co], self._t, np.zeros(self._size), diag=self._diag,
+            import torch
+            f64 = dict(dtype=torch.float64, device=self._device_of())
+            const = getattr(self, "_diag_const", None)
+            fast = StreamingBatch([co], self._t, torch.zeros((self._size,), **f64),
+                                  diag=(self._diag if const is None
+                                        else torch.full((self._size,), const, **f64)),
                                   device=self._device)
             if fast._wide_ok() and not fast._fused_ok():
                 # wide kernel (e.g. the 86-term solar kernel, W = 172): ONE pass of the fused wide sweep
