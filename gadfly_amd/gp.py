@@ -185,6 +185,7 @@ class GaussianProcess:
         self._factor = None
         self._fast = None
         self._t = None
+        self._t_dev = self._diag_dev = None
         self._mean_value = None
         self._diag = None
         self._size = None
@@ -299,6 +300,7 @@ class GaussianProcess:
         self._size = N
         self._mean_value = self._mean(t)
         self._diag = np.zeros(N, dtype=np.float64)
+        self._t_dev = self._diag_dev = None
         self._diag_const = 0.0              # a scalar diagonal is made on the device, not uploaded
         if yerr is not None:
             if diag is not None:
@@ -354,10 +356,12 @@ class GaussianProcess:
             import torch
             f64 = dict(dtype=torch.float64, device=self._device_of())
             const = getattr(self, "_diag_const", None)
-            fast = StreamingBatch([co], self._t, torch.zeros((self._size,), **f64),
-                                  diag=(self._diag if const is None
-                                        else torch.full((self._size,), const, **f64)),
-                                  device=self._device)
+            if self._t_dev is None:         # (recompute() with another kernel: t, diag are on the device already)
+                self._t_dev = torch.as_tensor(self._t).to(**f64)
+                self._diag_dev = (torch.as_tensor(self._diag).to(**f64) if const is None
+                                  else torch.full((self._size,), const, **f64))
+            fast = StreamingBatch([co], self._t_dev, torch.zeros((self._size,), **f64),
+                                  diag=self._diag_dev, device=self._device)
             if fast._wide_ok() and not fast._fused_ok():
                 # wide kernel (e.g. the 86-term solar kernel, W = 172): ONE pass of the fused wide sweep
                 # factorises and stores the factor in scaled form; solves run on it (engine.WideFactor)
