@@ -247,7 +247,10 @@ def test_wide_time_parallel(hip, J, N, L, kw):
     ll_seq = float(eng.log_likelihood()[0])
     ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y)
     assert info == 0 and abs(ll_seq - ref) <= RTOL_LL * abs(ref)
+    from gadfly_amd.engine import _TreeScanGraph
     ll_tp = float(eng.log_likelihood_time_parallel(chunk_len=L)[0])
+    # (the dense combine replays a captured HIP graph; an eager fall-back would hide a capture failure)
+    assert not _TreeScanGraph.disabled and len(_TreeScanGraph._cache) >= 1
     assert eng._wide_tp["nch"] > 1
     assert abs(ll_tp - ref) <= RTOL_LL * abs(ref), (ll_tp, ref)
     assert abs(ll_tp - ll_seq) <= 1e-10 * abs(ref)

@@ -560,8 +560,9 @@ def test_full_size_round_trip(hip):
     assert _relmax(a2, 2.5 * alpha) < 1e-10
 
 
-@pytest.mark.parametrize("case", [TP_CASES[0], TP_CASES[1], TP_CASES[4], TP_CASES[5]],
-                         ids=["solar6", "solar30", "solar30gaps", "mixed"])
+@pytest.mark.parametrize("case", [TP_CASES[0], TP_CASES[1], TP_CASES[4], TP_CASES[5],
+                                  ("solar", dict(J=12, N=2000), 256), ("solar", dict(J=20, N=2500, jitter_t=True), 128)],
+                         ids=["solar6", "solar30", "solar30gaps", "mixed", "solar12", "solar20jitter"])
 def test_scaled_factor_sweeps(hip, case):
     """Chunk-parallel triangular sweeps on the stored scaled factor against the oracle:
     solve_lower / solve_upper / apply_inverse / dot_tril, 1 and many right-hand sides."""
