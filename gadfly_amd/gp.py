@@ -50,11 +50,13 @@ class ConditionalDistribution:
         self.include_mean = include_mean
         self.kernel = kernel
         self._alpha = None
+        self._resid_dev = None
 
     def _get_alpha(self):
         if self._alpha is None:
             gp = self.gp
             resid = gp._to_device(self.y - gp._mean_value)
+            self._resid_dev = resid
             self._alpha = gp._engine.apply_inverse(resid.reshape(1, -1, 1))
         return self._alpha
 
@@ -63,6 +65,11 @@ class ConditionalDistribution:
         gp = self.gp
         alpha = self._get_alpha()
         if self.t is None and self.kernel is None:
+            if gp._diag_dev is not None:        # y - diag * alpha on the device: one array comes back
+                mu = (self._resid_dev - gp._diag_dev * alpha.reshape(-1)).cpu().numpy()
+                if self.include_mean:
+                    mu += gp._mean_value
+                return mu
             mu = self.y - gp._diag * alpha.reshape(-1).cpu().numpy()
             if not self.include_mean:
                 mu = mu - gp._mean_value
