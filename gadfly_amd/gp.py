@@ -360,7 +360,8 @@ class GaussianProcess:
         fast = None
         wide = None
         if W <= 63 or (len(co[0]) == 0 and W <= 176):
-            import torch
+            from . import _lib
+            torch = _lib.require_device()       # (fails loudly without a HIP device: no CPU path)
             f64 = dict(dtype=torch.float64, device=self._device_of())
             const = getattr(self, "_diag_const", None)
             if self._t_dev is None:         # (recompute() with another kernel: t, diag are on the device already)
