@@ -71,3 +71,32 @@ def test_dense_solve_rejects_bad_sizes(hip):
     assert hip.load().gf_dense_solve(1, 193, 2, hip.ptr(A), hip.ptr(B), None) != 0
     assert "unsupported" in hip.last_error()
     assert hip.load().gf_dense_solve(1, 0, 2, hip.ptr(A), hip.ptr(B), None) != 0
+
+
+@pytest.mark.parametrize("nch,W", [(11, 70), (16, 172), (3, 96)])
+def test_lft_tree_scan_against_sequential_application(hip, nch, W):
+    """The Blelloch scan over dense chunk maps (engine._lft_tree_scan: batched GEMMs on strided views +
+    gf_dense_solve, identity maps padding to a power of two) gives the start state of every chunk that
+    applying the maps one after the other gives; the captured-graph replay returns the same numbers."""
+    import torch
+    from gadfly_amd.engine import _lft_tree_scan, _lft_apply, _TreeScanGraph
+    g = torch.Generator(device="cuda").manual_seed(100 * nch + W)
+    kw = dict(dtype=torch.float64, device="cuda", generator=g)
+    Ph = 0.7 * torch.randn((nch, W, W), **kw) / W ** 0.5
+    L = torch.randn((nch, W, 6), **kw)
+    Xb = L @ L.transpose(1, 2) / 6
+    M = torch.randn((nch, W, 6), **kw)
+    G = -(M @ M.transpose(1, 2)) / 6
+    Yb = torch.randn((nch, W), **kw)
+    m = torch.randn((nch, W), **kw)
+    Xs, Ys = _lft_tree_scan(torch, Ph, G, Xb, Yb, m)
+    X = torch.zeros((1, W, W), dtype=torch.float64, device="cuda")
+    Y = torch.zeros((1, W), dtype=torch.float64, device="cuda")
+    for c in range(nch):
+        sx = float(X.abs().max()) + 1e-300
+        assert float((Xs[c] - X[0]).abs().max()) <= 1e-9 * max(sx, 1.0), c
+        assert float((Ys[c] - Y[0]).abs().max()) <= 1e-9 * max(float(Y.abs().max()), 1.0), c
+        X, Y = _lft_apply(torch, [a[c:c + 1] for a in (Ph, G, Xb, Yb, m)], X, Y)
+    Xg, Yg = _TreeScanGraph.run(torch, Ph, G, Xb, Yb, m)
+    assert not _TreeScanGraph.disabled
+    assert torch.equal(Xg, Xs) and torch.equal(Yg, Ys)
