@@ -263,7 +263,7 @@ class GaussianProcess:
 
     # ---- helpers ------------------------------------------------------------
     #: largest array (bytes) that goes through the pinned staging buffer on its way to the device
-    PIN_MAX_BYTES = 1 << 28
+    PIN_MAX_BYTES = 1 << 26
 
     def _to_device(self, x):
         """Host array -> float64 device tensor.  Arrays of the usual sizes (one or a few series) pass
