@@ -624,6 +624,7 @@ class WideFactor:
         _lib.check(rc, "gf_scaled_propagator")
         self._v1 = None
         self._Phi = None
+        self._chain = None
 
     def reduce(self, with_quad):
         """(loglike (B,), logdet (B,)) of the pass that built the factor (z = L^-1 of the owner's y)."""
@@ -658,6 +659,64 @@ class WideFactor:
             self._tp_bufs = None                        # the row scratch is no longer needed
         return self._Phi
 
+    def _chain_segments(self, up):
+        """The chunks' closed-loop transitions in sweep order (Phi_c ascending for the forward solve,
+        Phi_c^T descending for the backward one), cut into segments of L chunks (identity maps pad the
+        last one), with every segment's composed transition: (L, nseg, A (nseg, L, W, W), Psi (nseg, W, W)).
+        Built on first use, kept with the factor."""
+        if self._chain is None:
+            self._chain = {}
+        if up not in self._chain:
+            torch = self.torch
+            Phi = self._true_transitions()
+            A = Phi.transpose(1, 2).flip(0) if up else Phi
+            nch, W = self.nch, self.W
+            L = max(2, int(round(math.sqrt(nch / 2.0))))
+            nseg = -(-nch // L)
+            pad = nseg * L - nch
+            if pad:
+                eye = torch.eye(W, dtype=A.dtype, device=A.device).expand(pad, W, W)
+                A = torch.cat([A, eye])
+            A = A.contiguous().view(nseg, L, W, W)
+            Psi = A[:, 0]
+            for j in range(1, L):
+                Psi = torch.bmm(A[:, j], Psi)
+            self._chain[up] = (L, nseg, A, Psi.contiguous())
+        return self._chain[up]
+
+    def _chain_states(self, up, loc):
+        """True start state of every chunk from the chunks' local end states (one right-hand side):
+        x_{s+1} = loc_s + A_s x_s along the sweep.  Two levels -- every segment from a zero start (L batched
+        steps), the segments chained through their composed transitions (nseg steps), every segment again
+        from its true start (L batched steps) -- instead of nch dependent mat-vec launches (the Python loop
+        over 121 / 253 chunks was 2.0 / 4.2 ms of a 2.3 / 5.6 ms sweep at N = 1e5 / 1e6)."""
+        torch = self.torch
+        L, nseg, A, Psi = self._chain_segments(up)
+        nch, W = self.nch, self.W
+        if up:
+            loc = loc.flip(0)
+        pad = nseg * L - nch
+        if pad:
+            loc = torch.cat([loc, torch.zeros((pad, W), dtype=loc.dtype, device=loc.device)])
+        loc = loc.contiguous().view(nseg, L, W, 1)
+        e = torch.zeros((nseg, W, 1), dtype=loc.dtype, device=loc.device)
+        for j in range(L):                              # segment end states from a zero start
+            e = torch.baddbmm(loc[:, j], A[:, j], e)
+        cur = torch.zeros((W,), dtype=loc.dtype, device=loc.device)
+        starts = []
+        for s in range(nseg):                           # the segments' true start states
+            starts.append(cur)
+            if s + 1 < nseg:
+                cur = torch.addmv(e[s, :, 0], Psi[s], cur)
+        x = torch.stack(starts).unsqueeze(-1)
+        outs = []
+        for j in range(L):                              # every chunk's true start state
+            outs.append(x)
+            if j + 1 < L:
+                x = torch.baddbmm(loc[:, j], A[:, j], x)
+        out = torch.stack(outs, dim=1).view(nseg * L, W)[:nch]
+        return out.flip(0) if up else out
+
     def _mm_chunking(self):
         chunk_len = max(128, -(-self.N // 2048))
         chunk_len = (chunk_len + 63) // 64 * 64
@@ -683,19 +742,7 @@ class WideFactor:
             D[:, :W] = torch.exp(-span.view(nch, L).sum(dim=1)[:, None] * self.c.reshape(1, W))
             _lib.check(lib.gf_chunk_diag_scan(1, nch, ld, 1, p(D), p(F), st), "gf_chunk_diag_scan")
         else:
-            Phi = self._true_transitions()
-            loc = F[:, :W].clone()
-            cur = torch.zeros((W,), **f64)
-            if mode == _lib.GF_SOLVE_LOWER:
-                for c in range(nch):
-                    F[c, :W] = cur
-                    if c + 1 < nch:
-                        cur = torch.addmv(loc[c], Phi[c], cur)
-            else:
-                for c in range(nch - 1, -1, -1):
-                    F[c, :W] = cur
-                    if c > 0:
-                        cur = torch.addmv(loc[c], Phi[c].T, cur)
+            F[:, :W] = self._chain_states(mode == _lib.GF_SOLVE_UPPER, F[:, :W])
         _lib.check(lib.gf_solve_chunk(mode, 1, N, L, nch, W, ld, *rows, p(F), 1, st), "gf_solve_chunk")
         return Z
 
