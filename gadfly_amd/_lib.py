@@ -71,6 +71,7 @@ SIGNATURES = {
     "gf_loglike_finish": (_int, [_int, _i64] + [_vp] * 4 + [_vp]),
     "gf_solve": (_int, [_int, _int, _i64, _int, _int, _int] + [_vp] * 6 + [_vp]),
     "gf_solve_chunk": (_int, [_int, _int, _i64, _i64, _int, _int, _int] + [_vp] * 7 + [_int, _vp]),
+    "gf_solve_chunk_rhs": (_int, [_int, _int, _i64, _i64, _int, _int, _int, _int] + [_vp] * 7 + [_int, _vp]),
     "gf_chunk_diag_scan": (_int, [_int, _int, _int, _int, _vp, _vp, _vp]),
     "gf_cross_covariance": (_int, [_int, _i64, _int, _int, _int] + [_vp] * 6 + [_vp, _i64, _vp, _i64, _vp, _vp]),
     "gf_interp_work": (_i64, [_i64]),

@@ -3618,7 +3618,10 @@ __global__ void __launch_bounds__(64 * NWV) k_solve_rhs(const SolveArgs A) {
     static_assert(JB % 2 == 0 && JB <= 64, "column slice: even, at most one wave wide");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int b = blockIdx.y;
+    // (problem, chunk): nch = 1 is the whole series; chunk mode (F_state != nullptr) as in k_solve_vec --
+    // start state in, end state out (pending push folded; ascending sweeps apply a boundary's decay on
+    // entry, the descending one on exit), Z only when A.store
+    const int b = blockIdx.y / A.nch, ch = blockIdx.y - b * A.nch;
     const int r = blockIdx.x * 64 + lane;
     const int R = A.R;
     const bool rok = r < R;
@@ -3626,6 +3629,8 @@ __global__ void __launch_bounds__(64 * NWV) k_solve_rhs(const SolveArgs A) {
     const int64_t N = A.N;
     const int ld = A.ld;
     const size_t pb = (size_t)b * N;
+    const int64_t c0 = (int64_t)ch * A.chunk_len;
+    const int64_t L = (N - c0 < A.chunk_len) ? (N - c0) : A.chunk_len;
     const bool up = (A.mode == GF_SOLVE_UPPER);
     const bool mm = (A.mode == GF_MATMUL_LOWER);
     const double *__restrict__ push = (up ? A.U : A.Wm) + pb * ld;
@@ -3634,6 +3639,7 @@ __global__ void __launch_bounds__(64 * NWV) k_solve_rhs(const SolveArgs A) {
     const double *Y = A.Y + pb * R;     // (Z may alias Y: rows are read ahead of, never behind, the writes)
     const double *__restrict__ sc = A.scale ? A.scale + pb : nullptr;
     double *Z = A.Z + pb * R;
+    double *__restrict__ Fs = A.F_state ? A.F_state + (size_t)blockIdx.y * ld * R : nullptr;     // [ld][R]
     const int j0 = wave * JB;
     int jn = ld - j0;                    // valid columns in this wave's slice
     if (jn > JB) jn = JB;
@@ -3655,27 +3661,25 @@ __global__ void __launch_bounds__(64 * NWV) k_solve_rhs(const SolveArgs A) {
 
     double F[JB];
 #pragma unroll
-    for (int j = 0; j < JB; ++j) F[j] = 0.0;
-    auto row_of = [&](const int64_t s) { return up ? (N - 1 - s) : s; };
+    for (int j = 0; j < JB; ++j) F[j] = (Fs && j < jn) ? Fs[(size_t)(j0 + j) * R + rc] : 0.0;
+    auto row_of = [&](const int64_t s) { return up ? (c0 + L - 1 - s) : (c0 + s); };
     auto scaled = [&](const double yv, const double sv) {
         return sc ? (mm ? yv * sqrt(sv) : yv / sv) : yv;
     };
-    double carry;
-    {
-        const int64_t n = row_of(0);
-        const double yn = scaled(Y[(size_t)n * R + rc], sc ? sc[n] : 1.0);
-        if (rok && wave == 0) Z[(size_t)n * R + r] = yn;
-        carry = yn;
-    }
+    // the first row of the sweep carries nothing itself: the state handed over already holds the pending
+    // push of the row before it (zero at the very start)
+    double carry = 0.0;
     double rp[DEPTH], ra[DEPTH], rb[DEPTH], ry[DEPTH], rs[DEPTH];
+    auto clampN = [&](const int64_t n) { return n < 0 ? (int64_t)0 : (n > N - 1 ? N - 1 : n); };
     auto fetch = [&](const int slot, int64_t s) {
-        s = s < N ? s : N - 1;                      // past the end: re-read the last row, never used
+        s = s < L ? s : L - 1;                      // past the end: re-read the last row, never used
         const int64_t n = row_of(s);
-        const int64_t prev = up ? (n + 1) : (n - 1);
-        const int64_t prow = up ? (n + 1) : n;
+        const int64_t prev = clampN(up ? (n + 1) : (n - 1));    // (rows outside the series: multiplied by 0)
+        const int64_t prow = clampN(up ? (n + 1) : n);
         ry[slot] = Y[(size_t)n * R + rc];
         rs[slot] = sc ? sc[n + vz] : 1.0;
-        rp[slot] = Pg[(size_t)prow * ld + jc];
+        const bool entry = up && Fs != nullptr && s == 0;      // descending chunk entry: no decay here
+        rp[slot] = entry ? 1.0 : Pg[(size_t)prow * ld + jc];
         ra[slot] = push[(size_t)prev * ld + jc];
         rb[slot] = pull[(size_t)n * ld + jc];
     };
@@ -3707,14 +3711,14 @@ __global__ void __launch_bounds__(64 * NWV) k_solve_rhs(const SolveArgs A) {
             for (int w2 = 1; w2 < NWV; ++w2) dot += s_dot[buf][w2][lane];
         }
         const double zn = mm ? (yn + dot) : (yn - dot);
-        if (rok && wave == 0) Z[(size_t)n * R + r] = zn;
+        if (A.store && rok && wave == 0) Z[(size_t)n * R + r] = zn;
         carry = mm ? yn : zn;
     };
-    int64_t s0 = 1;
-    if (N - 1 >= DEPTH) {
+    int64_t s0 = 0;
+    if (L >= DEPTH) {
 #pragma unroll
-        for (int k = 0; k < DEPTH; ++k) fetch(k, 1 + k);
-        for (; s0 + DEPTH <= N; s0 += DEPTH) {
+        for (int k = 0; k < DEPTH; ++k) fetch(k, k);
+        for (; s0 + DEPTH <= L; s0 += DEPTH) {
 #pragma unroll
             for (int k = 0; k < DEPTH; ++k) {
                 process(s0 + k, rp[k], ra[k], rb[k], ry[k], rs[k]);
@@ -3722,9 +3726,21 @@ __global__ void __launch_bounds__(64 * NWV) k_solve_rhs(const SolveArgs A) {
             }
         }
     }
-    for (; s0 < N; ++s0) {                          // fewer than DEPTH rows left
+    for (; s0 < L; ++s0) {                          // fewer than DEPTH rows left
         fetch(0, s0);
         process(s0, rp[0], ra[0], rb[0], ry[0], rs[0]);
+    }
+    if (Fs) {                                       // end state: pending push folded, no decay
+        const int64_t last = row_of(L - 1);
+        wave_lds_fence();
+        sa[lane] = lok ? push[(size_t)last * ld + jc] : 0.0;
+        sp[lane] = (lok && up) ? Pg[(size_t)last * ld + jc] : 1.0;     // cross the chunk's first-row boundary
+        wave_lds_fence();
+        if (rok) {
+#pragma unroll
+            for (int j = 0; j < JB; ++j)
+                if (j < jn) Fs[(size_t)(j0 + j) * R + r] = sp[j] * fma(sa[j], carry, F[j]);
+        }
     }
 }
 
@@ -5143,6 +5159,20 @@ static void launch_solve_vec(const SolveArgs &A, int grid, hipStream_t st) {
 #undef GF_SV
 }
 
+// several right-hand sides: one workgroup per (tile of 64 right-hand sides, problem x chunk)
+static void launch_solve_rhs(const SolveArgs &A, int slots, hipStream_t st) {
+    const int ld = A.ld;
+    const dim3 grid((A.R + 63) / 64, slots);
+    if (ld <= 16)       hipLaunchKernelGGL((k_solve_rhs<16, 1>), grid, dim3(64), 0, st, A);
+    else if (ld <= 32)  hipLaunchKernelGGL((k_solve_rhs<32, 1>), grid, dim3(64), 0, st, A);
+    else if (ld <= 48)  hipLaunchKernelGGL((k_solve_rhs<48, 1>), grid, dim3(64), 0, st, A);
+    else if (ld <= 64)  hipLaunchKernelGGL((k_solve_rhs<64, 1>), grid, dim3(64), 0, st, A);
+    else if (ld <= 96)  hipLaunchKernelGGL((k_solve_rhs<48, 2>), grid, dim3(128), 0, st, A);
+    else if (ld <= 128) hipLaunchKernelGGL((k_solve_rhs<64, 2>), grid, dim3(128), 0, st, A);
+    else if (ld <= 192) hipLaunchKernelGGL((k_solve_rhs<48, 4>), grid, dim3(256), 0, st, A);
+    else                hipLaunchKernelGGL((k_solve_rhs<64, 4>), grid, dim3(256), 0, st, A);
+}
+
 // Chunk-parallel form of the one-right-hand-side sweeps of gf_solve (any width; what the wide stored
 // factor uses): local pass (F_state zeroed by the caller, store = 0) -> combine of the chunk states on the
 // caller's side (GF_MATMUL_LOWER: diagonal decays, gf_chunk_diag_scan; the solves: the chunks' closed-loop
@@ -5164,6 +5194,28 @@ int gf_solve_chunk(int mode, int B, int64_t N, int64_t chunk_len, int nch, int W
     A.chunk_len = chunk_len; A.nch = nch; A.store = store; A.F_state = F_state;
     launch_solve_vec(A, B * nch, (hipStream_t)stream);
     return check_launch("gf_solve_chunk");
+}
+
+// gf_solve_chunk with R right-hand sides (k_solve_rhs in chunk mode): Y, Z [B][N][R]; F_state
+// [B * nch][ld][R].  The combine between the two passes is the caller's (W x W chunk transitions applied to
+// W x R states: batched GEMMs).
+int gf_solve_chunk_rhs(int mode, int B, int64_t N, int64_t chunk_len, int nch, int W, int ld, int R,
+                       const double *U, const double *Wm, const double *P, const double *scale,
+                       const double *Y, double *Z, double *F_state, int store, void *stream) {
+    if (mode < 0 || mode > 2) return set_err("gf_solve_chunk_rhs: bad mode %s%lld", "", mode);
+    if (B < 1 || N < 1 || R < 1) return set_err("gf_solve_chunk_rhs: empty problem (N=%s%lld, R=%lld)", "", N, R);
+    if (W < 1 || W > GF_MAX_WIDTH) return set_err("gf_solve_chunk_rhs: width %s%lld unsupported (max %lld)", "", W, GF_MAX_WIDTH);
+    if (ld < W || (ld & 15)) return set_err("gf_solve_chunk_rhs: ld=%s%lld must be a multiple of 16 and >= W=%lld", "", ld, W);
+    if (nch < 1 || chunk_len < 1 || (int64_t)nch * chunk_len < N || (int64_t)(nch - 1) * chunk_len >= N)
+        return set_err("gf_solve_chunk_rhs: bad chunking (chunk_len=%s%lld, nch=%lld)", "", chunk_len, nch);
+    if (!U || !Wm || !P || !Y || !Z || !F_state) return set_err("gf_solve_chunk_rhs: null pointer%s", "");
+    if ((int64_t)B * nch > 65535) return set_err("gf_solve_chunk_rhs: too many chunks (B * nch = %s%lld > 65535)", "", (int64_t)B * nch);
+    SolveArgs A;
+    A.N = N; A.W = W; A.ld = ld; A.R = R; A.mode = mode;
+    A.U = U; A.Wm = Wm; A.P = P; A.scale = scale; A.Y = Y; A.Z = Z;
+    A.chunk_len = chunk_len; A.nch = nch; A.store = store; A.F_state = F_state;
+    launch_solve_rhs(A, B * nch, (hipStream_t)stream);
+    return check_launch("gf_solve_chunk_rhs");
 }
 
 // Scan of chunk states with DIAGONAL transitions: F_state slot c [rows][R] <- true start state of chunk c
@@ -5195,15 +5247,7 @@ int gf_solve(int mode, int B, int64_t N, int W, int ld, int R,
     if (R == 1) {
         launch_solve_vec(A, B, st);
     } else {
-        const dim3 grid((R + 63) / 64, B);
-        if (ld <= 16)       hipLaunchKernelGGL((k_solve_rhs<16, 1>), grid, dim3(64), 0, st, A);
-        else if (ld <= 32)  hipLaunchKernelGGL((k_solve_rhs<32, 1>), grid, dim3(64), 0, st, A);
-        else if (ld <= 48)  hipLaunchKernelGGL((k_solve_rhs<48, 1>), grid, dim3(64), 0, st, A);
-        else if (ld <= 64)  hipLaunchKernelGGL((k_solve_rhs<64, 1>), grid, dim3(64), 0, st, A);
-        else if (ld <= 96)  hipLaunchKernelGGL((k_solve_rhs<48, 2>), grid, dim3(128), 0, st, A);
-        else if (ld <= 128) hipLaunchKernelGGL((k_solve_rhs<64, 2>), grid, dim3(128), 0, st, A);
-        else if (ld <= 192) hipLaunchKernelGGL((k_solve_rhs<48, 4>), grid, dim3(256), 0, st, A);
-        else                hipLaunchKernelGGL((k_solve_rhs<64, 4>), grid, dim3(256), 0, st, A);
+        launch_solve_rhs(A, B, st);
     }
     return check_launch("gf_solve");
 }

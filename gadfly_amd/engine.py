@@ -693,29 +693,35 @@ class WideFactor:
         torch = self.torch
         L, nseg, A, Psi = self._chain_segments(up)
         nch, W = self.nch, self.W
+        vec = loc.ndim == 2                             # (nch, W), or (nch, W, R) for R right-hand sides
+        if vec:
+            loc = loc.unsqueeze(-1)
+        R = loc.shape[-1]
         if up:
             loc = loc.flip(0)
         pad = nseg * L - nch
         if pad:
-            loc = torch.cat([loc, torch.zeros((pad, W), dtype=loc.dtype, device=loc.device)])
-        loc = loc.contiguous().view(nseg, L, W, 1)
-        e = torch.zeros((nseg, W, 1), dtype=loc.dtype, device=loc.device)
+            loc = torch.cat([loc, torch.zeros((pad, W, R), dtype=loc.dtype, device=loc.device)])
+        loc = loc.contiguous().view(nseg, L, W, R)
+        e = torch.zeros((nseg, W, R), dtype=loc.dtype, device=loc.device)
         for j in range(L):                              # segment end states from a zero start
             e = torch.baddbmm(loc[:, j], A[:, j], e)
-        cur = torch.zeros((W,), dtype=loc.dtype, device=loc.device)
+        cur = torch.zeros((W, R), dtype=loc.dtype, device=loc.device)
         starts = []
         for s in range(nseg):                           # the segments' true start states
             starts.append(cur)
             if s + 1 < nseg:
-                cur = torch.addmv(e[s, :, 0], Psi[s], cur)
-        x = torch.stack(starts).unsqueeze(-1)
+                cur = torch.addmm(e[s], Psi[s], cur)
+        x = torch.stack(starts)
         outs = []
         for j in range(L):                              # every chunk's true start state
             outs.append(x)
             if j + 1 < L:
                 x = torch.baddbmm(loc[:, j], A[:, j], x)
-        out = torch.stack(outs, dim=1).view(nseg * L, W)[:nch]
-        return out.flip(0) if up else out
+        out = torch.stack(outs, dim=1).view(nseg * L, W, R)[:nch]
+        if up:
+            out = out.flip(0)
+        return out.squeeze(-1) if vec else out
 
     def _mm_chunking(self):
         chunk_len = max(128, -(-self.N // 2048))
@@ -756,6 +762,20 @@ class WideFactor:
         st = torch.cuda.current_stream(self.device).cuda_stream
         if R == 1 and B == 1 and self.time_parallel and self.nch > 1:
             return self._sweep_chunked(mode, Y, scale, Z)
+        if (B == 1 and self.time_parallel and self.nch > 1 and mode != _lib.GF_MATMUL_LOWER
+                and self.nch <= 65535):
+            # several right-hand sides (conditional variance / covariance): the same three steps with
+            # W x R chunk states (k_solve_rhs in chunk mode, the chain as batched GEMMs)
+            lib = self.lib
+            N, W, ld, L, nch = self.N, self.W, self.ld, self.chunk_len, self.nch
+            F = torch.zeros((nch, ld, R), dtype=torch.float64, device=self.device)
+            rows = (p(self.Ut), p(self.Wt), p(self.P), p(scale), p(Y), p(Z))
+            _lib.check(lib.gf_solve_chunk_rhs(mode, 1, N, L, nch, W, ld, R, *rows, p(F), 0, st),
+                       "gf_solve_chunk_rhs")
+            F[:, :W] = self._chain_states(mode == _lib.GF_SOLVE_UPPER, F[:, :W])
+            _lib.check(lib.gf_solve_chunk_rhs(mode, 1, N, L, nch, W, ld, R, *rows, p(F), 1, st),
+                       "gf_solve_chunk_rhs")
+            return Z
         rc = self.lib.gf_solve(mode, B, N, self.W, self.ld, R, p(self.Ut), p(self.Wt), p(self.P),
                                p(scale), p(Y), p(Z), st)
         _lib.check(rc, "gf_solve")

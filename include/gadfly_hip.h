@@ -331,6 +331,12 @@ int gf_solve(int mode, int B, int64_t N, int W, int ld, int R,
 int gf_solve_chunk(int mode, int B, int64_t N, int64_t chunk_len, int nch, int W, int ld,
                    const double *U, const double *Wm, const double *P, const double *scale,
                    const double *Y, double *Z, double *F_state, int store, void *stream);
+/* The same with R right-hand sides (Y, Z [B][N][R]; F_state [B * nch][ld][R]; B * nch <= 65535): the
+ * conditional variance / covariance on a wide stored factor (celerite2: solve_lower / solve_upper with a
+ * matrix right-hand side, /root/reference/gadfly/gp.py:295-304 through ConditionalDistribution). */
+int gf_solve_chunk_rhs(int mode, int B, int64_t N, int64_t chunk_len, int nch, int W, int ld, int R,
+                       const double *U, const double *Wm, const double *P, const double *scale,
+                       const double *Y, double *Z, double *F_state, int store, void *stream);
 int gf_chunk_diag_scan(int B, int nch, int rows, int R, const double *D, double *F_state, void *stream);
 
 /*

@@ -266,6 +266,13 @@ def test_wide_time_parallel(hip, J, N, L, kw):
     ref_ai = cref.solve_upper(t, c, U, W_ref, cref.solve_lower(t, c, U, W_ref, Y) / d_ref[:, None])
     got = fac.apply_inverse(torch.as_tensor(Y).cuda().reshape(1, n, 2))[0].cpu().numpy()
     assert _relmax(got, ref_ai) < TOL_VEC
+    # several right-hand sides are chunk-parallel too (k_solve_rhs in chunk mode, W x R states chained as
+    # batched GEMMs): two tiles of right-hand sides, both sweeps
+    Y70 = np.random.default_rng(J + 1).normal(size=(n, 70))
+    Y70d = torch.as_tensor(Y70).cuda().reshape(1, n, 70)
+    assert _relmax(fac.solve_lower(Y70d)[0].cpu().numpy(), cref.solve_lower(t, c, U, W_ref, Y70)) < TOL_VEC
+    assert _relmax(fac.solve_upper(Y70d)[0].cpu().numpy(), cref.solve_upper(t, c, U, W_ref, Y70)) < TOL_VEC
+    assert torch.equal(Y70d, torch.as_tensor(Y70).cuda().reshape(1, n, 70))       # inputs untouched
     # ONE right-hand side takes the chunk-parallel sweeps (gf_solve_chunk): local pass, combine through the
     # TRUE factor's chunk transitions (the solves) / the diagonal decays (dot_tril), final pass
     assert fac.nch > 1
