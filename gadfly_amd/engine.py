@@ -17,6 +17,7 @@ HBM layout (float64, row-major, all torch tensors on one device):
 """
 import functools
 import math
+import threading
 
 import numpy as np
 
@@ -395,6 +396,7 @@ class _TreeScanGraph:
     happen on the caller's stream)."""
 
     _cache = {}
+    _lock = threading.Lock()            # the cached graphs own fixed in / out buffers: one scan at a time
     MAX_ENTRIES = 4
     disabled = False
 
@@ -423,7 +425,13 @@ class _TreeScanGraph:
 
     @classmethod
     def run(cls, torch, Ph, G, Xb, Yb, m):
-        """The scan through a cached graph; eager when capture is unavailable."""
+        """The scan through a cached graph; eager when capture is unavailable.  The returned views of the
+        graph's output buffers are valid until the next scan of the same shape on this device."""
+        with cls._lock:
+            return cls._run_locked(torch, Ph, G, Xb, Yb, m)
+
+    @classmethod
+    def _run_locked(cls, torch, Ph, G, Xb, Yb, m):
         if cls.disabled:
             return _lft_tree_scan(torch, Ph, G, Xb, Yb, m)
         key = (Ph.device.index, Ph.shape[0], Ph.shape[-1])
