@@ -54,7 +54,7 @@ class ConditionalDistribution:
     def _get_alpha(self):
         if self._alpha is None:
             gp = self.gp
-            resid = gp._to_device(self.y - gp._mean_value)
+            resid = gp._resid_to_device(self.y)
             self._alpha = gp._engine.apply_inverse(resid.reshape(1, -1, 1))
         return self._alpha
 
@@ -265,6 +265,21 @@ class GaussianProcess:
     #: largest array (bytes) that goes through the pinned staging buffer on its way to the device
     PIN_MAX_BYTES = 1 << 26
 
+    def _resid_to_device(self, y):
+        """``y - mean`` as a device tensor: the subtraction writes straight into the page-locked staging
+        buffer (one pass over y instead of a temporary, a copy and an upload from pageable memory)."""
+        import torch
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        n = y.size
+        if y.ndim != 1 or not (0 < n * 8 <= self.PIN_MAX_BYTES):
+            return self._to_device(y - self._mean_value)
+        pin = getattr(self, "_pin", None)
+        if pin is None or pin.numel() < n:
+            pin = self._pin = torch.empty((n,), dtype=torch.float64, pin_memory=True)
+        stage = pin[:n]
+        np.subtract(y, self._mean_value, out=stage.numpy())
+        return stage.to(self._device_of())
+
     def _to_device(self, x):
         """Host array -> float64 device tensor.  Arrays of the usual sizes (one or a few series) pass
         through ONE reusable page-locked buffer: a copy straight from a freshly allocated pageable array
@@ -452,9 +467,9 @@ class GaussianProcess:
         Z = self._engine.dot_tril(Y)
         return self._to_host(Z.reshape(y.shape))
 
-    def _do_norm(self, y):
+    def _do_norm(self, y, resid=False):
         eng = self._engine
-        Y = self._to_device(y).reshape(1, self._size, 1)
+        Y = (self._resid_to_device(y) if resid else self._to_device(y)).reshape(1, self._size, 1)
         z = eng.solve_lower(Y).reshape(-1)
         return float((z * z / eng.d[0]).sum().item())
 
@@ -488,7 +503,7 @@ class GaussianProcess:
             self._fast.set_y(y - self._mean_value)
             out, _ = self._fast.evaluate()
             return float(out[0].item())
-        return -0.5 * self._do_norm(y - self._mean_value) - self._norm
+        return -0.5 * self._do_norm(y, resid=True) - self._norm
 
     def apply_inverse(self, y, *, inplace=False):
         """``K^-1 y`` (the mean is not applied)."""
