@@ -15,7 +15,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(CSRC, "libgadfly_hip.so")
-SOURCES = [os.path.join(CSRC, "gadfly_hip.hip")]
+SOURCES = [os.path.join(CSRC, "gadfly_hip.hip"), os.path.join(CSRC, "gadfly_dense.hip")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "gadfly_hip.h")
 
 GF_SOLVE_LOWER, GF_SOLVE_UPPER, GF_MATMUL_LOWER = 0, 1, 2
@@ -59,6 +59,14 @@ SIGNATURES = {
     "gf_chunk_linear_combine": (_int, [_int, _int, _i64, _i64, _int, _int, _int] + [_vp] * 5
                                 + [_vp]),
     "gf_dense_solve": (_int, [_int, _int, _int] + [_vp] * 2 + [_vp]),
+    "gf_dense_width": (_int, [_int]),
+    "gf_wide_combine_work": (_i64, [_int, _int, _int]),
+    "gf_wide_combine": (_int, [_int, _i64, _i64, _int, _int] + [_vp] * 6 + [_vp]),
+    "gf_wide_gram": (_int, [_int, _i64, _i64, _int, _int, _int] + [_vp] * 5 + [_vp]),
+    "gf_lft_tree_work": (_i64, [_int, _int, _int]),
+    "gf_lft_tree_scan": (_int, [_int, _int, _int] + [_vp] * 8 + [_vp]),
+    "gf_bgemm": (_int, [_int, _int, _int, _int, _int, _int, _vp, _int, _i64, _vp, _int, _i64,
+                        _vp, _int, _i64, _vp, _int, _i64, _vp]),
     "gf_chunk_segment_transitions": (_int, [_int, _int, _int] + [_vp] * 2 + [_vp]),
     "gf_chunk_linear_combine_seg": (_int, [_int, _int, _int, _int, _int] + [_vp] * 4 + [_vp]),
     "gf_chunk_transition": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int, _int] + [_vp] * 7
@@ -91,20 +99,34 @@ class GadflyHipError(RuntimeError):
     """Raised when the native library is missing or reports an argument/launch error."""
 
 
+HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"]
+_DEPS = [HEADER, os.path.join(CSRC, "fastmath.h"), os.path.join(CSRC, "gf_internal.h")]
+
+
 def hipcc_command(out=SO_PATH):
-    return ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-            "-o", out] + SOURCES
+    """The one-shot form of the build (what `build()` does per translation unit, then links)."""
+    return ["hipcc"] + HIPCC_FLAGS + ["-shared", "-o", out] + SOURCES
 
 
 def build(force=False, verbose=False):
-    """Compile the HIP library for gfx950 in-tree (cross-compiles without a GPU)."""
-    newest = max(os.path.getmtime(p) for p in SOURCES + [HEADER, os.path.join(CSRC, "fastmath.h")])
-    if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= newest:
-        return SO_PATH
-    cmd = hipcc_command()
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    """Compile the HIP library for gfx950 in-tree (cross-compiles without a GPU): one object per
+    translation unit (rebuilt only when its source or a shared header changed), then the link."""
+    deps = max(os.path.getmtime(p) for p in _DEPS)
+    objs, relink = [], force or not os.path.exists(SO_PATH)
+    for src in SOURCES:
+        obj = os.path.splitext(src)[0] + ".o"
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), deps):
+            cmd = ["hipcc"] + HIPCC_FLAGS + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            relink = True
+    if relink or os.path.getmtime(SO_PATH) < max(os.path.getmtime(o) for o in objs):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", SO_PATH] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return SO_PATH
 
 

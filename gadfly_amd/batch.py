@@ -105,6 +105,7 @@ class BatchedLogLikelihood:
         self._unresolved = []
         #: evaluations repeated with exact generator rows by the guard so far
         self.guard_reruns = 0
+        self._last_cond = None
 
     @property
     def B(self):
@@ -142,17 +143,18 @@ class BatchedLogLikelihood:
         # small batches of long series are chunked in time as well (exact, see engine.evaluate)
         out = eng.evaluate()[0]
         period = int(eng.generator_period)
-        if period > 1 and (eng._fused_ok() or eng._wide_ok()):
-            torch = eng.torch
-            acc = eng._tp["acc"] if getattr(eng, "_tp_used", False) else eng.acc
-            if getattr(eng, "_last_wide_tp", False):
-                acc = eng._wide_tp["acc"]
+        if eng._fused_ok() or eng._wide_ok():
+            acc = eng.last_acc()
             amax = eng._pack[2] if eng.diag is None else eng._pack[2] + eng._diag_amax
-            # a non-positive pivot (failed factorisation: -inf either way) is not an accuracy case
-            flag = (eng.GEN_ERR * period * amax > self.generator_target * acc[:, 2]) & (acc[:, 2] > 0)
-            self._unresolved.append((out, flag, eng._pack, period))
-            if len(self._unresolved) > 64:      # bound the backlog of a caller that never resolves
-                self.resolve()
+            # min pivot and largest diagonal of THIS evaluation (what calibrate() looks at; the
+            # engine's own state may belong to a guard rerun of an older pack by then)
+            self._last_cond = (acc[:, 2].clone(), amax)
+            if period > 1:
+                # a non-positive pivot (failed factorisation: -inf either way) is not an accuracy case
+                flag = (eng.GEN_ERR * period * amax > self.generator_target * acc[:, 2]) & (acc[:, 2] > 0)
+                self._unresolved.append((out, flag, eng._pack, period))
+                if len(self._unresolved) > 64:      # bound the backlog of a caller that never resolves
+                    self.resolve()
         return out
 
     def resolve(self):
@@ -170,7 +172,9 @@ class BatchedLogLikelihood:
         for (out, flag, pack, _), hit in zip(pending, flags):
             if not hit.any():
                 continue
-            eng.use_coefficients(pack)
+            # (the pack is switched directly: use_coefficients() would also drop the engine's
+            # construction-time coefficient list, which the stored-factor classes still need)
+            eng._pack = pack
             eng.generator_period = 1
             exact = eng.evaluate()[0]
             out.copy_(torch.where(flag, exact, out))
@@ -186,14 +190,25 @@ class BatchedLogLikelihood:
         if self.auto_generator_period:
             # the result copy synchronised anyway: adapt the generator period of the NEXT
             # evaluation to the conditioning just seen (hyperparameters move slowly in a sampler)
-            self.engine.calibrate_generator(self.generator_target)
+            self._calibrate_last()
         return res
+
+    def _calibrate_last(self):
+        """(condition, period) from the min pivots of the last evaluation enqueued HERE."""
+        eng = self.engine
+        if self._last_cond is None:
+            return eng.calibrate_generator(self.generator_target)
+        dmin, amax = self._last_cond
+        dmin = float(dmin.min().item())
+        cond = float(amax.max().item()) / dmin if dmin > 0.0 else float("inf")
+        eng.generator_period = eng.period_for_condition(cond, self.generator_target)
+        return cond, eng.generator_period
 
     def calibrate(self):
         """After asynchronous evaluations (:meth:`evaluate_device`): set the generator period
         from the condition estimate of the last one.  Returns (condition, period)."""
         self.resolve()
-        return self.engine.calibrate_generator(self.generator_target)
+        return self._calibrate_last()
 
 
 def log_likelihood_batch(kernels, t, y, yerr=None, diag=None, mean=0.0, device=None):

@@ -1,0 +1,713 @@
+// gadfly_dense.hip -- the DENSE part of the time-parallel factorisation of wide kernels (64 <= W <= 176)
+//
+// A chunk of the time axis maps its start state (X, Y) to its end state by a linear-fractional
+// transformation M = (Phi, G, Xbar, Ybar, m):
+//     X+ = Xbar + Phi K Phi^T,  K = (I - X G)^-1 X ;   Y+ = Ybar + Phi (I - X G)^-1 (Y - X m)
+// and two maps compose into one (M2 after M1, D = (I - X1 G2)^-1):
+//     Phi = Phi2 D Phi1 ;  X = X2 + Phi2 D X1 Phi2^T ;  G = G1 + Phi1^T G2 D Phi1
+//     v = D (Y1 - X1 m2) ;  Y = Y2 + Phi2 v ;  m = m1 + Phi1^T (m2 - G2 v)
+// so the true start states of all chunks come from an exclusive scan over the chunk maps.  For wide
+// kernels the maps are W x W matrices and every step is GEMM-shaped -- the one place of the path where
+// the FP64 matrix pipe pays.  This file holds that scan as hand-written kernels:
+//   k_jobs        a launch = up to 8 "jobs" over a batch of map pairs: 64 x 64 output tiles of batched
+//                 GEMMs on v_mfma_f64_16x16x4 (operands staged through LDS, K-steps of 16, register
+//                 double buffering; epilogues I - AB, D + AB, and D + AB computed on the upper
+//                 triangle and mirrored -- exactly symmetric results at half the tiles), the scan's
+//                 mat-vecs, and strided copies
+//   k_wide_gram   G_c = sum_n h_n h_n^T / d_n, m_c = sum_n h_n z_n / d_n of a chunk: one workgroup per
+//                 chunk, one wave per 16-row strip of G, the rows h_n read ONCE through LDS
+//   k_lft_pack / k_lft_unpack   sweep-state layout ([column][row], k_factorw / k_phiw) <-> dense maps
+// The one solve per tree level is gf_dense_solve (k_dense_solve, gadfly_hip.hip).
+//
+// Reference being replaced: celerite2's sequential `factor` reached from gadfly/gp.py:202 (`compute`)
+// with the reference's default kernel (gadfly/core.py:430-461, 86 terms, W = 172).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+#include "../../include/gadfly_hip.h"
+#include "gf_internal.h"
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+#define GF_MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+// v_mfma_f64_16x16x4 operand layout (tools/microbench/mfma_f64_layout.hip): lane (i, k) = (lane & 15,
+// lane >> 4) supplies A[i][k] and B[k][i]; accumulator register r of that lane is D[k + 4 r][i].
+
+constexpr int GT_LD = 80;               // LDS row stride of a 16 x 64 operand tile: rows k, k + 1 land 32
+                                        // banks apart, so one ds_read_b64 of 32 lanes is conflict-free
+constexpr int GT_TILE = 16 * GT_LD;     // doubles per operand tile
+
+__device__ __forceinline__ double wave_sum_x(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// One K-step (16 deep) of a 64-wide operand strip into registers, 4 doubles per thread (256 threads).
+//   KCONTIG: element (x, k) at p[x * ld + k]  (thread: x = tid / 4, four consecutive k)
+//   else   : element (x, k) at p[k * ld + x]  (thread: k = tid / 16, four consecutive x)
+// Out-of-range elements are zero.
+template <bool KCONTIG>
+__device__ __forceinline__ void gt_fetch(double (&v)[4], const double *__restrict__ p, const int ld,
+                                         const int x0, const int xlim, const int kb, const int K,
+                                         const int tid) {
+    const int x = KCONTIG ? x0 + (tid >> 2) : x0 + 4 * (tid & 15);
+    const int k = KCONTIG ? kb + 4 * (tid & 3) : kb + (tid >> 4);
+    const double *q = p + (size_t)(KCONTIG ? x : k) * ld + (KCONTIG ? k : x);
+    const bool all = KCONTIG ? (x < xlim && k + 3 < K) : (k < K && x + 3 < xlim);
+    if (all && ((reinterpret_cast<uintptr_t>(q) & 15) == 0)) {
+        const double2 a = reinterpret_cast<const double2 *>(q)[0], b = reinterpret_cast<const double2 *>(q)[1];
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = KCONTIG ? (x < xlim && k + e < K) : (k < K && x + e < xlim);
+            v[e] = ok ? q[e] : 0.0;
+        }
+    }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void gt_stash(double *S, const double (&v)[4], const int tid) {
+    if (KCONTIG) {
+        const int x = tid >> 2, k = 4 * (tid & 3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S[(k + e) * GT_LD + x] = v[e];
+    } else {
+        const int k = tid >> 4, x = 4 * (tid & 15);
+        reinterpret_cast<double2 *>(S + k * GT_LD + x)[0] = double2{v[0], v[1]};
+        reinterpret_cast<double2 *>(S + k * GT_LD + x)[1] = double2{v[2], v[3]};
+    }
+}
+
+// C tile (rows i0 .. i0 + 63, columns j0 .. j0 + 63) of op(A) (M x K) op(B) (K x N), row-major operands:
+// op(A)(i, k) = TA ? A[k lda + i] : A[i lda + k];  op(B)(k, j) = TB ? B[j ldb + k] : B[k ldb + j].
+// 256 threads: wave w owns rows i0 + 16 w .. + 15 as four 16 x 16 accumulator tiles.  epi(row, col, value)
+// is called for every in-range element.
+template <bool TA, bool TB, class Epi>
+__device__ __forceinline__ void gemm_tile(const double *__restrict__ A, const int lda,
+                                          const double *__restrict__ B, const int ldb, const int M,
+                                          const int N, const int K, const int i0, const int j0,
+                                          double *lds, Epi epi) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    double *As = lds, *Bs = lds + 2 * GT_TILE;
+    const int left = (N - j0 + 15) >> 4;
+    const int nct = left < 4 ? left : 4;            // live 16-column tiles
+    const bool rows_live = i0 + 16 * w < M;
+    d4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+    double va[4], vb[4];
+    gt_fetch<!TA>(va, A, lda, i0, M, 0, K, tid);
+    gt_fetch<TB>(vb, B, ldb, j0, N, 0, K, tid);
+    gt_stash<!TA>(As, va, tid);
+    gt_stash<TB>(Bs, vb, tid);
+    __syncthreads();
+    int cur = 0;
+    for (int kb = 0; kb < K; kb += 16) {
+        const bool more = kb + 16 < K;
+        if (more) {                                 // the next step's operands travel during the MFMAs
+            gt_fetch<!TA>(va, A, lda, i0, M, kb + 16, K, tid);
+            gt_fetch<TB>(vb, B, ldb, j0, N, kb + 16, K, tid);
+        }
+        if (rows_live) {
+            const double *a = As + cur * GT_TILE + 16 * w + li, *b = Bs + cur * GT_TILE + li;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double av = a[(4 * ks + lk) * GT_LD];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < nct) acc[q] = GF_MFMA64(av, b[(4 * ks + lk) * GT_LD + 16 * q], acc[q]);
+            }
+        }
+        if (more) {
+            gt_stash<!TA>(As + (cur ^ 1) * GT_TILE, va, tid);
+            gt_stash<TB>(Bs + (cur ^ 1) * GT_TILE, vb, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (rows_live) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q >= nct) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + 16 * w + lk + 4 * r, col = j0 + 16 * q + li;
+                if (row < M && col < N) epi(row, col, acc[q][r]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// job launches
+// ------------------------------------------------------------------------------------------------
+enum { JOB_GEMM = 0, JOB_MATVEC = 1, JOB_COPY = 2 };
+enum { EPI_PLAIN = 0,       // C = AB
+       EPI_IMINUS = 1,      // C = I - AB
+       EPI_ADD = 2,         // C = D + AB
+       EPI_ADD_SYMU = 3 };  // C = D + AB on the upper triangle, mirrored (tiles with tn >= tm only)
+
+struct Job {
+    const double *A, *B, *D;
+    double *C;
+    long long sA, sB, sC, sD;           // batch strides (elements)
+    double s;
+    int type, first;                    // `first`: first blockIdx.x of the job
+    int M, N, K, lda, ldb, ldc, ldd;
+    int ta, tb, epi, tn;                // tn: tiles per dimension (GEMM) / blocks (COPY)
+};
+constexpr int MAX_JOBS = 8;
+struct JobTable {
+    int njobs, nblocks;
+    Job j[MAX_JOBS];
+};
+
+// y[i] = a[i] + s sum_k Mat(i, k) x[k inc_x],  i < n, k < kn;  Mat(i, k) = trans ? Mt[k ld + i] : Mt[i ld + k]
+__device__ __forceinline__ void job_matvec(const Job &J, const double *Mt, const double *x, const double *a,
+                                           double *y) {
+    const int tid = threadIdx.x, n = J.M, kn = J.K, ld = J.lda, incx = J.ldb, incy = J.ldc;
+    if (J.ta) {                         // lanes along i: coalesced rows of Mt
+        for (int i = tid; i < n; i += 256) {
+            double a0 = 0.0, a1 = 0.0;
+            int k = 0;
+            for (; k + 1 < kn; k += 2) {
+                a0 = fma(Mt[(size_t)k * ld + i], x[(size_t)k * incx], a0);
+                a1 = fma(Mt[(size_t)(k + 1) * ld + i], x[(size_t)(k + 1) * incx], a1);
+            }
+            if (k < kn) a0 = fma(Mt[(size_t)k * ld + i], x[(size_t)k * incx], a0);
+            y[(size_t)i * incy] = fma(J.s, a0 + a1, a ? a[i] : 0.0);
+        }
+    } else {                            // one wave per row, lanes along k
+        const int lane = tid & 63, w = tid >> 6;
+        for (int i = w; i < n; i += 4) {
+            double p = 0.0;
+            for (int k = lane; k < kn; k += 64) p = fma(Mt[(size_t)i * ld + k], x[(size_t)k * incx], p);
+            p = wave_sum_x(p);
+            if (lane == 0) y[(size_t)i * incy] = fma(J.s, p, a ? a[i] : 0.0);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_jobs(const JobTable T) {
+    __shared__ __attribute__((aligned(16))) double lds[4 * GT_TILE];
+    Job J = T.j[0];
+#pragma unroll
+    for (int q = 1; q < MAX_JOBS; ++q)              // (constant indices: the table stays in the kernarg segment)
+        if (q < T.njobs && (int)blockIdx.x >= T.j[q].first) J = T.j[q];
+    const int t = (int)blockIdx.x - J.first;
+    const long long bi = blockIdx.y;
+    const double *A = J.A ? J.A + bi * J.sA : nullptr;
+    const double *B = J.B ? J.B + bi * J.sB : nullptr;
+    const double *D = J.D ? J.D + bi * J.sD : nullptr;
+    double *C = J.C + bi * J.sC;
+    if (J.type == JOB_MATVEC) {
+        job_matvec(J, A, B, D, C);
+        return;
+    }
+    if (J.type == JOB_COPY) {                       // rows M x columns N; A == nullptr: zeros
+        const long long tot = (long long)J.M * J.N;
+        for (long long e = (long long)t * 256 + threadIdx.x; e < tot; e += (long long)J.tn * 256) {
+            const int r = (int)(e / J.N), c = (int)(e - (long long)r * J.N);
+            C[(size_t)r * J.ldc + c] = A ? A[(size_t)r * J.lda + c] : 0.0;
+        }
+        return;
+    }
+    int tm, tn;
+    if (J.epi == EPI_ADD_SYMU) {                    // upper-triangular tiles, row by row
+        tm = 0;
+        int rem = t;
+        while (rem >= J.tn - tm) { rem -= J.tn - tm; ++tm; }
+        tn = tm + rem;
+    } else {
+        tm = t / J.tn;
+        tn = t - tm * J.tn;
+    }
+    const int epi = J.epi, ldc = J.ldc, ldd = J.ldd;
+    const bool diag_tile = tm == tn;
+    auto store = [&](const int row, const int col, const double v) {
+        if (epi == EPI_PLAIN) C[(size_t)row * ldc + col] = v;
+        else if (epi == EPI_IMINUS) C[(size_t)row * ldc + col] = ((row == col) ? 1.0 : 0.0) - v;
+        else if (epi == EPI_ADD) C[(size_t)row * ldc + col] = D[(size_t)row * ldd + col] + v;
+        else if (!diag_tile || col >= row) {
+            const double o = D[(size_t)row * ldd + col] + v;
+            C[(size_t)row * ldc + col] = o;
+            C[(size_t)col * ldc + row] = o;
+        }
+    };
+    if (!J.ta && !J.tb) gemm_tile<false, false>(A, J.lda, B, J.ldb, J.M, J.N, J.K, 64 * tm, 64 * tn, lds, store);
+    else if (!J.ta && J.tb) gemm_tile<false, true>(A, J.lda, B, J.ldb, J.M, J.N, J.K, 64 * tm, 64 * tn, lds, store);
+    else if (J.ta && !J.tb) gemm_tile<true, false>(A, J.lda, B, J.ldb, J.M, J.N, J.K, 64 * tm, 64 * tn, lds, store);
+    else gemm_tile<true, true>(A, J.lda, B, J.ldb, J.M, J.N, J.K, 64 * tm, 64 * tn, lds, store);
+}
+
+struct JobBuilder {
+    JobTable T;
+    JobBuilder() { T.njobs = 0; T.nblocks = 0; }
+    Job &add(int type, int nblocks) {
+        Job &j = T.j[T.njobs++];
+        memset(&j, 0, sizeof(j));
+        j.type = type;
+        j.first = T.nblocks;
+        T.nblocks += nblocks;
+        return j;
+    }
+    // C = epi(D, op(A) op(B)),  C: M x N, inner dimension K
+    void gemm(int ta, int tb, int epi, int M, int N, int K, const double *A, int lda, long long sA,
+              const double *B, int ldb, long long sB, const double *D, int ldd, long long sD, double *C,
+              int ldc, long long sC) {
+        const int tm = (M + 63) / 64, tn = (N + 63) / 64;
+        Job &j = add(JOB_GEMM, epi == EPI_ADD_SYMU ? tm * (tm + 1) / 2 : tm * tn);
+        j.ta = ta; j.tb = tb; j.epi = epi; j.M = M; j.N = N; j.K = K; j.tn = tn;
+        j.A = A; j.lda = lda; j.sA = sA; j.B = B; j.ldb = ldb; j.sB = sB;
+        j.D = D; j.ldd = ldd; j.sD = sD; j.C = C; j.ldc = ldc; j.sC = sC;
+    }
+    // y = a + s op(Mt) x   (n outputs, kn terms; a may be null)
+    void matvec(int trans, int n, int kn, double s, const double *Mt, int ld, long long sM, const double *x,
+                int incx, long long sx, const double *a, long long sa, double *y, int incy, long long sy) {
+        Job &j = add(JOB_MATVEC, 1);
+        j.ta = trans; j.M = n; j.K = kn; j.s = s;
+        j.A = Mt; j.lda = ld; j.sA = sM; j.B = x; j.ldb = incx; j.sB = sx;
+        j.D = a; j.sD = sa; j.C = y; j.ldc = incy; j.sC = sy;
+    }
+    // dst (rows x cols) = src, or zeros when src is null
+    void copy(int rows, int cols, const double *src, int lds_, long long ssrc, double *dst, int ldd_,
+              long long sdst) {
+        long long nb = ((long long)rows * cols + 2047) / 2048;
+        if (nb < 1) nb = 1;
+        if (nb > 16) nb = 16;
+        Job &j = add(JOB_COPY, (int)nb);
+        j.M = rows; j.N = cols; j.tn = (int)nb;
+        j.A = src; j.lda = lds_; j.sA = ssrc; j.C = dst; j.ldc = ldd_; j.sC = sdst;
+    }
+    void launch(long long batch, hipStream_t st) {
+        if (T.njobs == 0 || batch < 1) return;
+        hipLaunchKernelGGL(k_jobs, dim3((unsigned)T.nblocks, (unsigned)batch), dim3(256), 0, st, T);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Gram sums of a chunk: G = sum_n h_n h_n^T / d_n (upper triangle, mirrored), m = sum_n h_n z_n / d_n
+// ------------------------------------------------------------------------------------------------
+template <int NT>                       // WP = 16 NT
+__global__ void __launch_bounds__(64 * NT)
+k_wide_gram(const int64_t N, const int64_t L, const int nch, const int P, const int CP,
+            const double *__restrict__ h_, const double *__restrict__ dbar_, const double *__restrict__ zbar_,
+            double *__restrict__ G_out, double *__restrict__ m_out) {
+    constexpr int WP = 16 * NT, NTH = 64 * NT;
+    constexpr int HLD = (WP + 31) / 32 * 32 + 16;   // rows k, k + 1 land 32 banks apart
+    constexpr int NV = (8 * WP + NTH - 1) / NTH;    // double2 loads per thread and K-step (= 2)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int r = __builtin_amdgcn_readfirstlane(tid >> 6);     // 16-row strip of this wave
+    const int li = lane & 15, lk = lane >> 4;
+    const int slot = blockIdx.x, pr = slot / nch, ch = slot - pr * nch;
+    const int64_t c0 = (int64_t)ch * L;
+    const int rows = (int)((N - c0 < L) ? (N - c0) : L);
+    const size_t pb = (size_t)pr * N + c0;
+    const double *__restrict__ H = h_ + pb * CP;
+    const double *__restrict__ dg = dbar_ + pb;
+    const double *__restrict__ zg = zbar_ + pb;
+    __shared__ __attribute__((aligned(16))) double Hs[2][16 * HLD];
+    __shared__ double Ss[2][16], Zs[2][16];
+    d4 acc[NT + 1];
+#pragma unroll
+    for (int q = 0; q <= NT; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+    double2 v[NV];
+    double sv = 0.0, zv = 0.0;
+    auto fetch = [&](const int kb) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int e = tid + q * NTH, row = e / (WP / 2), c2 = e - row * (WP / 2);
+            const bool ok = e < 8 * WP && kb + row < rows;
+            v[q] = ok ? *reinterpret_cast<const double2 *>(H + (size_t)(kb + row) * CP + 2 * c2) : double2{0.0, 0.0};
+        }
+        if (tid < 16) {
+            const bool ok = kb + tid < rows;
+            const double d = ok ? dg[kb + tid] : 0.0;
+            sv = (d > 0.0) ? 1.0 / d : 0.0;
+            zv = ok ? zg[kb + tid] : 0.0;
+        }
+    };
+    auto stash = [&](const int buf) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int e = tid + q * NTH, row = e / (WP / 2), c2 = e - row * (WP / 2);
+            if (e < 8 * WP) *reinterpret_cast<double2 *>(&Hs[buf][row * HLD + 2 * c2]) = v[q];
+        }
+        if (tid < 16) { Ss[buf][tid] = sv; Zs[buf][tid] = zv; }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kb = 0; kb < rows; kb += 16) {
+        const bool more = kb + 16 < rows;
+        if (more) fetch(kb + 16);
+        const double *hrow = &Hs[cur][0];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = 4 * ks + lk;
+            const double av = hrow[k * HLD + 16 * r + li] * Ss[cur][k];
+#pragma unroll
+            for (int q = 0; q < NT; ++q)
+                if (q >= r) acc[q] = GF_MFMA64(av, hrow[k * HLD + 16 * q + li], acc[q]);
+            acc[NT] = GF_MFMA64(av, (li == 0) ? Zs[cur][k] : 0.0, acc[NT]);
+        }
+        if (more) stash(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const size_t mp = (size_t)pr * P + ch;          // dense map index (the scan pads nch to P)
+    double *__restrict__ Gd = G_out + mp * ((size_t)WP * WP);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        if (q < r) continue;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = 16 * r + lk + 4 * rr, col = 16 * q + li;
+            if (q > r || col >= row) {
+                Gd[(size_t)row * WP + col] = acc[q][rr];
+                Gd[(size_t)col * WP + row] = acc[q][rr];
+            }
+        }
+    }
+    if (li == 0) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) m_out[mp * WP + 16 * r + lk + 4 * rr] = acc[NT][rr];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sweep-state layout <-> dense maps
+//   state slot (k_factorw / k_phiw): [column j][row i] with RP rows per column, CP columns; the forward
+//   solve (Y) rides in column CP - 1.  dense: row-major WP x WP, zero pads.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_lft_pack(const int nch, const int P, const int W, const int WP, const int CP, const int RP,
+           const double *__restrict__ S_state, const double *__restrict__ Phi_state,
+           double *__restrict__ Ph, double *__restrict__ X, double *__restrict__ Y,
+           double *__restrict__ G, double *__restrict__ m) {
+    const int mp = blockIdx.x, pr = mp / P, ch = mp - pr * P;
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    const size_t msz = (size_t)WP * WP;
+    double *Pd = Ph + mp * msz, *Xd = X + mp * msz, *Yd = Y + (size_t)mp * WP;
+    if (ch >= nch) {                                // identity map pads the scan
+        double *Gd = G + mp * msz, *md = m + (size_t)mp * WP;
+        for (int e = tid; e < WP * WP; e += 256) {
+            const int i = e / WP, j = e - i * WP;
+            Pd[e] = (i == j) ? 1.0 : 0.0;
+            Xd[e] = 0.0;
+            Gd[e] = 0.0;
+        }
+        for (int e = tid; e < WP; e += 256) { Yd[e] = 0.0; md[e] = 0.0; }
+        return;
+    }
+    const size_t slot = (size_t)pr * nch + ch;
+    const double *__restrict__ Ss = S_state + slot * ((size_t)CP * RP);
+    const double *__restrict__ Ps = Phi_state + slot * ((size_t)CP * RP);
+    __shared__ double tP[32][33], tS[32][33];
+    const int nt = (WP + 31) / 32;
+    for (int t = 0; t < nt * nt; ++t) {
+        const int i0 = 32 * (t / nt), j0 = 32 * (t % nt);
+        // column j0 + a, rows i0 + tx (coalesced along the rows of a state column)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int a = ty + 8 * q, j = j0 + a, i = i0 + tx;
+            const bool ok = i < W && j < W;
+            tP[a][tx] = ok ? Ps[(size_t)j * RP + i] : 0.0;          // Phi(i, j)
+            tS[a][tx] = ok ? Ss[(size_t)j * RP + i] : 0.0;          // S(i, j)
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int a = ty + 8 * q, i = i0 + a, j = j0 + tx;      // dense row i, column j
+            if (i < WP && j < WP) {
+                Pd[(size_t)i * WP + j] = tP[tx][a];
+                // X symmetrised: (S(i, j) + S(j, i)) / 2, S(j, i) read straight (row i of the dense
+                // matrix = column i of the state: coalesced along j)
+                const double sji = (i < W && j < W) ? Ss[(size_t)i * RP + j] : 0.0;
+                Xd[(size_t)i * WP + j] = 0.5 * (tS[tx][a] + sji);
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < WP; e += 256) Yd[e] = (e < W) ? Ss[(size_t)(CP - 1) * RP + e] : 0.0;
+}
+
+__global__ void __launch_bounds__(256)
+k_lft_unpack(const int nch, const int P, const int W, const int WP, const int CP, const int RP,
+             const double *__restrict__ Xs, const double *__restrict__ Ys, double *__restrict__ S_state) {
+    const int slot = blockIdx.x, pr = slot / nch, ch = slot - pr * nch;
+    const size_t mp = (size_t)pr * P + ch;
+    const double *__restrict__ Xd = Xs + mp * ((size_t)WP * WP);
+    const double *__restrict__ Yd = Ys + mp * WP;
+    double *__restrict__ Sd = S_state + (size_t)slot * ((size_t)CP * RP);
+    for (int e = threadIdx.x; e < CP * RP; e += 256) {
+        const int col = e / RP, row = e - col * RP;
+        double v = 0.0;
+        if (row < W) {
+            if (col < W) v = Xd[(size_t)col * WP + row];            // X symmetric: S(row, col) = X[col][row]
+            else if (col == CP - 1) v = Yd[row];
+        }
+        Sd[e] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the scan
+// ------------------------------------------------------------------------------------------------
+struct Maps {                           // one level: n maps, dense
+    double *Ph, *G, *X, *Y, *m;
+};
+
+inline int ilog2(int P) { int l = 0; while ((1 << l) < P) ++l; return l; }
+
+struct TreePlan {
+    int B, P, WP, nlev, NR;
+    size_t msz, total;
+    // offsets into the workspace (doubles)
+    size_t lev_maps[32], lev_state[32], scrA, scrR, scrT1, scrT2, scrU;
+    TreePlan(int B_, int P_, int WP_) : B(B_), P(P_), WP(WP_) {
+        nlev = ilog2(P);
+        NR = 2 * WP + 16;
+        msz = (size_t)WP * WP;
+        size_t off = 0;
+        for (int l = 1; l < nlev; ++l) {            // level 0 = the caller's arrays
+            const size_t n = (size_t)B * (P >> l);
+            lev_maps[l] = off;  off += n * (3 * msz + 2 * WP);
+            lev_state[l] = off; off += n * (msz + WP);
+        }
+        const size_t pairs = (size_t)B * (P > 1 ? P / 2 : 1);
+        scrA = off;  off += pairs * msz;
+        scrR = off;  off += pairs * (size_t)WP * NR;
+        scrT1 = off; off += pairs * msz;
+        scrT2 = off; off += pairs * msz;
+        scrU = off;  off += pairs * WP;
+        total = off;
+    }
+    Maps maps(int l, double *work) const {
+        const size_t n = (size_t)B * (P >> l);
+        double *p = work + lev_maps[l];
+        Maps M;
+        M.Ph = p; M.G = p + n * msz; M.X = p + 2 * n * msz; M.Y = p + 3 * n * msz; M.m = M.Y + n * WP;
+        return M;
+    }
+};
+
+int tree_scan(const TreePlan &T, const Maps &M0, double *Xs0, double *Ys0, double *work, hipStream_t st) {
+    const int WP = T.WP, NR = T.NR, nlev = T.nlev;
+    const long long msz = (long long)T.msz;
+    const size_t nmaps0 = (size_t)T.B * T.P;
+    if (nlev == 0) {                                // one chunk per problem: the start state is zero
+        (void)hipMemsetAsync(Xs0, 0, nmaps0 * T.msz * sizeof(double), st);
+        (void)hipMemsetAsync(Ys0, 0, nmaps0 * WP * sizeof(double), st);
+        return gf_internal_check_launch("gf_lft_tree_scan");
+    }
+    double *A = work + T.scrA, *R = work + T.scrR, *T1 = work + T.scrT1, *T2 = work + T.scrT2, *U = work + T.scrU;
+    const long long sR = (long long)WP * NR;
+    auto level_maps = [&](int l) { return l == 0 ? M0 : T.maps(l, work); };
+    auto state_X = [&](int l) { return l == 0 ? Xs0 : work + T.lev_state[l]; };
+    auto state_Y = [&](int l) { return l == 0 ? Ys0 : work + T.lev_state[l] + (size_t)T.B * (T.P >> l) * T.msz; };
+    // ---- up-sweep: level l pairs (2k, 2k + 1) -> level l + 1 map k (the root is never needed) ----
+    for (int l = 0; l + 1 < nlev; ++l) {
+        const Maps S = level_maps(l), Dn = T.maps(l + 1, work);
+        const long long pairs = (long long)T.B * (T.P >> (l + 1));
+        const double *PL = S.Ph, *PR = S.Ph + msz, *GL = S.G, *GR = S.G + msz, *XL = S.X, *XR = S.X + msz;
+        const double *YL = S.Y, *YR = S.Y + WP, *mL = S.m, *mR = S.m + WP;
+        const long long s2 = 2 * msz, v2 = 2 * WP;
+        {   // A = I - X_L G_R ; rhs = [Y_L - X_L m_R, 0 ... | Phi_L | X_L]
+            JobBuilder jb;
+            jb.gemm(0, 0, EPI_IMINUS, WP, WP, WP, XL, WP, s2, GR, WP, s2, nullptr, 0, 0, A, WP, msz);
+            jb.matvec(1, WP, WP, -1.0, XL, WP, s2, mR, 1, v2, YL, v2, R, NR, sR);      // X symmetric: T form
+            jb.copy(WP, 15, nullptr, 0, 0, R + 1, NR, sR);
+            jb.copy(WP, WP, PL, WP, s2, R + 16, NR, sR);
+            jb.copy(WP, WP, XL, WP, s2, R + 16 + WP, NR, sR);
+            jb.launch(pairs, st);
+        }
+        if (gf_dense_solve((int)pairs, WP, NR, A, R, st)) return -1;
+        {   // Phi = Phi_R (D Phi_L) ; T1 = Phi_R (D X_L) ; T2 = G_R (D Phi_L) ; Y = Y_R + Phi_R v ; u = m_R - G_R v
+            JobBuilder jb;
+            jb.gemm(0, 0, EPI_PLAIN, WP, WP, WP, PR, WP, s2, R + 16, NR, sR, nullptr, 0, 0, Dn.Ph, WP, msz);
+            jb.gemm(0, 0, EPI_PLAIN, WP, WP, WP, PR, WP, s2, R + 16 + WP, NR, sR, nullptr, 0, 0, T1, WP, msz);
+            jb.gemm(0, 0, EPI_PLAIN, WP, WP, WP, GR, WP, s2, R + 16, NR, sR, nullptr, 0, 0, T2, WP, msz);
+            jb.matvec(0, WP, WP, 1.0, PR, WP, s2, R, NR, sR, YR, v2, Dn.Y, 1, WP);
+            jb.matvec(1, WP, WP, -1.0, GR, WP, s2, R, NR, sR, mR, v2, U, 1, WP);        // G symmetric
+            jb.launch(pairs, st);
+        }
+        {   // X = X_R + T1 Phi_R^T ; G = G_L + Phi_L^T T2 (both symmetric) ; m = m_L + Phi_L^T u
+            JobBuilder jb;
+            jb.gemm(0, 1, EPI_ADD_SYMU, WP, WP, WP, T1, WP, msz, PR, WP, s2, XR, WP, s2, Dn.X, WP, msz);
+            jb.gemm(1, 0, EPI_ADD_SYMU, WP, WP, WP, PL, WP, s2, T2, WP, msz, GL, WP, s2, Dn.G, WP, msz);
+            jb.matvec(1, WP, WP, 1.0, PL, WP, s2, U, 1, WP, mL, v2, Dn.m, 1, WP);
+            jb.launch(pairs, st);
+        }
+    }
+    // ---- down-sweep: parent state (level l + 1, block k) -> children (level l, blocks 2k, 2k + 1) ----
+    {   // top: the parent state is zero, so child 0 starts from zero and child 1 from (Xbar, Ybar) of map 0
+        const int l = nlev - 1;
+        const Maps S = level_maps(l);
+        double *Xc = state_X(l), *Yc = state_Y(l);
+        JobBuilder jb;
+        jb.copy(WP, WP, nullptr, 0, 0, Xc, WP, 2 * msz);
+        jb.copy(1, WP, nullptr, 0, 0, Yc, WP, 2 * WP);
+        jb.copy(WP, WP, S.X, WP, 2 * msz, Xc + msz, WP, 2 * msz);
+        jb.copy(1, WP, S.Y, WP, 2 * WP, Yc + WP, WP, 2 * WP);
+        jb.launch(T.B, st);
+    }
+    const int NRa = WP + 16;
+    const long long sRa = (long long)WP * NRa;
+    for (int l = nlev - 2; l >= 0; --l) {
+        const Maps S = level_maps(l);               // the LEFT map of every pair is applied
+        const long long pairs = (long long)T.B * (T.P >> (l + 1));
+        const double *Xp = state_X(l + 1), *Yp = state_Y(l + 1);
+        double *Xc = state_X(l), *Yc = state_Y(l);
+        const long long s2 = 2 * msz, v2 = 2 * WP;
+        {   // A = I - X G ; rhs = [Y - X m, 0 ... | X] ; left child inherits the parent's state
+            JobBuilder jb;
+            jb.gemm(0, 0, EPI_IMINUS, WP, WP, WP, Xp, WP, msz, S.G, WP, s2, nullptr, 0, 0, A, WP, msz);
+            jb.matvec(1, WP, WP, -1.0, Xp, WP, msz, S.m, 1, v2, Yp, WP, R, NRa, sRa);
+            jb.copy(WP, 15, nullptr, 0, 0, R + 1, NRa, sRa);
+            jb.copy(WP, WP, Xp, WP, msz, R + 16, NRa, sRa);
+            jb.copy(WP, WP, Xp, WP, msz, Xc, WP, s2);
+            jb.copy(1, WP, Yp, WP, WP, Yc, WP, v2);
+            jb.launch(pairs, st);
+        }
+        if (gf_dense_solve((int)pairs, WP, NRa, A, R, st)) return -1;
+        {   // T1 = Phi K ; Y+ = Ybar + Phi v
+            JobBuilder jb;
+            jb.gemm(0, 0, EPI_PLAIN, WP, WP, WP, S.Ph, WP, s2, R + 16, NRa, sRa, nullptr, 0, 0, T1, WP, msz);
+            jb.matvec(0, WP, WP, 1.0, S.Ph, WP, s2, R, NRa, sRa, S.Y, v2, Yc + WP, 1, v2);
+            jb.launch(pairs, st);
+        }
+        {   // X+ = Xbar + T1 Phi^T (symmetric)
+            JobBuilder jb;
+            jb.gemm(0, 1, EPI_ADD_SYMU, WP, WP, WP, T1, WP, msz, S.Ph, WP, s2, S.X, WP, s2, Xc + msz, WP, s2);
+            jb.launch(pairs, st);
+        }
+    }
+    return gf_internal_check_launch("gf_lft_tree_scan");
+}
+
+bool pow2(int x) { return x >= 1 && (x & (x - 1)) == 0; }
+
+template <int NT>
+void launch_gram(int slots, int64_t N, int64_t L, int nch, int P, int CP, const double *h, const double *dbar,
+                 const double *zbar, double *G, double *m, hipStream_t st) {
+    hipLaunchKernelGGL((k_wide_gram<NT>), dim3(slots), dim3(64 * NT), 0, st, N, L, nch, P, CP, h, dbar, zbar, G, m);
+}
+
+int dispatch_gram(int WP, int slots, int64_t N, int64_t L, int nch, int P, int CP, const double *h,
+                  const double *dbar, const double *zbar, double *G, double *m, hipStream_t st) {
+    switch (WP / 16) {
+#define GF_GR(n) case n: launch_gram<n>(slots, N, L, nch, P, CP, h, dbar, zbar, G, m, st); return 0;
+        GF_GR(4) GF_GR(5) GF_GR(6) GF_GR(7) GF_GR(8) GF_GR(9) GF_GR(10) GF_GR(11)
+#undef GF_GR
+    }
+    return -1;
+}
+
+}  // namespace
+
+// ==================================================================================================
+// C-ABI
+// ==================================================================================================
+extern "C" {
+
+int gf_bgemm(int batch, int trans_a, int trans_b, int M, int N, int K,
+             const double *A, int lda, int64_t stride_a, const double *B, int ldb, int64_t stride_b,
+             const double *D, int ldd, int64_t stride_d, double *C, int ldc, int64_t stride_c, void *stream) {
+    if (batch < 1 || M < 1 || N < 1 || K < 1)
+        return gf_internal_error(-1, "gf_bgemm: empty problem (batch=%d, M=%d, N=%d, K=%d)", batch, M, N, K);
+    if (!A || !B || !C) return gf_internal_error(-1, "gf_bgemm: null pointer");
+    if (batch > 65535) return gf_internal_error(-1, "gf_bgemm: batch=%d unsupported (max 65535)", batch);
+    JobBuilder jb;
+    jb.gemm(trans_a ? 1 : 0, trans_b ? 1 : 0, D ? EPI_ADD : EPI_PLAIN, M, N, K, A, lda, stride_a, B, ldb, stride_b,
+            D, ldd, stride_d, C, ldc, stride_c);
+    jb.launch(batch, (hipStream_t)stream);
+    return gf_internal_check_launch("gf_bgemm");
+}
+
+int gf_dense_width(int W) { return (W + 15) / 16 * 16; }
+
+int64_t gf_lft_tree_work(int B, int P, int WP) {
+    if (B < 1 || !pow2(P) || WP < 16 || WP > 192 || (WP & 15)) return -1;
+    return (int64_t)TreePlan(B, P, WP).total;
+}
+
+int gf_lft_tree_scan(int B, int P, int WP, const double *Phi, const double *G, const double *Xbar,
+                     const double *Ybar, const double *m, double *X_start, double *Y_start, double *work,
+                     void *stream) {
+    if (B < 1 || !pow2(P)) return gf_internal_error(-1, "gf_lft_tree_scan: P=%d must be a power of two (B=%d)", P, B);
+    if (WP < 16 || WP > 192 || (WP & 15))
+        return gf_internal_error(-1, "gf_lft_tree_scan: WP=%d must be a multiple of 16 in 16..192", WP);
+    if ((long long)B * P / 2 > 65535) return gf_internal_error(-1, "gf_lft_tree_scan: too many maps (B*P=%lld)", (long long)B * P);
+    if (!Phi || !G || !Xbar || !Ybar || !m || !X_start || !Y_start || (P > 2 && !work))
+        return gf_internal_error(-1, "gf_lft_tree_scan: null pointer");
+    TreePlan T(B, P, WP);
+    Maps M0;
+    M0.Ph = const_cast<double *>(Phi); M0.G = const_cast<double *>(G); M0.X = const_cast<double *>(Xbar);
+    M0.Y = const_cast<double *>(Ybar); M0.m = const_cast<double *>(m);
+    return tree_scan(T, M0, X_start, Y_start, work, (hipStream_t)stream);
+}
+
+int gf_wide_gram(int B, int64_t N, int64_t chunk_len, int nch, int P, int Jc, const double *h,
+                 const double *dbar, const double *zbar, double *G_out, double *m_out, void *stream) {
+    const int W = 2 * Jc, WP = gf_dense_width(W);
+    const int CP = gf_fused_row_stride(0, Jc);
+    if (B < 1 || N < 1) return gf_internal_error(-1, "gf_wide_gram: empty problem (N=%lld)", (long long)N);
+    if (W <= 63 || CP < 0 || WP > 176) return gf_internal_error(-1, "gf_wide_gram: width %d unsupported (64..176)", W);
+    if (nch < 1 || chunk_len < 1 || (int64_t)nch * chunk_len < N || (int64_t)(nch - 1) * chunk_len >= N || P < nch)
+        return gf_internal_error(-1, "gf_wide_gram: bad chunking (chunk_len=%lld, nch=%d, P=%d)", (long long)chunk_len, nch, P);
+    if (!h || !dbar || !zbar || !G_out || !m_out) return gf_internal_error(-1, "gf_wide_gram: null pointer");
+    if (dispatch_gram(WP, B * nch, N, chunk_len, nch, P, CP, h, dbar, zbar, G_out, m_out, (hipStream_t)stream))
+        return gf_internal_error(-1, "gf_wide_gram: internal dispatch error");
+    return gf_internal_check_launch("gf_wide_gram");
+}
+
+static int tree_P(int nch) { int P = 1; while (P < nch) P *= 2; return P; }
+
+int64_t gf_wide_combine_work(int B, int nch, int Jc) {
+    const int W = 2 * Jc, WP = gf_dense_width(W);
+    if (B < 1 || nch < 1 || W <= 63 || WP > 176) return -1;
+    const int P = tree_P(nch);
+    const size_t n = (size_t)B * P, msz = (size_t)WP * WP;
+    return (int64_t)(n * (3 * msz + 2 * WP) + n * (msz + WP) + TreePlan(B, P, WP).total);
+}
+
+int gf_wide_combine(int B, int64_t N, int64_t chunk_len, int nch, int Jc, const double *h, const double *dbar,
+                    const double *zbar, const double *Phi_state, double *S_state, double *work, void *stream) {
+    const int W = 2 * Jc, WP = gf_dense_width(W);
+    const int CP = gf_fused_row_stride(0, Jc);
+    if (B < 1 || N < 1) return gf_internal_error(-1, "gf_wide_combine: empty problem (N=%lld)", (long long)N);
+    if (W <= 63 || CP < 0 || WP > 176) return gf_internal_error(-1, "gf_wide_combine: width %d unsupported (64..176)", W);
+    if (nch < 2 || chunk_len < 1 || (int64_t)nch * chunk_len < N || (int64_t)(nch - 1) * chunk_len >= N)
+        return gf_internal_error(-1, "gf_wide_combine: bad chunking (chunk_len=%lld, nch=%d)", (long long)chunk_len, nch);
+    if (!h || !dbar || !zbar || !Phi_state || !S_state || !work) return gf_internal_error(-1, "gf_wide_combine: null pointer");
+    const int P = tree_P(nch);
+    if ((long long)B * P / 2 > 65535) return gf_internal_error(-1, "gf_wide_combine: too many chunks (B*P=%lld)", (long long)B * P);
+    const int RP = (int)(gf_fused_state_size(0, Jc) / CP);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)B * P, msz = (size_t)WP * WP;
+    Maps M0;
+    M0.Ph = work; M0.G = work + n * msz; M0.X = work + 2 * n * msz; M0.Y = work + 3 * n * msz; M0.m = M0.Y + n * WP;
+    double *Xs = M0.m + n * WP, *Ys = Xs + n * msz, *tw = Ys + n * WP;
+    hipLaunchKernelGGL(k_lft_pack, dim3((unsigned)n), dim3(256), 0, st, nch, P, W, WP, CP, RP, S_state, Phi_state,
+                       M0.Ph, M0.X, M0.Y, M0.G, M0.m);
+    if (dispatch_gram(WP, B * nch, N, chunk_len, nch, P, CP, h, dbar, zbar, M0.G, M0.m, st))
+        return gf_internal_error(-1, "gf_wide_combine: internal dispatch error");
+    TreePlan T(B, P, WP);
+    if (tree_scan(T, M0, Xs, Ys, tw, st)) return -1;
+    hipLaunchKernelGGL(k_lft_unpack, dim3((unsigned)(B * nch)), dim3(256), 0, st, nch, P, W, WP, CP, RP, Xs, Ys, S_state);
+    return gf_internal_check_launch("gf_wide_combine");
+}
+
+}  // extern "C"

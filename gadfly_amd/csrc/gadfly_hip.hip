@@ -19,12 +19,15 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <utility>
+#include <tuple>
 #include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdarg.h>
 #include <math.h>
 
 #include "../../include/gadfly_hip.h"
+#include "gf_internal.h"
 
 // sincos / exp with <= 1 ulp error for the argument ranges of k_build2 (validated against
 // long-double libm by oracle/fastmath_check.c); ~4x fewer instructions than the general OCML
@@ -36,10 +39,24 @@ namespace {
 
 thread_local char g_err[512] = "";
 
-int set_err(const char *fmt, const char *a = "", long long x = 0, long long y = 0) {
+int set_err_impl(const char *fmt, const char *a = "", long long x = 0, long long y = 0) {
     snprintf(g_err, sizeof(g_err), fmt, a, x, y);
     return -1;
 }
+
+// conversions in a format literal; set_err() refuses to compile when they do not match the arguments
+// (a missing argument would be read from the defaulted `x` as a char*)
+constexpr int fmt_conversions(const char *f) {
+    int n = 0;
+    for (; *f; ++f)
+        if (*f == '%') { if (f[1] == '%') ++f; else ++n; }
+    return n;
+}
+#define set_err(fmt, ...)                                                                              \
+    (static_cast<void>(sizeof(char[fmt_conversions(fmt) ==                                             \
+                                   (int)std::tuple_size<decltype(std::make_tuple(__VA_ARGS__))>::value \
+                                   ? 1 : -1])),                                                        \
+     set_err_impl(fmt, __VA_ARGS__))
 
 int check_launch(const char *what) {
     const hipError_t e = hipGetLastError();
@@ -49,6 +66,19 @@ int check_launch(const char *what) {
     }
     return 0;
 }
+}  // namespace
+
+// the same two services for the library's other translation units (gf_internal.h)
+int gf_internal_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int gf_internal_check_launch(const char *what) { return check_launch(what); }
+
+namespace {
 
 // ------------------------------------------------------------------------------------
 // wave-level primitives (64 lanes, DPP; no LDS traffic)
@@ -4811,8 +4841,9 @@ static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int6
                         int32_t *info, void *stream) {
     const int W = Jr + 2 * Jc;
     if (B < 1 || N < 1) return set_err("%s: empty problem (N=%lld)", who, N);
-    if ((Ut_out != nullptr) != (Wt_out != nullptr) || (Ut_out != nullptr) != (de_out != nullptr))
-        return set_err("%s: Ut_out, Wt_out, de_out go together%s", who);
+    // (the wide sweep stores u~ / reset spans and w~ independently: its nominal pass needs no w~ rows)
+    if ((Ut_out != nullptr) != (de_out != nullptr) || (Wt_out && !Ut_out) || (W <= 63 && Ut_out && !Wt_out))
+        return set_err("%s: Ut_out, Wt_out, de_out go together (Wt_out optional for W > 63)", who);
     if (!gf_fused_supported(Jr, Jc))
         return set_err("%s: width %lld unsupported (1..63 any terms; 64..176 complex terms only)", who, W);
     if (block < 1 || block > 64 || (block & (block - 1))) return set_err("%s: block=%lld must be a power of two in 1..64", who, block);
@@ -4821,7 +4852,7 @@ static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int6
         || (int64_t)(nch - 1) * chunk_len >= N)
         return set_err("%s: bad chunking (chunk_len=%lld, nch=%lld)", who, chunk_len, nch);
     if (!t || !y || !d || !z || !S_state || (!F_state && W <= 63) || !info || !diag_add || !cmax)
-        return set_err("%s: null pointer%s", who);
+        return set_err("%s: null pointer", who);
     if (check_sweep_options(who, gen_period, W > 63 ? GF_SWEEP_AUTO : variant, Jr, Jc)) return -1;
     const bool tiled = sweep_tiled(variant, Jr, Jc);
     const double gap = (block > 1) ? SC_SPAN / (double)(block - 1) : 0.0;

@@ -17,7 +17,6 @@ HBM layout (float64, row-major, all torch tensors on one device):
 """
 import functools
 import math
-import threading
 
 import numpy as np
 
@@ -307,148 +306,6 @@ SINCOS_RANGE = 3.0e9
 
 
 
-def _solve_quiet(torch, A, rhs):
-    """Batched dense solve that never raises (gf_dense_solve: Gauss-Jordan with partial pivoting in ONE
-    launch; hipSOLVER's blocked LU is ~300 launches per call at these sizes).  The maps of chunks at
-    or after a non-positive pivot are garbage (singular, NaN) by construction; they only ever feed
-    chunks that fail anyway."""
-    A = A.contiguous()
-    X = rhs.contiguous().clone()
-    batch, n, nrhs = X.shape
-    st = torch.cuda.current_stream(A.device).cuda_stream
-    rc = _lib.load().gf_dense_solve(batch, n, nrhs, _lib.ptr(A), _lib.ptr(X), st)
-    _lib.check(rc, "gf_dense_solve")
-    return X
-
-
-def _lft_compose(torch, M1, M2):
-    """Chunk map M2 after M1 (batched; each map = (Phi, G, Xbar, Ybar, m)):
-    D = (I - X1 G2)^-1;  Phi = Phi2 D Phi1;  X = X2 + Phi2 D X1 Phi2^T;  G = G1 + Phi1^T G2 D Phi1;
-    v = D (Y1 - X1 m2);  Y = Y2 + Phi2 v;  m = m1 + Phi1^T (m2 - G2 v)."""
-    P1, G1, X1, Y1, m1 = M1
-    P2, G2, X2, Y2, m2 = M2
-    W = P1.shape[-1]
-    A = torch.eye(W, dtype=P1.dtype, device=P1.device) - X1 @ G2
-    rhs = torch.cat([P1, X1, (Y1 - (X1 @ m2.unsqueeze(-1)).squeeze(-1)).unsqueeze(-1)], dim=-1)
-    sol = _solve_quiet(torch, A, rhs)
-    DP1, DX1, v = sol[..., :W], sol[..., W:2 * W], sol[..., 2 * W]
-    P12 = P2 @ DP1
-    X12 = X2 + P2 @ DX1 @ P2.transpose(-1, -2)
-    G12 = G1 + P1.transpose(-1, -2) @ G2 @ DP1
-    Y12 = Y2 + (P2 @ v.unsqueeze(-1)).squeeze(-1)
-    m12 = m1 + (P1.transpose(-1, -2) @ (m2 - (G2 @ v.unsqueeze(-1)).squeeze(-1)).unsqueeze(-1)).squeeze(-1)
-    return (P12, 0.5 * (G12 + G12.transpose(-1, -2)), 0.5 * (X12 + X12.transpose(-1, -2)), Y12, m12)
-
-
-def _lft_apply(torch, M, X, Y):
-    """State (X, Y) through a chunk map: X+ = Xbar + Phi K Phi^T, K = (I - X G)^-1 X;
-    Y+ = Ybar + Phi (I - X G)^-1 (Y - X m)."""
-    Ph, G, Xb, Yb, m = M
-    W = Ph.shape[-1]
-    A = torch.eye(W, dtype=Ph.dtype, device=Ph.device) - X @ G
-    rhs = torch.cat([X, (Y - (X @ m.unsqueeze(-1)).squeeze(-1)).unsqueeze(-1)], dim=-1)
-    sol = _solve_quiet(torch, A, rhs)
-    K, v = sol[..., :W], sol[..., W]
-    K = 0.5 * (K + K.transpose(-1, -2))
-    Xn = Xb + Ph @ K @ Ph.transpose(-1, -2)
-    Yn = Yb + (Ph @ v.unsqueeze(-1)).squeeze(-1)
-    return 0.5 * (Xn + Xn.transpose(-1, -2)), Yn
-
-
-def _lft_tree_scan(torch, Ph, G, Xb, Yb, m):
-    """True start state of every chunk from the chunk maps, as a Blelloch scan (2 log2 P batched
-    levels of dense W x W GEMMs through rocBLAS and one gf_dense_solve each).  Inputs are
-    (nch, W, W) / (nch, W); returns (Xstart (nch, W, W), Ystart (nch, W)).  The pairs of a level are
-    strided views of the map arrays (no gathers); no host synchronisation anywhere, so the whole scan
-    can be replayed from a captured HIP graph (:class:`_TreeScanGraph`)."""
-    nch, W = Ph.shape[0], Ph.shape[-1]
-    P = 1 << max(0, (nch - 1).bit_length())
-    kw = dict(dtype=Ph.dtype, device=Ph.device)
-    maps = [torch.zeros((P, W, W), **kw), torch.zeros((P, W, W), **kw), torch.zeros((P, W, W), **kw),
-            torch.zeros((P, W), **kw), torch.zeros((P, W), **kw)]
-    for a, v in zip(maps, (Ph, G, Xb, Yb, m)):
-        a[:nch] = v
-    if P > nch:                                         # identity maps pad the scan
-        maps[0][nch:] = torch.eye(W, **kw)
-    d = 1
-    while d < P:                                        # up-sweep: map[right] <- map[right] o map[left]
-        new = _lft_compose(torch, [a[d - 1::2 * d] for a in maps], [a[2 * d - 1::2 * d] for a in maps])
-        for a, v in zip(maps, new):
-            a[2 * d - 1::2 * d] = v
-        d *= 2
-    Xs = torch.zeros((P, W, W), **kw)
-    Ys = torch.zeros((P, W), **kw)
-    d = P // 2
-    while d >= 1:                                       # down-sweep
-        Xin, Yin = Xs[2 * d - 1::2 * d].clone(), Ys[2 * d - 1::2 * d].clone()
-        Xo, Yo = _lft_apply(torch, [a[d - 1::2 * d] for a in maps], Xin, Yin)
-        Xs[d - 1::2 * d], Ys[d - 1::2 * d] = Xin, Yin
-        Xs[2 * d - 1::2 * d], Ys[2 * d - 1::2 * d] = Xo, Yo
-        d //= 2
-    return Xs[:nch], Ys[:nch]
-
-
-class _TreeScanGraph:
-    """:func:`_lft_tree_scan` for one (nch, W) captured in a HIP graph: the scan is ~1 500 small
-    launches (batched GEMMs, copies, one solve per level) whose host-side launch cost exceeds their
-    GPU time several times over; replaying the captured graph leaves the GPU time.  Inputs are copied
-    into fixed buffers, the outputs are views of fixed buffers (consumed before the next replay: both
-    happen on the caller's stream)."""
-
-    _cache = {}
-    _lock = threading.Lock()            # the cached graphs own fixed in / out buffers: one scan at a time
-    MAX_ENTRIES = 4
-    disabled = False
-
-    def __init__(self, torch, nch, W, device):
-        kw = dict(dtype=torch.float64, device=device)
-        self.ins = [torch.zeros((nch, W, W), **kw) for _ in range(3)] + [torch.zeros((nch, W), **kw)
-                                                                         for _ in range(2)]
-        for a in self.ins[:3]:
-            a.copy_(torch.eye(W, **kw))                 # harmless maps for the warm-up
-        side = torch.cuda.Stream(device=device)
-        side.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(side):                   # library handles / workspaces exist before capture
-            _lft_tree_scan(torch, self.ins[0], self.ins[1], self.ins[2], self.ins[3], self.ins[4])
-        torch.cuda.current_stream(device).wait_stream(side)
-        torch.cuda.synchronize(device)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.outs = _lft_tree_scan(torch, self.ins[0], self.ins[1], self.ins[2], self.ins[3],
-                                       self.ins[4])
-
-    def __call__(self, Ph, G, Xb, Yb, m):
-        for a, v in zip(self.ins, (Ph, G, Xb, Yb, m)):
-            a.copy_(v)
-        self.graph.replay()
-        return self.outs
-
-    @classmethod
-    def run(cls, torch, Ph, G, Xb, Yb, m):
-        """The scan through a cached graph; eager when capture is unavailable.  The returned views of the
-        graph's output buffers are valid until the next scan of the same shape on this device."""
-        with cls._lock:
-            return cls._run_locked(torch, Ph, G, Xb, Yb, m)
-
-    @classmethod
-    def _run_locked(cls, torch, Ph, G, Xb, Yb, m):
-        if cls.disabled:
-            return _lft_tree_scan(torch, Ph, G, Xb, Yb, m)
-        key = (Ph.device.index, Ph.shape[0], Ph.shape[-1])
-        ent = cls._cache.pop(key, None)
-        if ent is None:
-            try:
-                ent = cls(torch, Ph.shape[0], Ph.shape[-1], Ph.device)
-            except RuntimeError:                        # capture refused: keep the eager scan
-                cls.disabled = True
-                torch.cuda.synchronize(Ph.device)
-                return _lft_tree_scan(torch, Ph, G, Xb, Yb, m)
-            while len(cls._cache) >= cls.MAX_ENTRIES:
-                cls._cache.pop(next(iter(cls._cache)))
-        cls._cache[key] = ent                           # most recently used last
-        return ent(Ph, G, Xb, Yb, m)
-
-
 class ScaledFactor:
     """
     The LDL^T factor of B problems stored in block-scaled form (rows u~, w~ = r/d, pivots d,
@@ -608,7 +465,9 @@ class WideFactor:
         self.c, self.t = c, owner.t
         self.info = torch.zeros((B,), dtype=torch.int32, device=self.device)
         st = torch.cuda.current_stream(self.device).cuda_stream
-        self.time_parallel = owner._wide_tp_ok() if time_parallel is None else bool(time_parallel)
+        # (the chunk-parallel SWEEPS on the stored factor are for one series; a batch is swept whole)
+        self.time_parallel = ((owner._wide_tp_ok() and B == 1) if time_parallel is None
+                              else bool(time_parallel))
         self.chunk_len, self.nch = N, 1
         self._tp_bufs = None
         if self.time_parallel:
@@ -667,6 +526,14 @@ class WideFactor:
             self._tp_bufs = None                        # the row scratch is no longer needed
         return self._Phi
 
+    def _gemm(self, batch, ta, tb, M, N, K, A, lda, sA, Bm, ldb, sB, D, ldd, sD, C, ldc, sC):
+        """C_b = D_b + op(A_b) op(B_b) on the library's FP64-MFMA GEMM tiles (gf_bgemm); operands are
+        (views of) device tensors, leading dimensions and batch strides in elements."""
+        st = self.torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.gf_bgemm(batch, ta, tb, M, N, K, _lib.ptr(A), lda, sA, _lib.ptr(Bm), ldb, sB,
+                               _lib.ptr(D), ldd, sD, _lib.ptr(C), ldc, sC, st)
+        _lib.check(rc, "gf_bgemm")
+
     def _chain_segments(self, up):
         """The chunks' closed-loop transitions in sweep order (Phi_c ascending for the forward solve,
         Phi_c^T descending for the backward one), cut into segments of L chunks (identity maps pad the
@@ -686,18 +553,23 @@ class WideFactor:
                 eye = torch.eye(W, dtype=A.dtype, device=A.device).expand(pad, W, W)
                 A = torch.cat([A, eye])
             A = A.contiguous().view(nseg, L, W, W)
+            WW = W * W
+            ping = [torch.empty((nseg, W, W), dtype=A.dtype, device=A.device) for _ in range(2)]
             Psi = A[:, 0]
-            for j in range(1, L):
-                Psi = torch.bmm(A[:, j], Psi)
+            sP = L * WW
+            for j in range(1, L):                       # Psi <- A_j Psi
+                out = ping[j & 1]
+                self._gemm(nseg, 0, 0, W, W, W, A[:, j], W, L * WW, Psi, W, sP, None, 0, 0, out, W, WW)
+                Psi, sP = out, WW
             self._chain[up] = (L, nseg, A, Psi.contiguous())
         return self._chain[up]
 
     def _chain_states(self, up, loc):
-        """True start state of every chunk from the chunks' local end states (one right-hand side):
-        x_{s+1} = loc_s + A_s x_s along the sweep.  Two levels -- every segment from a zero start (L batched
-        steps), the segments chained through their composed transitions (nseg steps), every segment again
-        from its true start (L batched steps) -- instead of nch dependent mat-vec launches (the Python loop
-        over 121 / 253 chunks was 2.0 / 4.2 ms of a 2.3 / 5.6 ms sweep at N = 1e5 / 1e6)."""
+        """True start state of every chunk from the chunks' local end states: x_{s+1} = loc_s + A_s x_s
+        along the sweep, for one right-hand side ((nch, W)) or R of them ((nch, W, R)).  Two levels --
+        every segment from a zero start (L batched steps), the segments chained through their composed
+        transitions (nseg steps), every segment again from its true start (L batched steps) -- instead
+        of nch dependent products; every step is one gf_bgemm launch."""
         torch = self.torch
         L, nseg, A, Psi = self._chain_segments(up)
         nch, W = self.nch, self.W
@@ -711,22 +583,19 @@ class WideFactor:
         if pad:
             loc = torch.cat([loc, torch.zeros((pad, W, R), dtype=loc.dtype, device=loc.device)])
         loc = loc.contiguous().view(nseg, L, W, R)
-        e = torch.zeros((nseg, W, R), dtype=loc.dtype, device=loc.device)
-        for j in range(L):                              # segment end states from a zero start
-            e = torch.baddbmm(loc[:, j], A[:, j], e)
-        cur = torch.zeros((W, R), dtype=loc.dtype, device=loc.device)
-        starts = []
-        for s in range(nseg):                           # the segments' true start states
-            starts.append(cur)
-            if s + 1 < nseg:
-                cur = torch.addmm(e[s], Psi[s], cur)
-        x = torch.stack(starts)
-        outs = []
-        for j in range(L):                              # every chunk's true start state
-            outs.append(x)
-            if j + 1 < L:
-                x = torch.baddbmm(loc[:, j], A[:, j], x)
-        out = torch.stack(outs, dim=1).view(nseg * L, W, R)[:nch]
+        WW, WR = W * W, W * R
+        kw = dict(dtype=loc.dtype, device=loc.device)
+        E = torch.zeros((nseg, L + 1, W, R), **kw)      # E[:, j]: state after j chunks from a zero start
+        for j in range(L):
+            self._gemm(nseg, 0, 0, W, R, W, A[:, j], W, L * WW, E[:, j], R, (L + 1) * WR,
+                       loc[:, j], R, L * WR, E[:, j + 1], R, (L + 1) * WR)
+        out = torch.zeros((nseg, L, W, R), **kw)        # out[s, j]: true start state of chunk s L + j
+        for s in range(nseg - 1):                       # the segments' true start states
+            self._gemm(1, 0, 0, W, R, W, Psi[s], W, 0, out[s, 0], R, 0, E[s, L], R, 0, out[s + 1, 0], R, 0)
+        for j in range(L - 1):                          # every chunk's true start state
+            self._gemm(nseg, 0, 0, W, R, W, A[:, j], W, L * WW, out[:, j], R, L * WR,
+                       loc[:, j], R, L * WR, out[:, j + 1], R, L * WR)
+        out = out.view(nseg * L, W, R)[:nch]
         if up:
             out = out.flip(0)
         return out.squeeze(-1) if vec else out
@@ -965,17 +834,28 @@ class StreamingBatch:
     # condition of 4e5)
     GEN_ERR = 1.6e-15
 
+    def last_acc(self):
+        """(B, 3) device tensor [sum log d, sum z^2/d, min d] of the LAST evaluation, whichever route ran."""
+        if getattr(self, "_last_wide_tp", False):
+            return self._wide_tp["acc"]
+        return self._tp["acc"] if getattr(self, "_tp_used", False) else self.acc
+
     def condition_estimate(self):
         """max(a) / min(d) over all problems of the LAST evaluation (synchronises): the factor by
         which rounding in the generator rows shows up in the log-likelihood."""
-        acc = self._tp["acc"] if getattr(self, "_tp_used", False) else self.acc
-        if getattr(self, "_last_wide_tp", False):
-            acc = self._wide_tp["acc"]
-        dmin = float(acc[:, 2].min().item())
+        dmin = float(self.last_acc()[:, 2].min().item())
         amax = float(self._pack[2].max().item())
         if self.diag is not None:
             amax += float(self.diag.max().item())
         return amax / dmin if dmin > 0.0 else float("inf")
+
+    def period_for_condition(self, cond, target=1e-9):
+        """Longest generator period (a power of two in 1..64) whose share GEN_ERR * period * cond of the
+        relative log-likelihood error stays below ``target``."""
+        period = 1
+        while period < 64 and self.GEN_ERR * (2 * period) * cond <= target:
+            period *= 2
+        return period
 
     def calibrate_generator(self, target=1e-9):
         """Choose the generator period (rows between exact re-anchorings, a power of two in 1..64)
@@ -983,11 +863,8 @@ class StreamingBatch:
         generator's contribution to the relative log-likelihood error stays below ``target``.
         Returns (condition estimate, period)."""
         cond = self.condition_estimate()
-        period = 1
-        while period < 64 and self.GEN_ERR * (2 * period) * cond <= target:
-            period *= 2
-        self.generator_period = period
-        return cond, period
+        self.generator_period = self.period_for_condition(cond, target)
+        return cond, self.generator_period
 
     def _make_pack(self, real, comp, diag_add, c):
         dev = self._dev
@@ -1045,6 +922,7 @@ class StreamingBatch:
         self.S_state.zero_()
         self.F_state.zero_()
         self.info.zero_()
+        self._tp_used, self._last_wide_tp = False, False     # (whose `acc` the last evaluation filled)
         if self._fused_ok() or self._wide_ok():
             return self._log_likelihood_fused(main)
         if self.bufs is None:
@@ -1223,7 +1101,7 @@ class StreamingBatch:
         out = torch.empty((B,), **f64)
         rc = lib.gf_loglike_finish(B, N, p(w["acc"]), p(self.info), p(out), None, st)
         _lib.check(rc, "gf_loglike_finish")
-        self._tp_used = True
+        self._tp_used, self._last_wide_tp = True, False
         return out, chunk_len, nch
 
     #: chunk counts above this use the log-depth tree combine (2 log2 P levels of ~0.13 ms)
@@ -1261,114 +1139,141 @@ class StreamingBatch:
         w["S"].view(B, nch, 4096).copy_(tr["X"][:, :nch])
         w["F"].view(B, nch, 64).copy_(tr["Y"][:, :nch])
 
-    # -- exact time-parallel evaluation of ONE series with a wide kernel -----------------------------
+    # -- exact time-parallel evaluation of FEW series with a wide kernel -----------------------------
     #: shortest series for which the wide time-parallel run replaces the sequential sweep
     wide_tp_min_rows = 16384
 
     WIDE_TP_COEF = 0.1
 
+    def _wide_slots(self):
+        """Workgroups of the wide sweep the chip runs at full per-workgroup speed: three per CU up to
+        W = 95 (four waves each), two up to W = 127, one beyond (seven waves of ~230 VGPRs)."""
+        nw = (self.W + 32) // 32
+        return 768 if nw <= 3 else (512 if nw == 4 else 256)
+
     def _wide_tp_ok(self):
-        return self._wide_ok() and self.B == 1 and self.N >= self.wide_tp_min_rows
+        """Chunking pays (three sweeps of N / nch rows instead of one of N) while the batch alone leaves
+        most of the workgroup slots empty."""
+        return (self._wide_ok() and self.N >= self.wide_tp_min_rows
+                and 6 * self.B <= self._wide_slots())
 
     def _wide_chunking(self, chunk_len):
         if chunk_len is None:
-            # three sweeps of N / nch rows (~1.4 us per row at W = 172) against the dense combine's
-            # 2 log2(nch) levels (~0.4 ms each: one gf_dense_solve + batched GEMMs): measured optimum
-            # nch ~ sqrt(0.1 N) -- 128 chunks at N = 1e5, 256 at N = 1e6 -- rounded to a power of two
-            # (the scan pads to one anyway)
-            want = max(2.0, math.sqrt(self.WIDE_TP_COEF * self.N))
-            nch = 1 << int(round(math.log2(want)))
-            chunk_len = -(-self.N // min(nch, 512))
+            if self.B == 1:
+                # three sweeps of N / nch rows (~1.4 us per row at W = 172) against the dense combine's
+                # 2 log2(nch) levels: nch ~ sqrt(WIDE_TP_COEF N), a power of two (the scan pads to one)
+                want = max(2.0, math.sqrt(self.WIDE_TP_COEF * self.N))
+                nch = min(1 << int(round(math.log2(want))), 512)
+            else:
+                # a batch: fill the workgroup slots, chunks of at least 2048 rows
+                nch = max(2, min(self._wide_slots() // self.B, self.N // 2048))
+            chunk_len = -(-self.N // nch)
         chunk_len = max(64, (int(chunk_len) + 63) // 64 * 64)
         return chunk_len, -(-self.N // chunk_len)
 
+    def _wide_ws(self, L, nch, keep):
+        """Row and state buffers of the wide time-parallel run, kept between evaluations (rows of all
+        problems back to back, four spare rows: the sweeps prefetch ahead unconditionally)."""
+        torch, lib = self.torch, self.lib
+        key = (L, nch)
+        # (a stored factor keeps r-bar / h / Phi for its lazily built chunk transitions: buffers of its own)
+        ws = None if keep else getattr(self, "_wide_ws_cache", None)
+        if ws is None or ws["key"] != key:
+            B, N = self.B, self.N
+            ld = int(lib.gf_fused_row_stride(self.Jr, self.Jc))
+            nS = int(lib.gf_fused_state_size(self.Jr, self.Jc))
+            f64 = dict(dtype=torch.float64, device=self.device)
+            rows = B * N + 4
+            ws = dict(key=key, ld=ld, nS=nS,
+                      dbar=torch.zeros((rows,), **f64), zbar=torch.zeros((rows,), **f64),
+                      rbar=torch.zeros((rows, ld), **f64), h=torch.zeros((rows, ld), **f64),
+                      S=torch.empty((B * nch, nS), **f64), Phi=torch.empty((B * nch, nS), **f64),
+                      cinfo=torch.zeros((B * nch,), dtype=torch.int32, device=self.device),
+                      work=torch.empty((max(1, int(lib.gf_wide_combine_work(B, max(nch, 2), self.Jc))),), **f64),
+                      red=torch.empty((B * int(lib.gf_reduce_work(N)),), **f64),
+                      acc=torch.empty((B, 3), **f64))
+            if not keep:
+                self._wide_ws_cache = ws
+        def rows(name):
+            """row buffer `name` of the workspace, allocated on first use"""
+            if name not in ws:
+                shape = (self.B * self.N + 4, ws["ld"]) if name == "Ut" else (self.B * self.N + 4,)
+                ws[name] = torch.zeros(shape, dtype=torch.float64, device=self.device)
+            return ws[name]
+
+        ws["rows"] = rows
+        return ws
+
     @_on_device
     def _tp_run_wide(self, chunk_len=None, stores=None, d=None, z=None, info=None):
-        """Chunk-parallel factor + forward solve of ONE series with a wide kernel (64 <= W <= 176):
+        """Chunk-parallel factor + forward solve of B series with a wide kernel (64 <= W <= 176):
         nominal pass (k_factorw, zero start states, rows stored) -> closed-loop transitions (k_phiw)
-        -> Gram sums and the LFT tree combine of the W x W chunk maps (dense GEMMs / solves: library
-        calls through torch.bmm / torch.linalg.solve) -> final pass from the true start states.
-        Fills d, z (and the stored factor rows); returns (loglike (1,), logdet (1,), chunk_len, nch)."""
-        if not self._wide_tp_ok() and not (self._wide_ok() and self.B == 1):
-            raise ValueError("wide time-parallel evaluation needs ONE series and a wide fused kernel")
+        -> Gram sums and the tree combine of the W x W chunk maps (gf_wide_combine: FP64-MFMA GEMM
+        jobs and one gf_dense_solve per level, all in the library) -> final pass from the true start
+        states.  Fills d, z (and the stored factor rows); returns (loglike (B,), logdet (B,), chunk_len,
+        nch)."""
+        if not self._wide_ok():
+            raise ValueError("wide time-parallel evaluation needs a wide fused kernel (64 <= W <= 176)")
         torch = self.torch
         lib, p = self.lib, _lib.ptr
-        N, W = self.N, self.W
+        B, N = self.B, self.N
         real, comp, diag_add, c, cmax, block, _ = self._pack
         L, nch = self._wide_chunking(chunk_len)
-        ld = int(lib.gf_fused_row_stride(self.Jr, self.Jc))
-        nS = int(lib.gf_fused_state_size(self.Jr, self.Jc))
-        RP = nS // ld
-        f64 = dict(dtype=torch.float64, device=self.device)
+        keep = stores is not None and nch > 1
+        ws = self._wide_ws(L, nch, keep=stores is not None)
         st = torch.cuda.current_stream(self.device).cuda_stream
-        NP = nch * L                                    # rows padded to whole chunks (zeros)
-
-        def rows_buf(cols=None):
-            shape = (NP + 2, cols) if cols else (NP + 2,)
-            return torch.zeros(shape, **f64)
-
         if stores is None:
-            Ut, Wt, de = rows_buf(ld), rows_buf(ld), rows_buf()
+            Ut, Wt, de = ws["rows"]("Ut"), None, ws["rows"]("de")
         else:
             Ut, Wt, de = stores
-        dbar, zbar, rbar, h = rows_buf(), rows_buf(), rows_buf(ld), rows_buf(ld)
-        S = torch.zeros((nch, nS), **f64)
-        Phi = torch.empty((nch, nS), **f64)
-        cinfo = torch.zeros((nch,), dtype=torch.int32, device=self.device)
+        dbar, zbar, rbar, h, S, Phi, cinfo = (ws[k] for k in ("dbar", "zbar", "rbar", "h", "S", "Phi", "cinfo"))
         opts = (int(self.generator_period), _lib.GF_SWEEP_AUTO)
         coeffs = (p(real[0]), p(real[1]), p(comp[0]), p(comp[1]), p(comp[2]), p(comp[3]))
         tyd = (p(self.t), self._bs(self.t), p(self.diag),
                0 if self.diag is None else self._bs(self.diag), p(self.y), self._bs(self.y))
 
         def sweep(dd, zz, r_out, st_rows):
-            rc = lib.gf_chunk_sweep(1, N, L, nch, self.Jr, self.Jc, block, *opts, *coeffs,
+            rc = lib.gf_chunk_sweep(B, N, L, nch, self.Jr, self.Jc, block, *opts, *coeffs,
                                     p(diag_add), p(cmax), *tyd, p(dd), p(zz), r_out, *st_rows,
                                     p(S), None, p(cinfo), st)
             _lib.check(rc, "gf_chunk_sweep")
 
+        S.zero_()
+        cinfo.zero_()
         if nch > 1:
             # 1. nominal pass: zero start states; d-bar, z-bar, r-bar, u~ rows, reset spans
-            sweep(dbar, zbar, p(rbar), (p(Ut), p(Wt), p(de)))
+            sweep(dbar, zbar, p(rbar), (p(Ut), None, p(de)))
             # 2. closed-loop transitions and the rows h
-            rc = lib.gf_chunk_transition_wide(1, N, L, nch, self.Jc, p(c), p(de), p(dbar), p(rbar),
+            rc = lib.gf_chunk_transition_wide(B, N, L, nch, self.Jc, p(c), p(de), p(dbar), p(rbar),
                                               p(Ut), p(h), p(Phi), st)
             _lib.check(rc, "gf_chunk_transition_wide")
-            # 3. chunk maps (Phi, G, Xbar, Ybar, m) and their tree combine
-            S3, P3 = S.view(nch, ld, RP), Phi.view(nch, ld, RP)
-            Xb = S3[:, :W, :W].transpose(1, 2).contiguous()
-            Yb = S3[:, ld - 1, :W].contiguous()
-            Ph = P3[:, :W, :W].transpose(1, 2).contiguous()
-            Hc = h[:NP].view(nch, L, ld)[:, :, :W]
-            dinv = torch.where(dbar[:NP] > 0, 1.0 / dbar[:NP], torch.zeros_like(dbar[:NP])).view(nch, L, 1)
-            Hd = (Hc * dinv).transpose(1, 2)            # (nch, W, L)
-            G = torch.bmm(Hd, Hc)
-            mm = torch.bmm(Hd, zbar[:NP].view(nch, L, 1)).squeeze(-1)
-            Xs, Ys = _TreeScanGraph.run(torch, Ph, 0.5 * (G + G.transpose(1, 2)),
-                                        0.5 * (Xb + Xb.transpose(1, 2)), Yb, mm)
-            S.zero_()
-            S3[:, :W, :W] = Xs.transpose(1, 2)
-            S3[:, ld - 1, :W] = Ys
+            # 3. chunk maps (Phi, G, Xbar, Ybar, m) and their tree combine: S <- true start states
+            rc = lib.gf_wide_combine(B, N, L, nch, self.Jc, p(h), p(dbar), p(zbar), p(Phi), p(S),
+                                     p(ws["work"]), st)
+            _lib.check(rc, "gf_wide_combine")
             cinfo.zero_()       # (a nominal pass can only fail at or after the true failing row)
         # 4. final pass from the true start states
-        dd = d.reshape(-1) if d is not None else rows_buf()
-        zz = z.reshape(-1) if z is not None else rows_buf()
-        keep = stores is not None and nch > 1
+        dd = d.reshape(-1) if d is not None else ws["rows"]("d")
+        zz = z.reshape(-1) if z is not None else ws["rows"]("z")
         sweep(dd, zz, p(rbar) if keep else None,     # (the TRUE factor's r rows replace the nominal ones)
               (p(Ut), p(Wt), p(de)) if stores is not None else (None, None, None))
         self._wide_tp_bufs = dict(r=rbar, h=h, Phi=Phi) if keep else None
+        # a chunk that failed marks its problem with the FIRST non-positive pivot
+        ci = cinfo.view(B, nch)
         big = torch.iinfo(torch.int32).max
-        first = torch.where(cinfo != 0, cinfo, torch.full_like(cinfo, big)).min()
-        flag = torch.where(first == big, torch.zeros_like(first), first).reshape(1)
+        first = torch.where(ci != 0, ci, torch.full_like(ci, big)).min(dim=1).values
+        flag = torch.where(first == big, torch.zeros_like(first), first)
         if info is not None:
             info.copy_(flag)
         self.info.copy_(flag)
-        work = torch.empty((int(lib.gf_reduce_work(N)),), **f64)
-        acc = torch.empty((1, 3), **f64)
-        out, logdet = torch.empty((1,), **f64), torch.empty((1,), **f64)
-        _lib.check(lib.gf_reduce_tile(1, N, p(dd), p(zz), p(work), p(acc), 1, st), "gf_reduce_tile")
-        _lib.check(lib.gf_loglike_finish(1, N, p(acc), p(self.info), p(out), p(logdet), st),
+        acc = ws["acc"]
+        out = torch.empty((B,), dtype=torch.float64, device=self.device)
+        logdet = torch.empty_like(out)
+        _lib.check(lib.gf_reduce_tile(B, N, p(dd), p(zz), p(ws["red"]), p(acc), 1, st), "gf_reduce_tile")
+        _lib.check(lib.gf_loglike_finish(B, N, p(acc), p(self.info), p(out), p(logdet), st),
                    "gf_loglike_finish")
         self._wide_tp = dict(d=dd, z=zz, acc=acc, chunk_len=L, nch=nch)
+        self._last_wide_tp, self._tp_used = True, False
         return out, logdet, L, nch
 
     @_on_device
@@ -1379,13 +1284,11 @@ class StreamingBatch:
         Same result as :meth:`log_likelihood` to rounding; ~3.5x the flops but O(N / nch)
         sequential depth -- the latency path for B = 1.  Needs the fused kernel's conditions.
         """
-        if self._wide_ok() and not self._fused_ok() and self.B == 1:
-            self._tp_used = False
+        if self._wide_ok() and not self._fused_ok():
             return self._tp_run_wide(chunk_len)[0]
         if not self._fused_ok():
             raise ValueError("time-parallel evaluation needs W <= 63 and |d t| < 3e9")
         if self._tp_chunking(chunk_len)[1] == 1:
-            self._tp_used = False
             return self.log_likelihood()
         return self._tp_run(chunk_len, store=False)[0]
 
@@ -1411,27 +1314,22 @@ class StreamingBatch:
     def evaluate(self, time_parallel=None):
         """(loglike (B,), logdet (B,)) device tensors; picks the time-parallel evaluation for
         few long series (B * N large per problem, B small) unless told otherwise."""
-        if time_parallel is None:
+        auto = time_parallel is None
+        force = getattr(self, "force_streaming", False)
+        if auto:
             # chunking costs ~3.5x the flops: it pays while the batch alone fills less than
             # ~1/8 of the 2048 wave slots (``force_streaming``: benchmarks of the streamed sweep)
-            time_parallel = (self._fused_ok() and self.B <= 256 and self.N >= 8192
-                             and not getattr(self, "force_streaming", False))
+            time_parallel = self._fused_ok() and self.B <= 256 and self.N >= 8192 and not force
+        # few long series with a wide kernel: the exact time-parallel evaluation on W x W chunk maps
         wide_tp = (self._wide_tp_ok() and not self._fused_ok()
-                   and (time_parallel or (time_parallel is None
-                                          and not getattr(self, "force_streaming", False))))
+                   and (bool(time_parallel) or (auto and not force)))
         if time_parallel and self._fused_ok():
             out = self.log_likelihood_time_parallel()
-            acc = self._tp["acc"] if getattr(self, "_tp_key", None) and self._tp_used else self.acc
-        elif wide_tp:               # ONE long series with a wide kernel: exact time-parallel evaluation
-            self._tp_used = False
+        elif wide_tp:
             out = self._tp_run_wide()[0]
-            acc = self._wide_tp["acc"]
-            self._last_wide_tp = True
         else:
-            self._tp_used = False
-            self._last_wide_tp = False
             out = self.log_likelihood()
-            acc = self.acc
+        acc = self.last_acc()
         torch = self.torch
         logdet = torch.where(self.info != 0, torch.full_like(acc[:, 0], float("-inf")), acc[:, 0])
         return out, logdet

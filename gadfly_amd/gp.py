@@ -16,6 +16,7 @@ log-determinant is ``-inf`` and the log-likelihood ``-inf`` (gp.py:188-192).
 """
 import numpy as np
 
+from . import _lib
 from . import units as _units
 from .engine import DeviceBatch, StreamingBatch, LOG_2PI
 
@@ -96,7 +97,6 @@ class ConditionalDistribution:
         an exposure-integrated kernel departs from its celerite coefficients) are patched from
         :meth:`Term.get_value`.  Yields (column slice, K block (N, R), K^-1 K block (N, R)).
         """
-        from . import _lib
         gp = self.gp
         kernel = gp.kernel if self.kernel is None else self.kernel
         xs = gp._t if self.t is None else self.t
@@ -149,9 +149,27 @@ class ConditionalDistribution:
         xs = gp._t if self.t is None else self.t
         blocks = list(self._cross_blocks())
         torch = gp._engine.torch
-        Kall = torch.cat([b[1] for b in blocks], dim=1)             # (N, M)
-        Sall = torch.cat([b[2] for b in blocks], dim=1)
-        return kernel.get_value(xs[:, None] - xs[None, :]) - (Kall.T @ Sall).cpu().numpy()
+        Kall = torch.cat([b[1] for b in blocks], dim=1).contiguous()            # (N, M)
+        Sall = torch.cat([b[2] for b in blocks], dim=1).contiguous()
+        N, M = Kall.shape
+        # K(t, t*)^T K^-1 K(t, t*) on the library's FP64-MFMA GEMM tiles (gf_bgemm, A transposed)
+        lib, p = _lib.load(), _lib.ptr
+        with torch.cuda.device(Kall.device):
+            # the long dimension N is cut into S slabs (one batch entry each: a tile's K-loop is sequential),
+            # the slabs' partial products are added afterwards
+            S = int(min(64, max(1, N // 4096)))
+            Ks = N // S
+            part = torch.empty((S, M, M), dtype=torch.float64, device=Kall.device)
+            st = torch.cuda.current_stream(Kall.device).cuda_stream
+            _lib.check(lib.gf_bgemm(S, 1, 0, M, M, Ks, p(Kall), M, Ks * M, p(Sall), M, Ks * M, None, 0, 0,
+                                    p(part), M, M * M, st), "gf_bgemm")
+            C = part.sum(dim=0)
+            if S * Ks < N:                      # the last N - S Ks rows
+                tail = torch.empty((M, M), dtype=torch.float64, device=Kall.device)
+                _lib.check(lib.gf_bgemm(1, 1, 0, M, M, N - S * Ks, p(Kall[S * Ks:]), M, 0, p(Sall[S * Ks:]), M, 0,
+                                        p(C), M, 0, p(tail), M, 0, st), "gf_bgemm")
+                C = tail
+        return kernel.get_value(xs[:, None] - xs[None, :]) - C.cpu().numpy()
 
     def sample(self, *, size=None, regularize=None):
         mu = self.mean
@@ -399,7 +417,6 @@ class GaussianProcess:
         fast = None
         wide = None
         if W <= 63 or (len(co[0]) == 0 and W <= 176):
-            from . import _lib
             torch = _lib.require_device()       # (fails loudly without a HIP device: no CPU path)
             f64 = dict(dtype=torch.float64, device=self._device_of())
             const = getattr(self, "_diag_const", None)
@@ -470,8 +487,18 @@ class GaussianProcess:
     def _do_norm(self, y, resid=False):
         eng = self._engine
         Y = (self._resid_to_device(y) if resid else self._to_device(y)).reshape(1, self._size, 1)
-        z = eng.solve_lower(Y).reshape(-1)
-        return float((z * z / eng.d[0]).sum().item())
+        z = eng.solve_lower(Y).reshape(-1).contiguous()
+        # sum z^2 / d on the library's fixed-shape reduction tree (gf_reduce_tile: the same deterministic
+        # kernels the batched evaluations finish on)
+        torch, lib, p = eng.torch, _lib.load(), _lib.ptr
+        N = self._size
+        with torch.cuda.device(eng.device):
+            work = torch.empty((int(lib.gf_reduce_work(N)),), dtype=torch.float64, device=eng.device)
+            acc = torch.empty((1, 3), dtype=torch.float64, device=eng.device)
+            st = torch.cuda.current_stream(eng.device).cuda_stream
+            _lib.check(lib.gf_reduce_tile(1, N, p(eng.d[0].contiguous()), p(z), p(work), p(acc), 1, st),
+                       "gf_reduce_tile")
+        return float(acc[0, 1].item())
 
     def _device_of(self):
         import torch

@@ -192,7 +192,8 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
  *                          sequential result to rounding; reduce with gf_reduce_tile.  With
  *                          Ut_out, Wt_out [B][N][64] and de_out [B][N] the pass also stores the
  *                          factor in scaled form (rows u~, w~ = r/d and the reset spans) for
- *                          gf_chunk_linear.
+ *                          gf_chunk_linear.  (Wide kernels, W > 63: Wt_out may be NULL with Ut_out,
+ *                          de_out given -- the nominal pass of their combine needs no w~ rows.)
  * Same argument conventions (gen_period and variant included: pass the SAME values to all
  * calls of one evaluation) and padding rules as gf_loglike_fused; dbar and rbar must be
  * readable two rows past the end.  Width 1..63, phases |d t| < 3e9.
@@ -285,6 +286,48 @@ int gf_chunk_linear_combine_seg(int mode, int B, int nch, int seg_len, int R, co
  * is sequential: celerite2.driver.factor, /root/reference/gadfly/gp.py:202).
  */
 int gf_dense_solve(int batch, int n, int nrhs, const double *A, double *B, void *stream);
+
+/*
+ * The dense combine of the time-parallel factorisation of a WIDE kernel (64 <= W <= 176), all of it in
+ * this library (gadfly_dense.hip: batched FP64-MFMA GEMM tiles, mat-vecs and copies as "job" launches,
+ * gf_dense_solve once per tree level).  celerite2 has no counterpart: its `factor` is sequential
+ * (celerite2.driver.factor <- /root/reference/gadfly/gp.py:202, the reference's default kernel
+ * /root/reference/gadfly/core.py:430-461 has W = 172).
+ *
+ * gf_wide_combine: one call between the nominal pass and the final pass of gf_chunk_sweep.
+ *   in : h, dbar, zbar   rows of the nominal pass / gf_chunk_transition_wide ([B*N (+2)][ld], [B*N], [B*N];
+ *                        ld = gf_fused_row_stride(0, Jc));
+ *        Phi_state       [B*nch][gf_fused_state_size] closed-loop transitions (gf_chunk_transition_wide);
+ *        S_state         [B*nch][gf_fused_state_size] END states of the nominal pass (zero start);
+ *   out: S_state         the TRUE start state of every chunk (what the final pass starts from).
+ *   Steps: pack the states into dense W' x W' maps (W' = gf_dense_width(W), zero pads; identity maps pad
+ *   nch to a power of two P) -> Gram sums G_c = sum h h^T / dbar, m_c = sum h zbar / dbar -> exclusive scan
+ *   over the chunk maps (Blelloch, 2 log2 P - 2 levels of 3 job launches + 1 solve) -> unpack.
+ *   work: gf_wide_combine_work(B, nch, Jc) doubles.  nch >= 2; B * P / 2 <= 65535.
+ * gf_wide_gram, gf_lft_tree_scan: the two middle steps on dense arrays (maps [B*P][W'][W'] / [B*P][W'],
+ *   row-major, W' a multiple of 16 <= 192, pads zero; symmetric G, Xbar): the scan returns the start
+ *   states X_start [B*P][W'][W'], Y_start [B*P][W']; work: gf_lft_tree_work(B, P, W') doubles.
+ * gf_bgemm: C_b = D_b + op(A_b) op(B_b) for b < batch (D may be NULL), row-major, any M, N, K and leading
+ *   dimensions (even leading dimensions and 16-byte aligned bases take the vector-load path); strides in
+ *   elements.  Used for the composed segment transitions and multi-right-hand-side chunk chains of the
+ *   solves on a wide stored factor, and the conditional covariance.
+ */
+int gf_dense_width(int W);
+int64_t gf_wide_combine_work(int B, int nch, int Jc);
+int gf_wide_combine(int B, int64_t N, int64_t chunk_len, int nch, int Jc,
+                    const double *h, const double *dbar, const double *zbar,
+                    const double *Phi_state, double *S_state, double *work, void *stream);
+int gf_wide_gram(int B, int64_t N, int64_t chunk_len, int nch, int P, int Jc,
+                 const double *h, const double *dbar, const double *zbar,
+                 double *G_out, double *m_out, void *stream);
+int64_t gf_lft_tree_work(int B, int P, int WP);
+int gf_lft_tree_scan(int B, int P, int WP, const double *Phi, const double *G, const double *Xbar,
+                     const double *Ybar, const double *m, double *X_start, double *Y_start,
+                     double *work, void *stream);
+int gf_bgemm(int batch, int trans_a, int trans_b, int M, int N, int K,
+             const double *A, int lda, int64_t stride_a, const double *B, int ldb, int64_t stride_b,
+             const double *D, int ldd, int64_t stride_d, double *C, int ldc, int64_t stride_c,
+             void *stream);
 
 /*
  * Log-likelihood reductions (fixed-shape tree, deterministic):

@@ -122,6 +122,72 @@ def test_cfg4_shape_every_entry(hip, path):
     assert np.max(np.abs(ll2 - ll[::-1]) / np.abs(ll[::-1])) <= 1e-12
 
 
+@pytest.mark.parametrize("N,L", [(3000, 256), (2500, 640)], ids=["12chunks", "4chunks-ragged"])
+def test_cfg4_shape_time_parallel_every_entry(hip, N, L):
+    """B = 9 walkers at W = 80, CHUNKED in time (what a GPU's shard of cfg4 runs: 64 walkers cannot fill
+    the chip, so every walker's series is cut into chunks swept concurrently and stitched exactly by the
+    batched dense combine, gf_wide_combine): every entry against the oracle, and against the sequential
+    wide sweep of the same engine."""
+    from gadfly_amd.engine import StreamingBatch
+    B = 9
+    kernels, t, y = _cfg4_problem(B, N)
+    diag = np.full(N, 900.0)
+    eng = StreamingBatch([k.get_device_coefficients() for k in kernels], t, y, diag=diag)
+    assert eng.W == 80 and eng._wide_ok() and not eng._fused_ok()
+    eng.generator_period = 1
+    ll_seq = eng.log_likelihood().cpu().numpy()
+    ll = eng.log_likelihood_time_parallel(chunk_len=L).cpu().numpy()
+    assert eng._last_wide_tp and eng._wide_tp["nch"] == -(-N // L)
+    d_tp = eng._wide_tp["d"][:B * N].view(B, N).cpu().numpy()
+    for i, k in enumerate(kernels):
+        ref = _ref_ll(k, t, diag, y)
+        assert abs(ll[i] - ref) <= RTOL_LL * abs(ref), (i, ll[i], ref)
+        assert abs(ll[i] - ll_seq[i]) <= 1e-10 * abs(ref), (i, ll[i], ll_seq[i])
+    # every pivot of two walkers against the oracle's factor
+    from oracle import cref, seq
+    for i in (0, B - 1):
+        prob = dict(kernel=kernels[i], t=t, diag_user=diag)
+        c, a, U, V = util.oracle_matrices(prob, seq)
+        d_ref, _, _ = cref.factor(t, c, a, U, V)
+        assert _relmax(d_tp[i], d_ref) < 1e-9
+    # the route the product picks for such a shard (long series, few walkers)
+    assert not eng._wide_tp_ok()                       # (too short here: the sequential sweep is used)
+    eng.wide_tp_min_rows = 1024
+    assert eng._wide_tp_ok()
+    out, _ = eng.evaluate()
+    assert eng._last_wide_tp and eng._wide_tp["nch"] > 1
+    assert np.max(np.abs(out.cpu().numpy() - ll) / np.abs(ll)) <= 1e-10
+    # one failing walker (negative diagonal from the middle on): -inf and the first failing row, the others untouched
+    bad = np.tile(diag, (B, 1))
+    bad[4, N // 2:] = -2.0 * kernels[4].get_value(np.zeros(1))[0]
+    engb = StreamingBatch([k.get_device_coefficients() for k in kernels], t, y, diag=bad)
+    engb.generator_period = 1
+    llb = engb.log_likelihood_time_parallel(chunk_len=L).cpu().numpy()
+    assert llb[4] == -np.inf and int(engb.info[4]) == N // 2 + 1
+    ok = np.arange(B) != 4
+    assert np.max(np.abs(llb[ok] - ll[ok]) / np.abs(ll[ok])) <= 1e-10
+
+
+def test_evaluate_picks_the_wide_time_parallel_route(hip):
+    """ONE long series with a wide kernel through evaluate() / BatchedLogLikelihood (no route argument):
+    the exact time-parallel evaluation must be the route taken, and the condition estimate afterwards
+    must read that run's accumulators."""
+    import gadfly_amd
+    N = 20_000
+    kernels, t, y = _cfg4_problem(1, N)
+    ev = gadfly_amd.BatchedLogLikelihood(kernels, t, y, yerr=30.0)
+    ll = ev.evaluate()
+    eng = ev.engine
+    assert eng._last_wide_tp and eng._wide_tp["nch"] > 1
+    ref = _ref_ll(kernels[0], t, np.full(N, 900.0), y)
+    assert abs(ll[0] - ref) <= RTOL_LL * abs(ref)
+    cond = eng.condition_estimate()
+    assert np.isfinite(cond) and cond > 1.0
+    eng.force_streaming = True                          # the streamed sweep on request
+    ll2 = ev.evaluate()
+    assert not eng._last_wide_tp and abs(ll2[0] - ref) <= RTOL_LL * abs(ref)
+
+
 def test_cfg4_full_size_sampled(hip):
     """512 walkers x N = 200 000, J = 40 (W = 80), shared t, y: walkers 0 and 511 against the
     oracle (about 2 s of host time each), all finite."""
@@ -247,10 +313,7 @@ def test_wide_time_parallel(hip, J, N, L, kw):
     ll_seq = float(eng.log_likelihood()[0])
     ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y)
     assert info == 0 and abs(ll_seq - ref) <= RTOL_LL * abs(ref)
-    from gadfly_amd.engine import _TreeScanGraph
     ll_tp = float(eng.log_likelihood_time_parallel(chunk_len=L)[0])
-    # (the dense combine replays a captured HIP graph; an eager fall-back would hide a capture failure)
-    assert not _TreeScanGraph.disabled and len(_TreeScanGraph._cache) >= 1
     assert eng._wide_tp["nch"] > 1
     assert abs(ll_tp - ref) <= RTOL_LL * abs(ref), (ll_tp, ref)
     assert abs(ll_tp - ll_seq) <= 1e-10 * abs(ref)

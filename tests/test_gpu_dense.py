@@ -73,30 +73,108 @@ def test_dense_solve_rejects_bad_sizes(hip):
     assert hip.load().gf_dense_solve(1, 0, 2, hip.ptr(A), hip.ptr(B), None) != 0
 
 
-@pytest.mark.parametrize("nch,W", [(11, 70), (16, 172), (3, 96)])
-def test_lft_tree_scan_against_sequential_application(hip, nch, W):
-    """The Blelloch scan over dense chunk maps (engine._lft_tree_scan: batched GEMMs on strided views +
-    gf_dense_solve, identity maps padding to a power of two) gives the start state of every chunk that
-    applying the maps one after the other gives; the captured-graph replay returns the same numbers."""
+def _padded(a, WP):
+    """(n, W[, W]) -> zero-padded (n, WP[, WP])"""
+    out = np.zeros((a.shape[0],) + (WP,) * (a.ndim - 1))
+    out[(slice(None),) + tuple(slice(0, k) for k in a.shape[1:])] = a
+    return out
+
+
+@pytest.mark.parametrize("B,nch,W", [(1, 11, 70), (1, 16, 172), (1, 3, 96), (3, 5, 80), (2, 2, 66), (1, 1, 80)])
+def test_lft_tree_scan_against_sequential_application(hip, B, nch, W):
+    """The exclusive scan over dense chunk maps (gf_lft_tree_scan: FP64-MFMA GEMM jobs + gf_dense_solve per
+    level, identity maps padding to a power of two, several problems per launch) gives the start state of
+    every chunk that applying the maps one after the other gives (oracle/lft.py, LAPACK solves)."""
     import torch
-    from gadfly_amd.engine import _lft_tree_scan, _lft_apply, _TreeScanGraph
-    g = torch.Generator(device="cuda").manual_seed(100 * nch + W)
-    kw = dict(dtype=torch.float64, device="cuda", generator=g)
-    Ph = 0.7 * torch.randn((nch, W, W), **kw) / W ** 0.5
-    L = torch.randn((nch, W, 6), **kw)
-    Xb = L @ L.transpose(1, 2) / 6
-    M = torch.randn((nch, W, 6), **kw)
-    G = -(M @ M.transpose(1, 2)) / 6
-    Yb = torch.randn((nch, W), **kw)
-    m = torch.randn((nch, W), **kw)
-    Xs, Ys = _lft_tree_scan(torch, Ph, G, Xb, Yb, m)
-    X = torch.zeros((1, W, W), dtype=torch.float64, device="cuda")
-    Y = torch.zeros((1, W), dtype=torch.float64, device="cuda")
-    for c in range(nch):
-        sx = float(X.abs().max()) + 1e-300
-        assert float((Xs[c] - X[0]).abs().max()) <= 1e-9 * max(sx, 1.0), c
-        assert float((Ys[c] - Y[0]).abs().max()) <= 1e-9 * max(float(Y.abs().max()), 1.0), c
-        X, Y = _lft_apply(torch, [a[c:c + 1] for a in (Ph, G, Xb, Yb, m)], X, Y)
-    Xg, Yg = _TreeScanGraph.run(torch, Ph, G, Xb, Yb, m)
-    assert not _TreeScanGraph.disabled
-    assert torch.equal(Xg, Xs) and torch.equal(Yg, Ys)
+    from oracle import lft
+    lib, p = hip.load(), hip.ptr
+    rng = np.random.default_rng(100 * nch + W + B)
+    WP = lib.gf_dense_width(W)
+    P = 1 << max(0, (nch - 1).bit_length())
+    probs = [lft.random_maps(rng, nch, W) for _ in range(B)]
+    arrs = []
+    for k in range(5):
+        a = np.zeros((B * P, WP, WP) if k < 3 else (B * P, WP))
+        for b in range(B):
+            a[b * P:b * P + nch] = _padded(np.stack([M[k] for M in probs[b]]), WP)
+            if k == 0:
+                a[b * P + nch:(b + 1) * P] = np.eye(WP)         # identity maps pad the scan
+        arrs.append(torch.as_tensor(a).cuda())
+    Xs = torch.full((B * P, WP, WP), np.nan, dtype=torch.float64, device="cuda")
+    Ys = torch.full((B * P, WP), np.nan, dtype=torch.float64, device="cuda")
+    nw = int(lib.gf_lft_tree_work(B, P, WP))
+    assert nw >= 0
+    work = torch.empty((max(nw, 1),), dtype=torch.float64, device="cuda")
+    rc = lib.gf_lft_tree_scan(B, P, WP, *[p(a) for a in arrs], p(Xs), p(Ys), p(work), None)
+    hip.check(rc, "gf_lft_tree_scan")
+    torch.cuda.synchronize()
+    Xs, Ys = Xs.cpu().numpy(), Ys.cpu().numpy()
+    assert np.all(np.isfinite(Xs)) and np.all(np.isfinite(Ys))
+    for b in range(B):
+        for c, (X, Y) in enumerate(lft.start_states(probs[b])):
+            got_X, got_Y = Xs[b * P + c], Ys[b * P + c]
+            assert np.abs(got_X[:W, :W] - X).max() <= 1e-9 * max(np.abs(X).max(), 1.0), (b, c)
+            assert np.abs(got_Y[:W] - Y).max() <= 1e-9 * max(np.abs(Y).max(), 1.0), (b, c)
+            assert np.array_equal(got_X, got_X.T)                 # exactly symmetric by construction
+            assert not got_X[W:].any() and not got_X[:, W:].any() and not got_Y[W:].any()
+
+
+@pytest.mark.parametrize("ta,tb,M,N,K", [(0, 0, 64, 64, 64), (0, 0, 172, 172, 172), (0, 1, 80, 96, 50),
+                                          (1, 0, 100, 1, 172), (1, 1, 33, 70, 17), (0, 0, 176, 7, 176),
+                                          (1, 0, 300, 300, 1000)])
+def test_bgemm(hip, ta, tb, M, N, K):
+    """gf_bgemm: C = D + op(A) op(B), batched with strides, against numpy."""
+    import torch
+    lib, p = hip.load(), hip.ptr
+    rng = np.random.default_rng(M + 7 * N + 13 * K + ta + 2 * tb)
+    batch = 3
+    A = rng.normal(size=(batch,) + ((K, M) if ta else (M, K)))
+    Bm = rng.normal(size=(batch,) + ((N, K) if tb else (K, N)))
+    D = rng.normal(size=(batch, M, N))
+    ref = (A.transpose(0, 2, 1) if ta else A) @ (Bm.transpose(0, 2, 1) if tb else Bm)
+    Ad, Bd, Dd = (torch.as_tensor(x).cuda() for x in (A, Bm, D))
+    for with_d in (False, True):
+        C = torch.full((batch, M, N + 3), np.nan, dtype=torch.float64, device="cuda")      # ldc > N
+        rc = lib.gf_bgemm(batch, ta, tb, M, N, K, p(Ad), A.shape[2], A.shape[1] * A.shape[2],
+                          p(Bd), Bm.shape[2], Bm.shape[1] * Bm.shape[2],
+                          p(Dd) if with_d else None, N, M * N, p(C), N + 3, M * (N + 3), None)
+        hip.check(rc, "gf_bgemm")
+        got = C.cpu().numpy()
+        want = ref + (D if with_d else 0.0)
+        assert np.abs(got[:, :, :N] - want).max() <= 1e-12 * K * max(1.0, np.abs(want).max())
+        assert np.all(np.isnan(got[:, :, N:]))                      # nothing written beyond N columns
+    assert lib.gf_bgemm(0, 0, 0, 4, 4, 4, p(Ad), 4, 0, p(Bd), 4, 0, None, 0, 0, p(C), 4, 0, None) != 0
+
+
+@pytest.mark.parametrize("B,J,N,L", [(1, 40, 700, 256), (3, 33, 1000, 192), (1, 86, 900, 320)])
+def test_wide_gram(hip, B, J, N, L):
+    """gf_wide_gram: G_c = sum h h^T / d, m_c = sum h z / d over the rows of every chunk (ragged last chunk,
+    non-positive pivots skipped), written into the dense map slots [B][P]."""
+    import torch
+    lib, p = hip.load(), hip.ptr
+    rng = np.random.default_rng(J + N)
+    W = 2 * J
+    WP, CP = lib.gf_dense_width(W), lib.gf_fused_row_stride(0, J)
+    nch = -(-N // L)
+    P = 1 << max(0, (nch - 1).bit_length())
+    h = np.zeros((B * N + 2, CP))
+    h[:B * N, :W] = rng.normal(size=(B * N, W))
+    d = rng.uniform(0.5, 2.0, size=B * N + 2)
+    d[rng.integers(0, B * N, 5)] = -1.0                             # failed pivots contribute nothing
+    z = rng.normal(size=B * N + 2)
+    hd, dd, zd = (torch.as_tensor(x).cuda() for x in (h, d, z))
+    G = torch.full((B * P, WP, WP), np.nan, dtype=torch.float64, device="cuda")
+    m = torch.full((B * P, WP), np.nan, dtype=torch.float64, device="cuda")
+    rc = lib.gf_wide_gram(B, N, L, nch, P, J, p(hd), p(dd), p(zd), p(G), p(m), None)
+    hip.check(rc, "gf_wide_gram")
+    G, m = G.cpu().numpy(), m.cpu().numpy()
+    for b in range(B):
+        for c in range(nch):
+            r0, r1 = b * N + c * L, b * N + min(N, (c + 1) * L)
+            s = np.where(d[r0:r1] > 0, 1.0 / d[r0:r1], 0.0)
+            Gr = (h[r0:r1, :W] * s[:, None]).T @ h[r0:r1, :W]
+            mr = (h[r0:r1, :W] * s[:, None]).T @ z[r0:r1]
+            g = G[b * P + c]
+            assert np.abs(g[:W, :W] - Gr).max() <= 1e-12 * np.abs(Gr).max() * L
+            assert np.abs(m[b * P + c, :W] - mr).max() <= 1e-12 * np.abs(mr).max() * L
+            assert np.array_equal(g, g.T) and not g[W:].any() and not m[b * P + c, W:].any()
