@@ -172,29 +172,79 @@ struct JobTable {
     Job j[MAX_JOBS];
 };
 
-// y[i] = a[i] + s sum_k Mat(i, k) x[k inc_x],  i < n, k < kn;  Mat(i, k) = trans ? Mt[k ld + i] : Mt[i ld + k]
-__device__ __forceinline__ void job_matvec(const Job &J, const double *Mt, const double *x, const double *a,
-                                           double *y) {
-    const int tid = threadIdx.x, n = J.M, kn = J.K, ld = J.lda, incx = J.ldb, incy = J.ldc;
-    if (J.ta) {                         // lanes along i: coalesced rows of Mt
-        for (int i = tid; i < n; i += 256) {
-            double a0 = 0.0, a1 = 0.0;
-            int k = 0;
-            for (; k + 1 < kn; k += 2) {
-                a0 = fma(Mt[(size_t)k * ld + i], x[(size_t)k * incx], a0);
-                a1 = fma(Mt[(size_t)(k + 1) * ld + i], x[(size_t)(k + 1) * incx], a1);
+template <int CTRL>
+__device__ __forceinline__ double dpp_row(double v) {              // DPP move inside each 16-lane row
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// sum over each 16-lane row, every lane of the row holds it (quad swaps, then the two mirrors)
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_row<0xB1>(v);
+    v += dpp_row<0x4E>(v);
+    v += dpp_row<0x141>(v);
+    v += dpp_row<0x140>(v);
+    return v;
+}
+
+// y[i] = a[i] + s sum_k Mat(i, k) x[k inc_x],  i < n <= 192, k < kn <= 192;
+// Mat(i, k) = trans ? Mt[k ld + i] : Mt[i ld + k].  One workgroup; every load is a coalesced row piece and
+// independent of the others (the scan's mat-vecs sit on the critical path of every level: a dependent
+// chain of loads and wave reductions per row made them the longest job of their launches).
+__device__ __forceinline__ void job_matvec(const Job &J, const double *__restrict__ Mt,
+                                           const double *__restrict__ x, const double *__restrict__ a,
+                                           double *__restrict__ y, double *lds) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n = J.M, kn = J.K, ld = J.lda, incx = J.ldb, incy = J.ldc;
+    double *part = lds;                                 // [4][192]
+    if (J.ta) {                         // lanes along i, the k range split over the four waves
+        const int kq = (kn + 3) >> 2, k0 = w * kq, k1 = (k0 + kq < kn) ? k0 + kq : kn;
+        const int i0 = (lane < n) ? lane : n - 1, i1 = (lane + 64 < n) ? lane + 64 : n - 1,
+                  i2 = (lane + 128 < n) ? lane + 128 : n - 1;
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0;
+        int k = k0;
+        for (; k + 1 < k1; k += 2) {
+            const double xa = x[(size_t)k * incx], xb = x[(size_t)(k + 1) * incx];
+            const double *ra = Mt + (size_t)k * ld, *rb = ra + ld;
+            p0 = fma(ra[i0], xa, p0); p1 = fma(ra[i1], xa, p1); p2 = fma(ra[i2], xa, p2);
+            q0 = fma(rb[i0], xb, q0); q1 = fma(rb[i1], xb, q1); q2 = fma(rb[i2], xb, q2);
+        }
+        if (k < k1) {
+            const double xa = x[(size_t)k * incx];
+            const double *ra = Mt + (size_t)k * ld;
+            p0 = fma(ra[i0], xa, p0); p1 = fma(ra[i1], xa, p1); p2 = fma(ra[i2], xa, p2);
+        }
+        part[w * 192 + lane] = p0 + q0;
+        part[w * 192 + lane + 64] = p1 + q1;
+        part[w * 192 + lane + 128] = p2 + q2;
+    } else {                            // lanes along k; wave w: rows w, w + 4, ..., four at a time
+        const int c0 = (lane < kn) ? lane : kn - 1, c1 = (lane + 64 < kn) ? lane + 64 : kn - 1,
+                  c2 = (lane + 128 < kn) ? lane + 128 : kn - 1;
+        const double x0 = (lane < kn) ? x[(size_t)c0 * incx] : 0.0;
+        const double x1 = (lane + 64 < kn) ? x[(size_t)c1 * incx] : 0.0;
+        const double x2 = (lane + 128 < kn) ? x[(size_t)c2 * incx] : 0.0;
+        for (int i = w; i < n; i += 16) {
+            double p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = (i + 4 * u < n) ? i + 4 * u : n - 1;
+                const double *row = Mt + (size_t)r * ld;
+                p[u] = fma(row[c0], x0, fma(row[c1], x1, row[c2] * x2));
             }
-            if (k < kn) a0 = fma(Mt[(size_t)k * ld + i], x[(size_t)k * incx], a0);
-            y[(size_t)i * incy] = fma(J.s, a0 + a1, a ? a[i] : 0.0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = row16_sum(p[u]);
+            if ((lane & 15) == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i + 4 * u < n) part[(lane >> 4) * 192 + i + 4 * u] = p[u];
+            }
         }
-    } else {                            // one wave per row, lanes along k
-        const int lane = tid & 63, w = tid >> 6;
-        for (int i = w; i < n; i += 4) {
-            double p = 0.0;
-            for (int k = lane; k < kn; k += 64) p = fma(Mt[(size_t)i * ld + k], x[(size_t)k * incx], p);
-            p = wave_sum_x(p);
-            if (lane == 0) y[(size_t)i * incy] = fma(J.s, p, a ? a[i] : 0.0);
-        }
+    }
+    __syncthreads();
+    if (tid < n) {
+        const double v = (part[tid] + part[192 + tid]) + (part[384 + tid] + part[576 + tid]);
+        y[(size_t)tid * incy] = fma(J.s, v, a ? a[tid] : 0.0);
     }
 }
 
@@ -211,7 +261,7 @@ __global__ void __launch_bounds__(256) k_jobs(const JobTable T) {
     const double *D = J.D ? J.D + bi * J.sD : nullptr;
     double *C = J.C + bi * J.sC;
     if (J.type == JOB_MATVEC) {
-        job_matvec(J, A, B, D, C);
+        job_matvec(J, A, B, D, C, lds);
         return;
     }
     if (J.type == JOB_COPY) {                       // rows M x columns N; A == nullptr: zeros
@@ -303,11 +353,15 @@ __global__ void __launch_bounds__(64 * NT)
 k_wide_gram(const int64_t N, const int64_t L, const int nch, const int P, const int CP,
             const double *__restrict__ h_, const double *__restrict__ dbar_, const double *__restrict__ zbar_,
             double *__restrict__ G_out, double *__restrict__ m_out) {
-    constexpr int WP = 16 * NT, NTH = 64 * NT;
+    constexpr int WP = 16 * NT;
     constexpr int HLD = (WP + 31) / 32 * 32 + 16;   // rows k, k + 1 land 32 banks apart
-    constexpr int NV = (8 * WP + NTH - 1) / NTH;    // double2 loads per thread and K-step (= 2)
+    constexpr int NV = 4;                           // double2 loads per thread and K-step (at most)
+    // gridDim.y workgroups share a chunk (few chunks: the reference's default kernel has 128 on 256 CUs):
+    // workgroup y takes the 16-row strips r = y, y + gridDim.y, ... (every workgroup stages all rows h)
+    const int split = gridDim.y, NTH = blockDim.x;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int r = __builtin_amdgcn_readfirstlane(tid >> 6);     // 16-row strip of this wave
+    const int r = __builtin_amdgcn_readfirstlane((int)(tid >> 6) * split + (int)blockIdx.y);
+    const bool live = r < NT;
     const int li = lane & 15, lk = lane >> 4;
     const int slot = blockIdx.x, pr = slot / nch, ch = slot - pr * nch;
     const int64_t c0 = (int64_t)ch * L;
@@ -352,20 +406,23 @@ k_wide_gram(const int64_t N, const int64_t L, const int nch, const int P, const 
     for (int kb = 0; kb < rows; kb += 16) {
         const bool more = kb + 16 < rows;
         if (more) fetch(kb + 16);
-        const double *hrow = &Hs[cur][0];
+        if (live) {
+            const double *hrow = &Hs[cur][0];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int k = 4 * ks + lk;
-            const double av = hrow[k * HLD + 16 * r + li] * Ss[cur][k];
+            for (int ks = 0; ks < 4; ++ks) {
+                const int k = 4 * ks + lk;
+                const double av = hrow[k * HLD + 16 * r + li] * Ss[cur][k];
 #pragma unroll
-            for (int q = 0; q < NT; ++q)
-                if (q >= r) acc[q] = GF_MFMA64(av, hrow[k * HLD + 16 * q + li], acc[q]);
-            acc[NT] = GF_MFMA64(av, (li == 0) ? Zs[cur][k] : 0.0, acc[NT]);
+                for (int q = 0; q < NT; ++q)
+                    if (q >= r) acc[q] = GF_MFMA64(av, hrow[k * HLD + 16 * q + li], acc[q]);
+                acc[NT] = GF_MFMA64(av, (li == 0) ? Zs[cur][k] : 0.0, acc[NT]);
+            }
         }
         if (more) stash(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
+    if (!live) return;
     const size_t mp = (size_t)pr * P + ch;          // dense map index (the scan pads nch to P)
     double *__restrict__ Gd = G_out + mp * ((size_t)WP * WP);
 #pragma unroll
@@ -397,18 +454,23 @@ k_lft_pack(const int nch, const int P, const int W, const int WP, const int CP, 
            double *__restrict__ Ph, double *__restrict__ X, double *__restrict__ Y,
            double *__restrict__ G, double *__restrict__ m) {
     const int mp = blockIdx.x, pr = mp / P, ch = mp - pr * P;
+    const int band = blockIdx.y;                    // dense rows 32 band .. 32 band + 31
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
     const size_t msz = (size_t)WP * WP;
     double *Pd = Ph + mp * msz, *Xd = X + mp * msz, *Yd = Y + (size_t)mp * WP;
+    const int i0 = 32 * band;
     if (ch >= nch) {                                // identity map pads the scan
         double *Gd = G + mp * msz, *md = m + (size_t)mp * WP;
-        for (int e = tid; e < WP * WP; e += 256) {
-            const int i = e / WP, j = e - i * WP;
-            Pd[e] = (i == j) ? 1.0 : 0.0;
-            Xd[e] = 0.0;
-            Gd[e] = 0.0;
+        for (int e = tid; e < 32 * WP; e += 256) {
+            const int i = i0 + e / WP, j = e % WP;
+            if (i < WP) {
+                Pd[(size_t)i * WP + j] = (i == j) ? 1.0 : 0.0;
+                Xd[(size_t)i * WP + j] = 0.0;
+                Gd[(size_t)i * WP + j] = 0.0;
+            }
         }
-        for (int e = tid; e < WP; e += 256) { Yd[e] = 0.0; md[e] = 0.0; }
+        if (band == 0)
+            for (int e = tid; e < WP; e += 256) { Yd[e] = 0.0; md[e] = 0.0; }
         return;
     }
     const size_t slot = (size_t)pr * nch + ch;
@@ -416,8 +478,8 @@ k_lft_pack(const int nch, const int P, const int W, const int WP, const int CP, 
     const double *__restrict__ Ps = Phi_state + slot * ((size_t)CP * RP);
     __shared__ double tP[32][33], tS[32][33];
     const int nt = (WP + 31) / 32;
-    for (int t = 0; t < nt * nt; ++t) {
-        const int i0 = 32 * (t / nt), j0 = 32 * (t % nt);
+    for (int t = 0; t < nt; ++t) {
+        const int j0 = 32 * t;
         // column j0 + a, rows i0 + tx (coalesced along the rows of a state column)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -440,7 +502,8 @@ k_lft_pack(const int nch, const int P, const int W, const int WP, const int CP, 
         }
         __syncthreads();
     }
-    for (int e = tid; e < WP; e += 256) Yd[e] = (e < W) ? Ss[(size_t)(CP - 1) * RP + e] : 0.0;
+    if (band == 0)
+        for (int e = tid; e < WP; e += 256) Yd[e] = (e < W) ? Ss[(size_t)(CP - 1) * RP + e] : 0.0;
 }
 
 __global__ void __launch_bounds__(256)
@@ -451,7 +514,7 @@ k_lft_unpack(const int nch, const int P, const int W, const int WP, const int CP
     const double *__restrict__ Xd = Xs + mp * ((size_t)WP * WP);
     const double *__restrict__ Yd = Ys + mp * WP;
     double *__restrict__ Sd = S_state + (size_t)slot * ((size_t)CP * RP);
-    for (int e = threadIdx.x; e < CP * RP; e += 256) {
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < CP * RP; e += 256 * gridDim.y) {
         const int col = e / RP, row = e - col * RP;
         double v = 0.0;
         if (row < W) {
@@ -602,7 +665,11 @@ bool pow2(int x) { return x >= 1 && (x & (x - 1)) == 0; }
 template <int NT>
 void launch_gram(int slots, int64_t N, int64_t L, int nch, int P, int CP, const double *h, const double *dbar,
                  const double *zbar, double *G, double *m, hipStream_t st) {
-    hipLaunchKernelGGL((k_wide_gram<NT>), dim3(slots), dim3(64 * NT), 0, st, N, L, nch, P, CP, h, dbar, zbar, G, m);
+    // few chunks: two workgroups per chunk, strips dealt alternately (the strips' work falls off linearly)
+    const int split = (slots < 200 && NT >= 4) ? 2 : 1;
+    const int waves = (NT + split - 1) / split;
+    hipLaunchKernelGGL((k_wide_gram<NT>), dim3(slots, split), dim3(64 * waves), 0, st, N, L, nch, P, CP, h, dbar,
+                       zbar, G, m);
 }
 
 int dispatch_gram(int WP, int slots, int64_t N, int64_t L, int nch, int P, int CP, const double *h,
@@ -700,13 +767,13 @@ int gf_wide_combine(int B, int64_t N, int64_t chunk_len, int nch, int Jc, const 
     Maps M0;
     M0.Ph = work; M0.G = work + n * msz; M0.X = work + 2 * n * msz; M0.Y = work + 3 * n * msz; M0.m = M0.Y + n * WP;
     double *Xs = M0.m + n * WP, *Ys = Xs + n * msz, *tw = Ys + n * WP;
-    hipLaunchKernelGGL(k_lft_pack, dim3((unsigned)n), dim3(256), 0, st, nch, P, W, WP, CP, RP, S_state, Phi_state,
+    hipLaunchKernelGGL(k_lft_pack, dim3((unsigned)n, (unsigned)((WP + 31) / 32)), dim3(256), 0, st, nch, P, W, WP, CP, RP, S_state, Phi_state,
                        M0.Ph, M0.X, M0.Y, M0.G, M0.m);
     if (dispatch_gram(WP, B * nch, N, chunk_len, nch, P, CP, h, dbar, zbar, M0.G, M0.m, st))
         return gf_internal_error(-1, "gf_wide_combine: internal dispatch error");
     TreePlan T(B, P, WP);
     if (tree_scan(T, M0, Xs, Ys, tw, st)) return -1;
-    hipLaunchKernelGGL(k_lft_unpack, dim3((unsigned)(B * nch)), dim3(256), 0, st, nch, P, W, WP, CP, RP, Xs, Ys, S_state);
+    hipLaunchKernelGGL(k_lft_unpack, dim3((unsigned)(B * nch), 8), dim3(256), 0, st, nch, P, W, WP, CP, RP, Xs, Ys, S_state);
     return gf_internal_check_launch("gf_wide_combine");
 }
 

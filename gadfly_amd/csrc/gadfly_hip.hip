@@ -1847,17 +1847,40 @@ __device__ __forceinline__ double own_column_sum8(const double a, const double b
     return s;
 }
 
-template <int TR>
-__global__ void __launch_bounds__(64, 2)
+// One LDS-DMA instruction (global_load_lds_dwordx4): lane l copies 16 bytes from ITS OWN global address to
+// LDS byte `lds_byte` + 16 l -- no VGPR destination, so a deep prefetch costs LDS instead of registers.
+// hipcc does not count it: completion is waited for with vm_wait (vector-memory operations retire in
+// issue order).  `after` is a value that must exist before the copy may issue (keeps the copy behind
+// the reads of the ring slot it overwrites).
+__device__ __forceinline__ void glds16(const void *gsrc, const unsigned lds_byte, const int after) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte), "v"(after) : "memory");
+}
+template <int CNT>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(CNT) : "memory"); }
+
+// D ring slots (a power of two) of NI kilobytes per row vector; rows arrive D - 2 rows ahead of their use
+// (the u~ row, the pivot and the reset span of a row travel in ONE slot: lanes 63 / 62 of the last piece
+// fetch the 16-byte pairs that hold dbar[row] / de[row]).  The register queue this replaces was two rows
+// deep: with row arrays beyond the caches (a shard of cfg4: 3 x 9.8 GB) a row cost 0.9 us, all of it
+// memory latency at eight waves per CU.
+template <int TR, int D, int NI>
+__global__ void __launch_bounds__(64, (TR <= 12 && D <= 4) ? 4 : 2)
 k_phiw(const int64_t N, const int64_t chunk_len, const int nch, const int W, const int CP,
        const double *__restrict__ c_, const double *__restrict__ de_, const double *__restrict__ dbar_,
        const double *__restrict__ rbar_, const double *__restrict__ ut_,
        double *__restrict__ h_out, double *__restrict__ Phi_out) {
+    static_assert((D & (D - 1)) == 0 && D >= 4, "ring slots: a power of two");
     constexpr int RP = 8 * TR;                      // state rows, padded
     constexpr int LV = 192;                         // LDS row vectors (CP, RP <= 192)
     constexpr int NL = 3;                           // row entries per lane (lane, lane + 64, lane + 128)
+    constexpr int SL = 128 * NI;                    // doubles per ring slot (CP <= SL - 4)
+    constexpr int SD = SL - 2, SE = SL - 4;         // the row's pivot pair / reset-span pair
     const int lane = threadIdx.x;
-    const int nwv = CP / 16;                        // waves (16-column groups) per chunk
+    // waves (16-column groups) per chunk: groups made of pad columns only are not swept (the combine reads
+    // 16 ceil(W / 16) columns of h and W columns of Phi; what lies beyond is left unwritten)
+    const int nwv = (W + 15) / 16;
     const int slot = blockIdx.x / nwv, wave = blockIdx.x - slot * nwv;
     const int pr = slot / nch, ch = slot - pr * nch;
     const int g = lane >> 3, c = lane & 7;
@@ -1866,24 +1889,53 @@ k_phiw(const int64_t N, const int64_t chunk_len, const int nch, const int W, con
     const int64_t c0 = (int64_t)ch * chunk_len;
     const int64_t rows = (N - c0 < chunk_len) ? (N - c0) : chunk_len;
     const size_t pb = (size_t)pr * N + c0;
-    const double *__restrict__ eg = de_ + pb;
-    const double *__restrict__ dg = dbar_ + pb;
-    const double *__restrict__ rg = rbar_ + pb * CP;
-    const double *__restrict__ ug = ut_ + pb * CP;
     double *__restrict__ hg = h_out + pb * CP + own;
-    __shared__ __attribute__((aligned(16))) double s_w[LV], s_u[LV], s_e[LV];
-    const double2 *pw = (const double2 *)s_w + g, *pu = (const double2 *)s_u + g, *pe = (const double2 *)s_e + g;
-    int idx[NL];
+    __shared__ __attribute__((aligned(16))) double ring_u[D][SL], ring_r[D + 1][SL], s_e[LV];
+    const unsigned lds_u = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(&ring_u[0][0]));
+    const unsigned lds_r = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(&ring_r[0][0]));
+    const double2 *pe = (const double2 *)s_e + g;
     double ci[NL];
-    bool ok[NL];
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
         const int i = lane + 64 * k;
-        ok[k] = i < CP;
-        idx[k] = ok[k] ? i : (CP - 1);
         ci[k] = (i < W) ? c_[(size_t)pr * W + i] : 0.0;
-        s_w[i] = 0.0; s_u[i] = 0.0; s_e[i] = 1.0;   // (LV = 192 = 3 * 64: every entry initialised)
+        s_e[i] = 1.0;                               // (LV = 192 = 3 * 64: every entry initialised)
     }
+    for (int e = lane; e < SL; e += 64) ring_r[D][e] = 0.0;        // "no pending update" for the first row
+    // Per-lane source of piece j of a row's u~ slot / r~ slot: address = cursor & mask, the cursor advancing by
+    // `step` bytes per row.  Data lanes: the row's doubles 128 j + 2 lane (lanes past the row re-read its
+    // start).  Lanes 63 / 62 of the last piece: the aligned 16-byte pair that holds dbar[row] / de[row] (step
+    // 8, mask clears bit 3).  Rows are fetched D - 1 ahead, unconditionally: the caller's arrays are readable
+    // 8 rows past the end.
+    uintptr_t cu[NI], cr[NI], mu[NI];
+    unsigned long long su_step[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int e = 128 * j + 2 * lane;
+        const int ec = (e < CP) ? e : 0;
+        cu[j] = reinterpret_cast<uintptr_t>(ut_ + pb * CP + ec);
+        cr[j] = reinterpret_cast<uintptr_t>(rbar_ + pb * CP + ec);
+        mu[j] = ~(uintptr_t)0;
+        su_step[j] = (unsigned long long)CP * 8;
+        if (j == NI - 1 && lane >= 62) {
+            cu[j] = reinterpret_cast<uintptr_t>((lane == 63 ? dbar_ : de_) + pb);
+            mu[j] = ~(uintptr_t)15;
+            su_step[j] = 8;
+        }
+    }
+    const unsigned long long r_step = (unsigned long long)CP * 8;
+    auto issue = [&](const int64_t m, const int after) {      // row m (the cursors stand at it) -> slot m mod D
+        const unsigned so = (unsigned)(m & (D - 1)) * (SL * 8);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            glds16(reinterpret_cast<const void *>(cu[j] & mu[j]), lds_u + so + 1024 * j, after);
+            glds16(reinterpret_cast<const void *>(cr[j]), lds_r + so + 1024 * j, after);
+            cu[j] += su_step[j];
+            cr[j] += r_step;
+        }
+    };
+#pragma unroll
+    for (int m = 0; m < D - 1; ++m) issue(m, 0);
     double T[TR][2];
 #pragma unroll
     for (int m2 = 0; m2 < TR; ++m2) {               // Phi = I
@@ -1892,51 +1944,37 @@ k_phiw(const int64_t N, const int64_t chunk_len, const int nch, const int W, con
         T[m2][1] = (row == 2 * cb + 1) ? 1.0 : 0.0;
     }
     double q0 = 0.0, q1 = 0.0;
-    // rows n and n + 1 of u~ and r~ in registers (the caller pads both arrays by two rows)
-    const int vz = __builtin_amdgcn_mbcnt_lo(0u, 0u);
-    double u_a[NL], u_b[NL], r_a[NL], r_b[NL];
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-        u_a[k] = ug[idx[k]]; u_b[k] = ug[CP + idx[k]];
-        r_a[k] = rg[idx[k]]; r_b[k] = rg[CP + idx[k]];
-    }
-    double d_a = dg[vz], d_b = dg[1 + vz], e_a = eg[vz], e_b = eg[1 + vz];
+    wave_lds_fence();
     for (int64_t n = 0; n < rows; ++n) {
-        const double dcur = d_a, de = read_lane(e_a, 0);
-        double rcur[NL];
-        wave_lds_fence();
-#pragma unroll
-        for (int k = 0; k < NL; ++k) { if (ok[k]) s_u[lane + 64 * k] = u_a[k]; rcur[k] = r_a[k]; }
+        // row n has landed: the operations issued after its copies are the (D - 2) rows behind it and, once
+        // the loop is in its steady state, one h store per iteration
+        if (n < D - 2) vm_wait<(D - 2) * 2 * NI>();
+        else vm_wait<(D - 2) * (2 * NI + 1)>();
+        const int sl = (int)(n & (D - 1)), par = (int)((pb + n) & 1);
+        const double dcur = ring_u[sl][SD + par];
+        const double de = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(ring_u[sl][SE + par])),
+                                           __builtin_amdgcn_readfirstlane(__double2loint(ring_u[sl][SE + par])));
+        const double2 *pu = (const double2 *)&ring_u[sl][0] + g;
+        const double2 *pw = (const double2 *)&ring_r[(n == 0) ? D : (int)((n - 1) & (D - 1))][0] + g;
         if (de >= 0.0) {                    // reset row: Phi <- E (Phi + pending): row scaling only
 #pragma unroll
-            for (int k = 0; k < NL; ++k) if (ok[k]) s_e[lane + 64 * k] = fm_exp(-ci[k] * de);
+            for (int k = 0; k < NL; ++k) s_e[lane + 64 * k] = fm_exp(-ci[k] * de);
             wave_lds_fence();
             double d0, d1;
             sweepw_run<TR, true, 8>(T, pe, pw, q0, q1, 1.0, 1.0, d0, d1);
             q0 = 0.0;
             q1 = 0.0;
         }
-        // next rows into the register queue
-#pragma unroll
-        for (int k = 0; k < NL; ++k) {
-            u_a[k] = u_b[k]; r_a[k] = r_b[k];
-            u_b[k] = ug[(size_t)(n + 2) * CP + idx[k]];
-            r_b[k] = rg[(size_t)(n + 2) * CP + idx[k]];
-        }
-        d_a = d_b; e_a = e_b;
-        d_b = dg[n + 2 + vz];
-        e_b = eg[n + 2 + vz];
-        wave_lds_fence();
         double acc0, acc1;
         sweepw_run<TR, false, 8>(T, pu, pw, q0, q1, 0.0, 0.0, acc0, acc1);
         const double h = own_column_sum8(acc0, acc1);
         hg[(size_t)n * CP] = h;             // (the four owner lanes of a column write the same value)
-        both_halves(-h / dcur, q0, q1);
-        wave_lds_fence();
-#pragma unroll
-        for (int k = 0; k < NL; ++k) if (ok[k]) s_w[lane + 64 * k] = rcur[k];   // pending: Phi_i -= (r_i / d) h_j
+        both_halves(-h * fast_rcp(dcur), q0, q1);      // pending: Phi_i -= (r_i / d) h_j, row n's r from its ring slot
+        // row n + D - 1 into the slot of row n - 1, whose r~ this iteration's sweeps were the last to read
+        issue(n + D - 1, __double2loint(h));
     }
-    wave_lds_fence();
+    vm_wait<0>();                           // no copy may outlive the wave's LDS allocation
+    const double *s_w = &ring_r[(int)((rows - 1) & (D - 1))][0];
     double *__restrict__ col0 = Phi_out + (size_t)slot * ((size_t)CP * RP) + (size_t)(2 * cb) * RP + 2 * g;
     double *__restrict__ col1 = col0 + RP;
 #pragma unroll
@@ -5023,15 +5061,16 @@ int gf_chunk_transition_wide(int B, int64_t N, int64_t chunk_len, int nch, int J
     if (!c || !de || !dbar || !rbar || !Ut || !h_out || !Phi_out) return set_err("gf_chunk_transition_wide: null pointer%s", "");
     const WideShape ws = wide_shape(W);
     const int CP = 32 * ws.nw, tr8 = ws.tr / 2;     // rows per lane with 8 row groups
-    const int64_t grid = (int64_t)B * nch * (CP / 16);
+    const int64_t grid = (int64_t)B * nch * ((W + 15) / 16);
     if (grid > 0x7fffffffLL) return set_err("gf_chunk_transition_wide: problem too large%s", "");
     hipStream_t st = (hipStream_t)stream;
-#define GF_PW(TRv) case TRv: hipLaunchKernelGGL((k_phiw<TRv>), dim3((unsigned)grid), dim3(64), 0, st, N, chunk_len, nch, W, CP, c, de, dbar, rbar, Ut, h_out, Phi_out); break;
-    switch (tr8) {
-        GF_PW(8) GF_PW(10) GF_PW(12) GF_PW(14) GF_PW(16) GF_PW(18) GF_PW(20) GF_PW(22)
-        default: return set_err("gf_chunk_transition_wide: internal dispatch error%s", "");
-    }
+    // one kilobyte per row vector while the row, its pivot pair and its reset-span pair fit (CP <= 124), else two
+    const int ni = (CP * 8 + 32 <= 1024) ? 1 : 2;
+#define GF_PW(TRv, Dv, NIv) if (tr8 == TRv && ni == NIv) { hipLaunchKernelGGL((k_phiw<TRv, Dv, NIv>), dim3((unsigned)grid), dim3(64), 0, st, N, chunk_len, nch, W, CP, c, de, dbar, rbar, Ut, h_out, Phi_out); return check_launch("gf_chunk_transition_wide"); }
+    GF_PW(8, 4, 1) GF_PW(10, 4, 1) GF_PW(12, 4, 1)
+    GF_PW(12, 4, 2) GF_PW(14, 4, 2) GF_PW(16, 4, 2) GF_PW(18, 4, 2) GF_PW(20, 4, 2) GF_PW(22, 4, 2)
 #undef GF_PW
+    return set_err("gf_chunk_transition_wide: internal dispatch error%s", "");
     return check_launch("gf_chunk_transition_wide");
 }
 

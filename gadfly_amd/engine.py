@@ -455,12 +455,12 @@ class WideFactor:
         B, N = self.B, self.N
         self.ld = int(lib.gf_fused_row_stride(owner.Jr, owner.Jc))
         f64 = dict(dtype=torch.float64, device=self.device)
-        # (two spare rows: the transition sweep reads its rows two ahead, unconditionally)
-        self.Ut = torch.zeros((B * N + 2, self.ld), **f64)[:B * N].view(B, N, self.ld)
+        # (eight spare rows: the transition sweep fetches its rows ahead, unconditionally)
+        self.Ut = torch.zeros((B * N + 8, self.ld), **f64)[:B * N].view(B, N, self.ld)
         self.Wt = torch.empty((B, N, self.ld), **f64)
-        self.de = torch.zeros((B * N + 2,), **f64)[:B * N].view(B, N)
-        self.d = torch.zeros((B * N + 2,), **f64)[:B * N].view(B, N)
-        self.z = torch.zeros((B * N + 2,), **f64)[:B * N].view(B, N)
+        self.de = torch.zeros((B * N + 8,), **f64)[:B * N].view(B, N)
+        self.d = torch.zeros((B * N + 8,), **f64)[:B * N].view(B, N)
+        self.z = torch.zeros((B * N + 8,), **f64)[:B * N].view(B, N)
         real, comp, diag_add, c, cmax, block, _ = owner._pack
         self.c, self.t = c, owner.t
         self.info = torch.zeros((B,), dtype=torch.int32, device=self.device)
@@ -1173,7 +1173,7 @@ class StreamingBatch:
 
     def _wide_ws(self, L, nch, keep):
         """Row and state buffers of the wide time-parallel run, kept between evaluations (rows of all
-        problems back to back, four spare rows: the sweeps prefetch ahead unconditionally)."""
+        problems back to back, eight spare rows: the sweeps prefetch ahead unconditionally)."""
         torch, lib = self.torch, self.lib
         key = (L, nch)
         # (a stored factor keeps r-bar / h / Phi for its lazily built chunk transitions: buffers of its own)
@@ -1183,7 +1183,7 @@ class StreamingBatch:
             ld = int(lib.gf_fused_row_stride(self.Jr, self.Jc))
             nS = int(lib.gf_fused_state_size(self.Jr, self.Jc))
             f64 = dict(dtype=torch.float64, device=self.device)
-            rows = B * N + 4
+            rows = B * N + 8
             ws = dict(key=key, ld=ld, nS=nS,
                       dbar=torch.zeros((rows,), **f64), zbar=torch.zeros((rows,), **f64),
                       rbar=torch.zeros((rows, ld), **f64), h=torch.zeros((rows, ld), **f64),
@@ -1197,7 +1197,7 @@ class StreamingBatch:
         def rows(name):
             """row buffer `name` of the workspace, allocated on first use"""
             if name not in ws:
-                shape = (self.B * self.N + 4, ws["ld"]) if name == "Ut" else (self.B * self.N + 4,)
+                shape = (self.B * self.N + 8, ws["ld"]) if name == "Ut" else (self.B * self.N + 8,)
                 ws[name] = torch.zeros(shape, dtype=torch.float64, device=self.device)
             return ws[name]
 

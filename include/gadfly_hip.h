@@ -231,11 +231,12 @@ int gf_scaled_propagator(int B, int64_t N, int W, int ld, const double *c, const
 /*
  * Wide kernels (64 <= W <= 176, complex terms): the closed-loop transition sweep of step 2 on the rows
  * the nominal pass stored -- Ut [B][N][ld] (u~ rows), rbar [B][N][ld], dbar [B][N], de [B][N] (reset
- * spans), ld = gf_fused_row_stride; c [B][W] decay rates; every array readable two rows past the
- * end.  Outputs the rows h [B][N][ld] and Phi [B*nch][gf_fused_state_size] in the layout of S_state
- * ([column][row], padded).  The Gram sums G = sum h h^T / dbar, m = sum h zbar / dbar and the
- * combines of the W x W chunk maps are plain dense GEMMs / solves on these outputs: the caller runs
- * them as library calls (rocBLAS / hipSOLVER; the Python side uses torch.bmm / torch.linalg.solve).
+ * spans), ld = gf_fused_row_stride; c [B][W] decay rates; Ut, rbar, dbar and de readable EIGHT rows
+ * past the end (the rows are fetched ahead by LDS-DMA, unconditionally).  Outputs the rows h [B][N][ld]
+ * and Phi [B*nch][gf_fused_state_size] in the layout of S_state ([column][row], padded; columns from
+ * 16 ceil(W / 16) on are left unwritten in both).  The Gram sums
+ * G = sum h h^T / dbar, m = sum h zbar / dbar and the combine of the W x W chunk maps follow in
+ * gf_wide_combine.
  */
 int gf_chunk_transition_wide(int B, int64_t N, int64_t chunk_len, int nch, int Jc,
                              const double *c, const double *de, const double *dbar, const double *rbar,

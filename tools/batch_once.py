@@ -20,7 +20,12 @@ reps = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 hps, t, y, texp = cfg4_walkers(B, N, J)
 kernels = [gadfly_amd.StellarOscillatorKernel(hp, texp=texp) for hp in hps]
 ev = gadfly_amd.BatchedLogLikelihood(kernels, t, y, yerr=30.0)
-ev.engine.force_streaming = True
+ev.engine.force_streaming = os.environ.get("ROUTE", "stream") == "stream"     # ROUTE=auto: the product's choice
+if os.environ.get("CHUNK_LEN"):                 # time-parallel route with a given chunk length
+    ev.engine.force_streaming = False
+    ev.engine.wide_tp_min_rows = 0
+    _len = int(os.environ["CHUNK_LEN"])
+    ev.engine._wide_chunking = (lambda chunk_len, _orig=ev.engine._wide_chunking: _orig(_len))
 ev.engine.generator_period = int(os.environ.get("GEN_PERIOD", "64"))
 ev.auto_generator_period = False
 for _ in range(reps):

@@ -71,7 +71,7 @@ def measure_cfg3(frac=1.0, jitter=False):
     W = 2 * J
     gb = 8.0 * N * (3 * W + 4) * B / 1e9
     i = min(100, B - 1)
-    path, period = _path(ev.engine), int(ev.engine.generator_period)
+    path, period, reruns = _path(ev.engine), int(ev.engine.generator_period), int(ev.guard_reruns)
     extra = {}
     if not jitter:      # the same batch with +-0.2 s jitter on every other star's time stamps (exact rows)
         del ev
@@ -81,7 +81,7 @@ def measure_cfg3(frac=1.0, jitter=False):
                         + ("every other star with jittered time stamps" if jitter else "uniform 58.85 s cadence"),
             "value": B / dt, "unit": "evals/s", "ms": 1e3 * dt, "algorithmic_GB": gb,
             "algorithmic_GBs": gb / dt, "frac": gb / dt / HBM_PEAK_GBS, "path": path,
-            "generator_period": period, "guard_reruns": int(ev.guard_reruns),
+            "generator_period": period, "guard_reruns": reruns,
             "all_finite": bool(np.all(np.isfinite(ll))),
             "_sample": dict(kind="loglike", index=i, coeffs=kernels[i].get_device_coefficients(),
                             t=t[i], diag=yerr[i] ** 2, y=y[i], got=float(ll[i]))}
