@@ -62,7 +62,7 @@ SIGNATURES = {
     "gf_dense_width": (_int, [_int]),
     "gf_wide_combine_work": (_i64, [_int, _int, _int]),
     "gf_wide_combine": (_int, [_int, _i64, _i64, _int, _int] + [_vp] * 6 + [_vp]),
-    "gf_wide_gram": (_int, [_int, _i64, _i64, _int, _int, _int] + [_vp] * 5 + [_vp]),
+    "gf_wide_gram": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int] + [_vp] * 5 + [_vp]),
     "gf_lft_tree_work": (_i64, [_int, _int, _int]),
     "gf_lft_tree_scan": (_int, [_int, _int, _int] + [_vp] * 8 + [_vp]),
     "gf_bgemm": (_int, [_int, _int, _int, _int, _int, _int, _vp, _int, _i64, _vp, _int, _i64,
@@ -71,7 +71,7 @@ SIGNATURES = {
     "gf_chunk_linear_combine_seg": (_int, [_int, _int, _int, _int, _int] + [_vp] * 4 + [_vp]),
     "gf_chunk_transition": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int, _int] + [_vp] * 7
                             + [_vp, _i64] + [_vp] * 7 + [_vp]),
-    "gf_chunk_transition_wide": (_int, [_int, _i64, _i64, _int, _int] + [_vp] * 7 + [_vp]),
+    "gf_chunk_transition_wide": (_int, [_int, _i64, _i64, _int, _int, _int, _int] + [_vp] * 7 + [_vp]),
     "gf_chunk_combine": (_int, [_int, _int] + [_vp] * 5 + [_vp]),
     "gf_chunk_combine_tree": (_int, [_int, _int] + [_vp] * 7 + [_vp]),
     "gf_reduce_work": (_i64, [_i64]),

@@ -350,8 +350,8 @@ struct JobBuilder {
 // ------------------------------------------------------------------------------------------------
 template <int NT>                       // WP = 16 NT
 __global__ void __launch_bounds__(64 * NT)
-k_wide_gram(const int64_t N, const int64_t L, const int nch, const int P, const int CP,
-            const double *__restrict__ h_, const double *__restrict__ dbar_, const double *__restrict__ zbar_,
+k_wide_gram(const int64_t N, const int64_t L, const int nch, const int ch0, const int nsel, const int P,
+            const int CP, const double *__restrict__ h_, const double *__restrict__ dbar_, const double *__restrict__ zbar_,
             double *__restrict__ G_out, double *__restrict__ m_out) {
     constexpr int WP = 16 * NT;
     constexpr int HLD = (WP + 31) / 32 * 32 + 16;   // rows k, k + 1 land 32 banks apart
@@ -363,7 +363,7 @@ k_wide_gram(const int64_t N, const int64_t L, const int nch, const int P, const 
     const int r = __builtin_amdgcn_readfirstlane((int)(tid >> 6) * split + (int)blockIdx.y);
     const bool live = r < NT;
     const int li = lane & 15, lk = lane >> 4;
-    const int slot = blockIdx.x, pr = slot / nch, ch = slot - pr * nch;
+    const int sel = blockIdx.x, pr = sel / nsel, ch = ch0 + (sel - pr * nsel);      // chunks ch0 .. ch0 + nsel - 1
     const int64_t c0 = (int64_t)ch * L;
     const int rows = (int)((N - c0 < L) ? (N - c0) : L);
     const size_t pb = (size_t)pr * N + c0;
@@ -459,7 +459,10 @@ k_lft_pack(const int nch, const int P, const int W, const int WP, const int CP, 
     const size_t msz = (size_t)WP * WP;
     double *Pd = Ph + mp * msz, *Xd = X + mp * msz, *Yd = Y + (size_t)mp * WP;
     const int i0 = 32 * band;
-    if (ch >= nch) {                                // identity map pads the scan
+    // The start states never depend on the LAST chunk's map, and on the FIRST chunk's only through its end
+    // state from a zero start (Xbar, Ybar): the last chunk becomes one more identity map, the first keeps
+    // Xbar, Ybar with Phi = G = m = 0 -- so callers need not sweep transitions or Gram sums for either.
+    if (ch >= nch - 1) {                            // identity map pads the scan
         double *Gd = G + mp * msz, *md = m + (size_t)mp * WP;
         for (int e = tid; e < 32 * WP; e += 256) {
             const int i = i0 + e / WP, j = e % WP;
@@ -493,7 +496,8 @@ k_lft_pack(const int nch, const int P, const int W, const int WP, const int CP, 
         for (int q = 0; q < 4; ++q) {
             const int a = ty + 8 * q, i = i0 + a, j = j0 + tx;      // dense row i, column j
             if (i < WP && j < WP) {
-                Pd[(size_t)i * WP + j] = tP[tx][a];
+                Pd[(size_t)i * WP + j] = (ch == 0) ? 0.0 : tP[tx][a];
+                if (ch == 0) G[mp * msz + (size_t)i * WP + j] = 0.0;
                 // X symmetrised: (S(i, j) + S(j, i)) / 2, S(j, i) read straight (row i of the dense
                 // matrix = column i of the state: coalesced along j)
                 const double sji = (i < W && j < W) ? Ss[(size_t)i * RP + j] : 0.0;
@@ -503,7 +507,10 @@ k_lft_pack(const int nch, const int P, const int W, const int WP, const int CP, 
         __syncthreads();
     }
     if (band == 0)
-        for (int e = tid; e < WP; e += 256) Yd[e] = (e < W) ? Ss[(size_t)(CP - 1) * RP + e] : 0.0;
+        for (int e = tid; e < WP; e += 256) {
+            Yd[e] = (e < W) ? Ss[(size_t)(CP - 1) * RP + e] : 0.0;
+            if (ch == 0) m[(size_t)mp * WP + e] = 0.0;
+        }
 }
 
 __global__ void __launch_bounds__(256)
@@ -663,19 +670,21 @@ int tree_scan(const TreePlan &T, const Maps &M0, double *Xs0, double *Ys0, doubl
 bool pow2(int x) { return x >= 1 && (x & (x - 1)) == 0; }
 
 template <int NT>
-void launch_gram(int slots, int64_t N, int64_t L, int nch, int P, int CP, const double *h, const double *dbar,
-                 const double *zbar, double *G, double *m, hipStream_t st) {
+void launch_gram(int B, int64_t N, int64_t L, int nch, int ch0, int nsel, int P, int CP, const double *h,
+                 const double *dbar, const double *zbar, double *G, double *m, hipStream_t st) {
     // few chunks: two workgroups per chunk, strips dealt alternately (the strips' work falls off linearly)
+    const int slots = B * nsel;
     const int split = (slots < 200 && NT >= 4) ? 2 : 1;
     const int waves = (NT + split - 1) / split;
-    hipLaunchKernelGGL((k_wide_gram<NT>), dim3(slots, split), dim3(64 * waves), 0, st, N, L, nch, P, CP, h, dbar,
-                       zbar, G, m);
+    hipLaunchKernelGGL((k_wide_gram<NT>), dim3(slots, split), dim3(64 * waves), 0, st, N, L, nch, ch0, nsel, P, CP,
+                       h, dbar, zbar, G, m);
 }
 
-int dispatch_gram(int WP, int slots, int64_t N, int64_t L, int nch, int P, int CP, const double *h,
+int dispatch_gram(int WP, int B, int64_t N, int64_t L, int nch, int ch0, int nsel, int P, int CP, const double *h,
                   const double *dbar, const double *zbar, double *G, double *m, hipStream_t st) {
+    if (nsel < 1) return 0;
     switch (WP / 16) {
-#define GF_GR(n) case n: launch_gram<n>(slots, N, L, nch, P, CP, h, dbar, zbar, G, m, st); return 0;
+#define GF_GR(n) case n: launch_gram<n>(B, N, L, nch, ch0, nsel, P, CP, h, dbar, zbar, G, m, st); return 0;
         GF_GR(4) GF_GR(5) GF_GR(6) GF_GR(7) GF_GR(8) GF_GR(9) GF_GR(10) GF_GR(11)
 #undef GF_GR
     }
@@ -726,16 +735,19 @@ int gf_lft_tree_scan(int B, int P, int WP, const double *Phi, const double *G, c
     return tree_scan(T, M0, X_start, Y_start, work, (hipStream_t)stream);
 }
 
-int gf_wide_gram(int B, int64_t N, int64_t chunk_len, int nch, int P, int Jc, const double *h,
-                 const double *dbar, const double *zbar, double *G_out, double *m_out, void *stream) {
+int gf_wide_gram(int B, int64_t N, int64_t chunk_len, int nch, int chunk_first, int chunk_count, int P, int Jc,
+                 const double *h, const double *dbar, const double *zbar, double *G_out, double *m_out, void *stream) {
     const int W = 2 * Jc, WP = gf_dense_width(W);
     const int CP = gf_fused_row_stride(0, Jc);
     if (B < 1 || N < 1) return gf_internal_error(-1, "gf_wide_gram: empty problem (N=%lld)", (long long)N);
     if (W <= 63 || CP < 0 || WP > 176) return gf_internal_error(-1, "gf_wide_gram: width %d unsupported (64..176)", W);
     if (nch < 1 || chunk_len < 1 || (int64_t)nch * chunk_len < N || (int64_t)(nch - 1) * chunk_len >= N || P < nch)
         return gf_internal_error(-1, "gf_wide_gram: bad chunking (chunk_len=%lld, nch=%d, P=%d)", (long long)chunk_len, nch, P);
+    if (chunk_first < 0 || chunk_count < 0 || chunk_first + chunk_count > nch)
+        return gf_internal_error(-1, "gf_wide_gram: bad chunk range (first=%d, count=%d)", chunk_first, chunk_count);
     if (!h || !dbar || !zbar || !G_out || !m_out) return gf_internal_error(-1, "gf_wide_gram: null pointer");
-    if (dispatch_gram(WP, B * nch, N, chunk_len, nch, P, CP, h, dbar, zbar, G_out, m_out, (hipStream_t)stream))
+    if (dispatch_gram(WP, B, N, chunk_len, nch, chunk_first, chunk_count, P, CP, h, dbar, zbar, G_out, m_out,
+                      (hipStream_t)stream))
         return gf_internal_error(-1, "gf_wide_gram: internal dispatch error");
     return gf_internal_check_launch("gf_wide_gram");
 }
@@ -769,7 +781,8 @@ int gf_wide_combine(int B, int64_t N, int64_t chunk_len, int nch, int Jc, const 
     double *Xs = M0.m + n * WP, *Ys = Xs + n * msz, *tw = Ys + n * WP;
     hipLaunchKernelGGL(k_lft_pack, dim3((unsigned)n, (unsigned)((WP + 31) / 32)), dim3(256), 0, st, nch, P, W, WP, CP, RP, S_state, Phi_state,
                        M0.Ph, M0.X, M0.Y, M0.G, M0.m);
-    if (dispatch_gram(WP, B * nch, N, chunk_len, nch, P, CP, h, dbar, zbar, M0.G, M0.m, st))
+    // (the maps of the first and the last chunk are not needed: see k_lft_pack)
+    if (dispatch_gram(WP, B, N, chunk_len, nch, 1, nch - 2, P, CP, h, dbar, zbar, M0.G, M0.m, st))
         return gf_internal_error(-1, "gf_wide_combine: internal dispatch error");
     TreePlan T(B, P, WP);
     if (tree_scan(T, M0, Xs, Ys, tw, st)) return -1;

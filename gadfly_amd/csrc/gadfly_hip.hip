@@ -1867,7 +1867,8 @@ __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :
 // memory latency at eight waves per CU.
 template <int TR, int D, int NI>
 __global__ void __launch_bounds__(64, (TR <= 12 && D <= 4) ? 4 : 2)
-k_phiw(const int64_t N, const int64_t chunk_len, const int nch, const int W, const int CP,
+k_phiw(const int64_t N, const int64_t chunk_len, const int nch, const int ch0, const int nsel, const int W,
+       const int CP,
        const double *__restrict__ c_, const double *__restrict__ de_, const double *__restrict__ dbar_,
        const double *__restrict__ rbar_, const double *__restrict__ ut_,
        double *__restrict__ h_out, double *__restrict__ Phi_out) {
@@ -1881,8 +1882,9 @@ k_phiw(const int64_t N, const int64_t chunk_len, const int nch, const int W, con
     // waves (16-column groups) per chunk: groups made of pad columns only are not swept (the combine reads
     // 16 ceil(W / 16) columns of h and W columns of Phi; what lies beyond is left unwritten)
     const int nwv = (W + 15) / 16;
-    const int slot = blockIdx.x / nwv, wave = blockIdx.x - slot * nwv;
-    const int pr = slot / nch, ch = slot - pr * nch;
+    const int sel = blockIdx.x / nwv, wave = blockIdx.x - sel * nwv;
+    const int pr = sel / nsel, ch = ch0 + (sel - pr * nsel);       // chunks ch0 .. ch0 + nsel - 1 of every problem
+    const int slot = pr * nch + ch;
     const int g = lane >> 3, c = lane & 7;
     const int cb = wave * 8 + c;                    // column pair of this lane
     const int own = 2 * cb + (lane >> 5);           // its own column (h, multipliers)
@@ -5049,10 +5051,13 @@ int gf_chunk_combine_tree(int B, int P, double *Phi, double *G, double *m, doubl
     return check_launch("gf_chunk_combine_tree");
 }
 
-int gf_chunk_transition_wide(int B, int64_t N, int64_t chunk_len, int nch, int Jc,
-                             const double *c, const double *de, const double *dbar, const double *rbar,
+int gf_chunk_transition_wide(int B, int64_t N, int64_t chunk_len, int nch, int chunk_first, int chunk_count,
+                             int Jc, const double *c, const double *de, const double *dbar, const double *rbar,
                              const double *Ut, double *h_out, double *Phi_out, void *stream) {
     const int W = 2 * Jc;
+    if (chunk_first < 0 || chunk_count < 0 || chunk_first + chunk_count > nch)
+        return set_err("gf_chunk_transition_wide: bad chunk range (first=%s%lld, count=%lld)", "", chunk_first, chunk_count);
+    if (chunk_count == 0) return 0;
     if (B < 1 || N < 1) return set_err("gf_chunk_transition_wide: empty problem (N=%s%lld)", "", N);
     if (W <= 63 || !gf_fused_supported(0, Jc)) return set_err("gf_chunk_transition_wide: width %s%lld unsupported (64..176)", "", W);
     if (nch < 1 || chunk_len < 1 || (nch > 1 && (chunk_len % 64) != 0) || (int64_t)nch * chunk_len < N
@@ -5061,12 +5066,12 @@ int gf_chunk_transition_wide(int B, int64_t N, int64_t chunk_len, int nch, int J
     if (!c || !de || !dbar || !rbar || !Ut || !h_out || !Phi_out) return set_err("gf_chunk_transition_wide: null pointer%s", "");
     const WideShape ws = wide_shape(W);
     const int CP = 32 * ws.nw, tr8 = ws.tr / 2;     // rows per lane with 8 row groups
-    const int64_t grid = (int64_t)B * nch * ((W + 15) / 16);
+    const int64_t grid = (int64_t)B * chunk_count * ((W + 15) / 16);
     if (grid > 0x7fffffffLL) return set_err("gf_chunk_transition_wide: problem too large%s", "");
     hipStream_t st = (hipStream_t)stream;
     // one kilobyte per row vector while the row, its pivot pair and its reset-span pair fit (CP <= 124), else two
     const int ni = (CP * 8 + 32 <= 1024) ? 1 : 2;
-#define GF_PW(TRv, Dv, NIv) if (tr8 == TRv && ni == NIv) { hipLaunchKernelGGL((k_phiw<TRv, Dv, NIv>), dim3((unsigned)grid), dim3(64), 0, st, N, chunk_len, nch, W, CP, c, de, dbar, rbar, Ut, h_out, Phi_out); return check_launch("gf_chunk_transition_wide"); }
+#define GF_PW(TRv, Dv, NIv) if (tr8 == TRv && ni == NIv) { hipLaunchKernelGGL((k_phiw<TRv, Dv, NIv>), dim3((unsigned)grid), dim3(64), 0, st, N, chunk_len, nch, chunk_first, chunk_count, W, CP, c, de, dbar, rbar, Ut, h_out, Phi_out); return check_launch("gf_chunk_transition_wide"); }
     GF_PW(8, 4, 1) GF_PW(10, 4, 1) GF_PW(12, 4, 1)
     GF_PW(12, 4, 2) GF_PW(14, 4, 2) GF_PW(16, 4, 2) GF_PW(18, 4, 2) GF_PW(20, 4, 2) GF_PW(22, 4, 2)
 #undef GF_PW

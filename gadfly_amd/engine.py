@@ -516,7 +516,7 @@ class WideFactor:
             torch, lib, p = self.torch, self.lib, _lib.ptr
             w = self._tp_bufs
             st = torch.cuda.current_stream(self.device).cuda_stream
-            rc = lib.gf_chunk_transition_wide(1, self.N, self.chunk_len, self.nch, self.owner.Jc, p(self.c),
+            rc = lib.gf_chunk_transition_wide(1, self.N, self.chunk_len, self.nch, 0, self.nch, self.owner.Jc, p(self.c),
                                               p(self.de), p(self.d), p(w["r"]), p(self.Ut), p(w["h"]),
                                               p(w["Phi"]), st)
             _lib.check(rc, "gf_chunk_transition_wide")
@@ -1240,28 +1240,41 @@ class StreamingBatch:
 
         S.zero_()
         cinfo.zero_()
+        ci = cinfo.view(B, nch)
+        skip_first = nch > 1 and stores is None     # chunk 0 starts from zero: its nominal pass IS its final pass
+        ci0 = None
         if nch > 1:
-            # 1. nominal pass: zero start states; d-bar, z-bar, r-bar, u~ rows, reset spans
+            # 1. nominal pass: zero start states; d-bar, z-bar, r-bar, u~ rows, reset spans.  Nothing of the LAST
+            #    chunk's map is ever needed (gf_wide_combine): its slots are marked done and exit at once
+            ci[:, nch - 1] = -1
             sweep(dbar, zbar, p(rbar), (p(Ut), None, p(de)))
-            # 2. closed-loop transitions and the rows h
-            rc = lib.gf_chunk_transition_wide(B, N, L, nch, self.Jc, p(c), p(de), p(dbar), p(rbar),
-                                              p(Ut), p(h), p(Phi), st)
+            # 2. closed-loop transitions and the rows h (not for the first chunk either: from a zero start
+            #    state its map acts through its end state alone)
+            rc = lib.gf_chunk_transition_wide(B, N, L, nch, 1, nch - 2, self.Jc, p(c), p(de), p(dbar),
+                                              p(rbar), p(Ut), p(h), p(Phi), st)
             _lib.check(rc, "gf_chunk_transition_wide")
             # 3. chunk maps (Phi, G, Xbar, Ybar, m) and their tree combine: S <- true start states
             rc = lib.gf_wide_combine(B, N, L, nch, self.Jc, p(h), p(dbar), p(zbar), p(Phi), p(S),
                                      p(ws["work"]), st)
             _lib.check(rc, "gf_wide_combine")
-            cinfo.zero_()       # (a nominal pass can only fail at or after the true failing row)
+            ci0 = ci[:, 0].clone()      # (a nominal pass can only fail at or after the true failing row: the
+            cinfo.zero_()               #  final pass decides -- except for chunk 0, whose nominal pass is exact)
         # 4. final pass from the true start states
         dd = d.reshape(-1) if d is not None else ws["rows"]("d")
         zz = z.reshape(-1) if z is not None else ws["rows"]("z")
+        if skip_first:
+            L0 = min(L, N)
+            dd[:B * N].view(B, N)[:, :L0] = dbar[:B * N].view(B, N)[:, :L0]
+            zz[:B * N].view(B, N)[:, :L0] = zbar[:B * N].view(B, N)[:, :L0]
+            ci[:, 0] = -1
         sweep(dd, zz, p(rbar) if keep else None,     # (the TRUE factor's r rows replace the nominal ones)
               (p(Ut), p(Wt), p(de)) if stores is not None else (None, None, None))
+        if skip_first:
+            ci[:, 0] = ci0
         self._wide_tp_bufs = dict(r=rbar, h=h, Phi=Phi) if keep else None
         # a chunk that failed marks its problem with the FIRST non-positive pivot
-        ci = cinfo.view(B, nch)
         big = torch.iinfo(torch.int32).max
-        first = torch.where(ci != 0, ci, torch.full_like(ci, big)).min(dim=1).values
+        first = torch.where(ci > 0, ci, torch.full_like(ci, big)).min(dim=1).values
         flag = torch.where(first == big, torch.zeros_like(first), first)
         if info is not None:
             info.copy_(flag)

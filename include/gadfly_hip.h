@@ -236,9 +236,9 @@ int gf_scaled_propagator(int B, int64_t N, int W, int ld, const double *c, const
  * and Phi [B*nch][gf_fused_state_size] in the layout of S_state ([column][row], padded; columns from
  * 16 ceil(W / 16) on are left unwritten in both).  The Gram sums
  * G = sum h h^T / dbar, m = sum h zbar / dbar and the combine of the W x W chunk maps follow in
- * gf_wide_combine.
+ * gf_wide_combine.  Only the chunks chunk_first .. chunk_first + chunk_count - 1 of every problem are swept.
  */
-int gf_chunk_transition_wide(int B, int64_t N, int64_t chunk_len, int nch, int Jc,
+int gf_chunk_transition_wide(int B, int64_t N, int64_t chunk_len, int nch, int chunk_first, int chunk_count, int Jc,
                              const double *c, const double *de, const double *dbar, const double *rbar,
                              const double *Ut, double *h_out, double *Phi_out, void *stream);
 int gf_chunk_combine(int B, int nch, const double *Phi, const double *G, const double *m,
@@ -301,6 +301,10 @@ int gf_dense_solve(int batch, int n, int nrhs, const double *A, double *B, void 
  *        Phi_state       [B*nch][gf_fused_state_size] closed-loop transitions (gf_chunk_transition_wide);
  *        S_state         [B*nch][gf_fused_state_size] END states of the nominal pass (zero start);
  *   out: S_state         the TRUE start state of every chunk (what the final pass starts from).
+ *   The start states do not depend on the LAST chunk's map at all, and on the FIRST chunk's only through
+ *   its end state: h, dbar, zbar and Phi_state are read for the chunks 1 .. nch - 2 only, S_state of the last
+ *   chunk is not read -- the caller may skip the last chunk in the nominal pass and both end chunks in
+ *   gf_chunk_transition_wide (chunk_first = 1, chunk_count = nch - 2).
  *   Steps: pack the states into dense W' x W' maps (W' = gf_dense_width(W), zero pads; identity maps pad
  *   nch to a power of two P) -> Gram sums G_c = sum h h^T / dbar, m_c = sum h zbar / dbar -> exclusive scan
  *   over the chunk maps (Blelloch, 2 log2 P - 2 levels of 3 job launches + 1 solve) -> unpack.
@@ -318,7 +322,7 @@ int64_t gf_wide_combine_work(int B, int nch, int Jc);
 int gf_wide_combine(int B, int64_t N, int64_t chunk_len, int nch, int Jc,
                     const double *h, const double *dbar, const double *zbar,
                     const double *Phi_state, double *S_state, double *work, void *stream);
-int gf_wide_gram(int B, int64_t N, int64_t chunk_len, int nch, int P, int Jc,
+int gf_wide_gram(int B, int64_t N, int64_t chunk_len, int nch, int chunk_first, int chunk_count, int P, int Jc,
                  const double *h, const double *dbar, const double *zbar,
                  double *G_out, double *m_out, void *stream);
 int64_t gf_lft_tree_work(int B, int P, int WP);

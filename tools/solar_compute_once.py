@@ -15,6 +15,9 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 k = gadfly_amd.SolarOscillatorKernel(texp=60.0, bandpass="SOHO VIRGO")
 t = np.linspace(0, 100, N) * 0.0864 * (N / 1e5)
+if os.environ.get("WIDE_TP_COEF"):              # chunk count of the time-parallel factorisation ~ sqrt(coef N)
+    from gadfly_amd.engine import StreamingBatch
+    StreamingBatch.WIDE_TP_COEF = float(os.environ["WIDE_TP_COEF"])
 gp = gadfly_amd.GaussianProcess(k)
 for i in range(reps + 1):
     torch.cuda.synchronize()
