@@ -70,7 +70,13 @@ def parse():
     ap.add_argument("--no-exact-rows", action="store_true",
                     help="skip the extra step with exact generator rows (period 1)")
     ap.add_argument("--cpu-threads", type=int, default=0,
-                    help="host threads of the all-cores CPU baseline (0 = min(cpu_count, 16))")
+                    help="host threads of the all-cores CPU baseline (0 = every core this process may use, "
+                         "at most 64: an evaluation holds 1.5 GB)")
+    ap.add_argument("--strong-rows-scale", type=float, default=1.0,
+                    help="scale the series length of the strong-scaling legs (rehearsals on one GPU; the "
+                         "record uses 1.0 = BASELINE.json's sizes)")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="--gpus N > 1: skip the strong-scaling legs (cfg3 / cfg4 partitioned over the ranks)")
     return ap.parse_args()
 
 
@@ -122,6 +128,43 @@ def oracle_loglikes(jobs, threads):
     return [r[0] for r in res], [r[1] for r in res], wall, [r[2] for r in res]
 
 
+def host_cores():
+    """(cores this process may use, how that was found): the scheduler affinity, capped by the cgroup CPU
+    quota when there is one (a GPU box hands a job a share of the host's cores)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    how = f"sched_getaffinity={n}"
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            q = max(1, int(float(quota) / float(period)))
+            how += f", cgroup cpu.max={q}"
+            n = min(n, q)
+    except (OSError, ValueError):
+        pass
+    return n, how
+
+
+def celerite2_loglike(hp, delta, t, yerr, y):
+    """The reference's own CPU path (celerite2 is what gadfly.GaussianProcess calls,
+    /root/reference/gadfly/gp.py:202, :350) when the package happens to be importable on this host;
+    returns None otherwise (it is not installed in the build image and cannot be fetched)."""
+    try:
+        import celerite2
+        from celerite2 import terms
+    except ImportError:
+        return None
+    sho = [terms.SHOTerm(S0=p["hyperparameters"]["S0"], w0=p["hyperparameters"]["w0"],
+                         Q=p["hyperparameters"]["Q"]) for p in hp]
+    t0 = time.perf_counter()
+    gp = celerite2.GaussianProcess(terms.TermConvolution(terms.TermSum(*sho), delta), mean=0.0)
+    gp.compute(t, yerr=yerr)
+    v = gp.log_likelihood(y)
+    return float(v), time.perf_counter() - t0
+
+
 def check_sample(sample):
     """Oracle check of ONE entry of a configuration measured by tools/configs.py."""
     from oracle import cref
@@ -161,9 +204,13 @@ def other_configs(check):
     """BASELINE.json configs 2 (API legs), 3, 4, 5 on this GPU: measured by tools/configs.py, one
     sampled entry of each checked against the oracle here (a failed check fails the run)."""
     from tools import configs
+    import torch
     out = {}
     for name, fn in (("cfg2_api", configs.measure_cfg2_api), ("cfg3", configs.measure_cfg3),
-                     ("cfg4", configs.measure_cfg4), ("cfg5", configs.measure_cfg5)):
+                     ("cfg3_shard", lambda: configs.measure_cfg3_shard(out["cfg3"]["ms"])),
+                     ("cfg4", configs.measure_cfg4),
+                     ("cfg4_shard", lambda: configs.measure_cfg4_shard(out["cfg4"]["ms"])),
+                     ("cfg5", configs.measure_cfg5)):
         r = fn()
         sample = r.pop("_sample")
         if check:
@@ -171,7 +218,24 @@ def other_configs(check):
             if not r["parity"]["ok"]:
                 raise SystemExit(f"parity gate failed in {name}: {r['parity']}")
         out[name] = r
-        import torch
+        torch.cuda.empty_cache()
+    return out
+
+
+def strong_configs(dist, device, rank, world, backend, check, rows_scale=1.0):
+    """--gpus N > 1: BASELINE.json's sharded configurations (cfg3: 256 light curves, cfg4: 512 walkers) with
+    the WHOLE batch partitioned over the N ranks -- strong scaling, next to the weak-scaling headline."""
+    from tools import configs
+    import torch
+    out = {}
+    for which in ("cfg3", "cfg4"):
+        r = configs.measure_strong(which, dist, device, rank, world, backend, rows_scale)
+        sample = r.pop("_sample")
+        if rank == 0 and check:
+            r["parity"] = check_sample(sample)
+            if not r["parity"]["ok"]:
+                raise SystemExit(f"parity gate failed in strong-scaling {which}: {r['parity']}")
+        out[which + "_strong"] = r
         torch.cuda.empty_cache()
     return out
 
@@ -371,28 +435,33 @@ def main():
                     break
             except (OSError, ValueError, KeyError):
                 pass
+        valu_tf = alg_flops / (fac_avg_ms * 1e-3) / 1e12
         result["roofline"] = {
-            # the contract's HBM-algorithmic fraction: algorithmic bytes / kernel time vs HBM peak
-            "bound": "hbm",
+            # what binds this kernel: the fused sweep moves ~1.6 % of the algorithmic bytes
+            # through HBM; it is FP64-vector-issue- and dependent-chain-bound.  achieved = ALGORITHMIC flops
+            # (5 W^2 per row and evaluation) per launch / the launch's HIP-event time
+            "bound": "fp64_valu",
             "kernel": ("k_factor7 (fused build + factor + forward solve, 2 x 32 lane tiling)" if tiled else
                        "k_factor3 (fused build + factor + forward solve, one column per lane)" if fused
                        else "materialised rows: k_build2 + k_factor2 / k_factor2w / k_factor"),
-            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "achieved": valu_tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+            "frac": valu_tf / FP64_VALU_PEAK_TF,
+            "algorithmic_flops_per_launch": alg_flops,
+            # the contract's HBM-algorithmic figure: algorithmic bytes 8 (3 W + 4) per row and evaluation
+            # per launch / the same time, against the HBM peak
+            "hbm_algorithmic": {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                "algorithmic_bytes_per_launch": alg_bytes},
+            "traffic": traffic, "traffic_source": traffic_src,
+            "hbm_measured_GBs": (traffic / (fac_avg_ms * 1e-3) / 1e9) if traffic else None,
             "kernel_ms": fac_avg_ms, "launches_timed": len(fac_ms),
             "rows_per_launch": fac_avg_rows,
-            "algorithmic_bytes_per_launch": alg_bytes,
-            # what actually binds this kernel: the fused sweep moves ~1.6 % of the
-            # algorithmic bytes through HBM; it is FP64-vector-issue- and dependent-chain-bound
-            "binding_resource": "fp64_valu",
-            "fp64_valu_frac": alg_flops / (fac_avg_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
-            "hbm_measured_GBs": (traffic / (fac_avg_ms * 1e-3) / 1e9) if traffic else None,
         }
         if exact is not None:
             result["exact_rows"] = exact
         oracle_ok = not args.no_cpu_baseline and world == 1
         if oracle_ok:
-            threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
+            usable, how = host_cores()
+            threads = args.cpu_threads or min(usable, 64)
             diag = np.full(N, yerr ** 2)
             # ---- cpu_baseline: ONE evaluation on ONE core (celerite2 is single-threaded) ----------
             k0 = walker_kernel(args.warmup, 0)              # first timed evaluation
@@ -402,8 +471,19 @@ def main():
                 "sample": f"1 evaluation of the first timed walker on all {N} rows ({wall1:.2f} s; "
                           "oracle/celerite_ref.c, gcc -O3 -march=x86-64-v3 restatement of the "
                           "celerite2 algorithm, single thread like celerite2)",
-                "host_cpu_count": os.cpu_count(),
+                "host_cpu_count": os.cpu_count(), "usable_cores": usable, "usable_cores_from": how,
             }
+            # the reference's own CPU path, should celerite2 be importable on this host
+            c2 = celerite2_loglike(jitter_hyperparameters(base, 1000 + walker_ids(args.warmup)[0]),
+                                   k0.delta, t, yerr, y)
+            if c2 is not None:
+                v2, wall2 = c2
+                result["cpu_baseline"].update(
+                    value=1.0 / wall2, kind="celerite2",
+                    sample=f"1 evaluation of the first timed walker through celerite2.GaussianProcess "
+                           f"(compute + log_likelihood, {wall2:.2f} s, one core)",
+                    port={"value": 1.0 / wall1, "unit": "evals/s", "cores": 1},
+                    celerite2_vs_gpu_rel_err=abs(float(lls[args.warmup, 0]) - v2) / abs(v2))
             # ---- parity gate: >= 8 timed evaluations spread over the steps, including the one with
             # the largest device condition estimate max(a)/min(d); run on all host cores, which is
             # also the all-cores CPU baseline (one problem per thread) ------------------------------
@@ -429,8 +509,10 @@ def main():
             }
             result["cpu_baseline"]["all_cores"] = {
                 "value": len(jobs) / wall, "unit": "evals/s", "cores": min(threads, len(jobs)),
-                "sample": f"{len(jobs)} evaluations, one per thread ({wall:.2f} s wall, "
-                          f"{np.mean(each):.2f} s each)",
+                "kind": "port",
+                "sample": f"{len(jobs)} evaluations, one per thread on every core this process may use "
+                          f"({how}; at most 64: an evaluation holds 1.5 GB) -- {wall:.2f} s wall, "
+                          f"{np.mean(each):.2f} s each",
             }
             if any(infos) or info1[0] or max(rels) > 1e-8 or \
                     result["parity"]["loglike_rel_err_first_timed"] > 1e-8:
@@ -439,6 +521,27 @@ def main():
             del ev, eng, outs, mind
             torch.cuda.empty_cache()
             result["configs"] = other_configs(check=oracle_ok)
+            api = result["configs"]["cfg2_api"]
+            # ONE MCMC chain (one proposal at a time) through the drop-in class: fresh hyperparameters,
+            # factorisation, log-likelihood -- the latency path next to the batched headline
+            result["single_chain"] = {
+                "value": 1e3 / api["recompute_plus_log_likelihood_ms"], "unit": "evals/s",
+                "ms_per_eval": api["recompute_plus_log_likelihood_ms"],
+                "what": "GaussianProcess.recompute() + log_likelihood(y) at N=1e6, J=30: one evaluation at a "
+                        "time (exact time-parallel factorisation), host arrays in and out",
+            }
+    # ---- strong scaling of the sharded configurations (every rank takes part: collectives) ----------
+    if dist is not None and world > 1 and not args.no_strong and not args.no_configs:
+        try:
+            del ev, eng, outs, mind
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        strong = strong_configs(dist, device, rank, world, backend, check=not args.no_cpu_baseline,
+                                rows_scale=args.strong_rows_scale)
+        if rank == 0:
+            result["configs"] = strong
+    if rank == 0:
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()

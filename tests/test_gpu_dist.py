@@ -81,3 +81,24 @@ def test_bench_self_launch_two_ranks(hip):
     assert len(lines) == 1, out.stdout[-2000:]
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
+
+
+def test_bench_strong_scaling_legs_two_ranks(hip):
+    """`bench.py --gpus 2`: after the weak-scaling headline every rank takes its block of cfg3's 256 light
+    curves and of cfg4's 512 walkers (static partition), evaluates it, and the results are all_gathered --
+    the strong-scaling legs the driver's multi-GPU run records.  Two ranks share the box's one GPU here
+    (gloo, short series); entry 0 of each batch is checked against the oracle by rank 0."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(GADFLY_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--rows", "16384", "--evals", "64", "--strong-rows-scale", "0.05"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak"
+    for name, B in (("cfg3_strong", 256), ("cfg4_strong", 512)):
+        leg = res["configs"][name]
+        assert leg["scaling"] == "strong" and leg["n_gpus"] == 2 and leg["all_finite"]
+        assert leg["value"] > 0 and abs(leg["value"] * leg["ms"] * 1e-3 - B) < 1e-6 * B
+        assert leg["parity"]["ok"] and leg["parity"]["rel_err"] <= 1e-8

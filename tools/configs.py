@@ -131,6 +131,63 @@ def measure_cfg4_shard(full_ms=None):
     return r
 
 
+def measure_strong(which, dist, device, rank, world, backend, rows_scale=1.0):
+    """cfg3 / cfg4 STRONG scaling: the whole batch (256 light curves / 512 walkers) partitioned over the ranks
+    (static block partition, gadfly_amd.dist.shard_bounds), every rank evaluates its block on its own GPU
+    and the B scalars are collected with one all_gather (RCCL over xGMI) -- the collective is inside the
+    timed region.  Every rank calls this; returns the dict on every rank (timings MAX-reduced)."""
+    import torch
+    import gadfly_amd
+    from gadfly_amd.dist import shard_bounds, gather_results
+    from gadfly_amd.synth import cfg3_light_curves, cfg4_walkers
+    if which == "cfg3":
+        B, N, J = 256, max(1024, int(65_000 * rows_scale)), 20       # (rows_scale < 1: rehearsals only)
+        hps, t, y, yerr, texp = cfg3_light_curves(B, N, J, jitter=False)
+    else:
+        B, N, J = 512, max(1024, int(200_000 * rows_scale)), 40
+        hps, t, y, texp = cfg4_walkers(B, N, J)
+        yerr = 30.0
+    lo, hi = shard_bounds(B, world, rank)
+    kernels = [gadfly_amd.StellarOscillatorKernel(hp, texp=texp) for hp in hps[lo:hi]]
+    if which == "cfg3":
+        ev = gadfly_amd.BatchedLogLikelihood(kernels, t[lo:hi], y[lo:hi], yerr=yerr[lo:hi], device=device)
+    else:
+        ev = gadfly_amd.BatchedLogLikelihood(kernels, t, y, yerr=yerr, device=device)
+    ev.evaluate()                                   # warm-up + generator calibration
+
+    def once():
+        out = _guarded(ev)
+        return gather_results(out.cpu().numpy(), B, device=device if backend == "nccl" else "cpu")
+
+    once()
+    times, full = [], None
+    for _ in range(3):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        full = once()
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                          device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        times.append(float(dt.item()))
+    dt = float(np.median(times))
+    W = 2 * J
+    gb = 8.0 * N * (3 * W + 4) * B / 1e9
+    i = 0
+    return {"workload": f"{which}: {B} x N={N}, J={J} (W={W}) partitioned over {world} GPUs ({hi - lo} on rank {rank}), "
+                        "results all_gathered",
+            "scaling": "strong", "n_gpus": world, "value": B / dt, "unit": "evals/s", "ms": 1e3 * dt,
+            "algorithmic_GBs": gb / dt, "frac_of_aggregate_hbm": gb / dt / (HBM_PEAK_GBS * world),
+            "path": _path(ev.engine), "all_finite": bool(np.all(np.isfinite(full))),
+            "_sample": dict(kind="loglike", index=i, coeffs=gadfly_amd.StellarOscillatorKernel(
+                                hps[i], texp=texp).get_device_coefficients(),
+                            t=t[i] if which == "cfg3" else t, diag=(yerr[i] ** 2 if which == "cfg3"
+                                                                    else np.full(N, 900.0)),
+                            y=y[i] if which == "cfg3" else y, got=float(full[i]))}
+
+
 def measure_cfg5():
     import torch
     import gadfly_amd
