@@ -50,7 +50,7 @@ SIGNATURES = {
     "gf_fused_state_size": (_i64, [_int, _int]),
     "gf_loglike_fused": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int] + [_vp] * 8
                          + [_vp, _i64, _vp, _i64, _vp, _i64] + [_vp] * 5 + [_vp]),
-    "gf_chunk_sweep": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int, _int] + [_vp] * 8
+    "gf_chunk_sweep": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int] + [_vp] * 8
                        + [_vp, _i64, _vp, _i64, _vp, _i64] + [_vp] * 9 + [_vp]),
     "gf_fused_row_stride": (_int, [_int, _int]),
     "gf_scaled_propagator": (_int, [_int, _i64, _int, _int, _vp, _vp, _vp, _vp]),
@@ -69,8 +69,7 @@ SIGNATURES = {
                         _vp, _int, _i64, _vp, _int, _i64, _vp]),
     "gf_chunk_segment_transitions": (_int, [_int, _int, _int] + [_vp] * 2 + [_vp]),
     "gf_chunk_linear_combine_seg": (_int, [_int, _int, _int, _int, _int] + [_vp] * 4 + [_vp]),
-    "gf_chunk_transition": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int, _int] + [_vp] * 7
-                            + [_vp, _i64] + [_vp] * 7 + [_vp]),
+    "gf_chunk_transition": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int, _int] + [_vp] * 9 + [_vp]),
     "gf_chunk_transition_wide": (_int, [_int, _i64, _i64, _int, _int, _int, _int] + [_vp] * 7 + [_vp]),
     "gf_chunk_combine": (_int, [_int, _int] + [_vp] * 5 + [_vp]),
     "gf_chunk_combine_tree": (_int, [_int, _int] + [_vp] * 7 + [_vp]),

@@ -964,7 +964,7 @@ struct RowGen {
 template <int ROWS>
 __global__ void __launch_bounds__(64, 2)
 k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int nch,
-          const int Jr, const int Jc, const int block_sub, const double gap,
+          const int ch0, const int nsel, const int Jr, const int Jc, const int block_sub, const double gap,
           const double *__restrict__ ar_, const double *__restrict__ cr_,
           const double *__restrict__ ac_, const double *__restrict__ bc_,
           const double *__restrict__ cc_, const double *__restrict__ dc_,
@@ -977,9 +977,10 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
           double *__restrict__ S_state, double *__restrict__ F_state,
           int32_t *__restrict__ info) {
     const int lane = threadIdx.x;
-    const int b = blockIdx.x;                       // state slot = problem * nch + chunk
+    const int sel = blockIdx.x;                     // chunks ch0 .. ch0 + nsel - 1 of every problem
+    const int pr = sel / nsel, ch = ch0 + (sel - pr * nsel);
+    const int b = pr * nch + ch;                    // state slot = problem * nch + chunk
     if (info[b] != 0) return;
-    const int pr = b / nch, ch = b - pr * nch;
     const int64_t c0 = (int64_t)ch * chunk_len;     // first row of the chunk within this call
     const int64_t rows = (N - c0 < chunk_len) ? (N - c0) : chunk_len;
     const int64_t g0 = n_first + c0;                // global index of the chunk's first row
@@ -1080,7 +1081,8 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
         q = fma(zn, is63, r) * inv;                 // lane 63: z / d (r is 0 there)
         const size_t ro = opaque_uniform((size_t)n * 64);
         if (rg) rg[ro] = r;                         // r~ rows for k_phi (chunk mode)
-        if (ug) { ug[ro] = ut_c; wg[ro] = fl ? 0.0 : q; }
+        if (ug) ug[ro] = ut_c;
+        if (wg) wg[ro] = fl ? 0.0 : q;
         if (lane == 0) { dg[n] = dn; zg[n] = zn; }
     }
     if (fail) {
@@ -1130,6 +1132,19 @@ __device__ __forceinline__ void both_halves(const double x, double &lo, double &
     lo = __hiloint2double(h[0], l[0]);
     up = __hiloint2double(h[1], l[1]);
 }
+
+// One LDS-DMA instruction (global_load_lds_dwordx4): lane l copies 16 bytes from ITS OWN global address to
+// LDS byte `lds_byte` + 16 l -- no VGPR destination, so a deep prefetch costs LDS instead of registers.
+// hipcc does not count it: completion is waited for with vm_wait (vector-memory operations retire in
+// issue order).  `after` is a value that must exist before the copy may issue (keeps the copy behind
+// the reads of the ring slot it overwrites).
+__device__ __forceinline__ void glds16(const void *gsrc, const unsigned lds_byte, const int after) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte), "v"(after) : "memory");
+}
+template <int CNT>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(CNT) : "memory"); }
 
 constexpr int S7_AHEAD = 1;         // batches (one row pair = 8 FMAs + 2 reads) of LDS look-ahead
 
@@ -1184,7 +1199,7 @@ __device__ __forceinline__ void sweep7_run(double (&T)[ROWS / 2][2], double2 (&u
 template <int ROWS>
 __global__ void __launch_bounds__(64, 2)
 k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int nch,
-          const int Jr, const int Jc, const int block_sub, const double gap,
+          const int ch0, const int nsel, const int Jr, const int Jc, const int block_sub, const double gap,
           const double *__restrict__ ar_, const double *__restrict__ cr_,
           const double *__restrict__ ac_, const double *__restrict__ bc_,
           const double *__restrict__ cc_, const double *__restrict__ dc_,
@@ -1198,9 +1213,10 @@ k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
           int32_t *__restrict__ info) {
     const int lane = threadIdx.x;
     const int g = lane >> 5, c = lane & 31;         // row group, column block (columns 2c, 2c + 1)
-    const int b = blockIdx.x;                       // state slot = problem * nch + chunk
+    const int sel = blockIdx.x;                     // chunks ch0 .. ch0 + nsel - 1 of every problem
+    const int pr = sel / nsel, ch = ch0 + (sel - pr * nsel);
+    const int b = pr * nch + ch;                    // state slot = problem * nch + chunk
     if (info[b] != 0) return;
-    const int pr = b / nch, ch = b - pr * nch;
     const int64_t c0 = (int64_t)ch * chunk_len;
     const int64_t rows = (N - c0 < chunk_len) ? (N - c0) : chunk_len;
     const int64_t g0 = n_first + c0;
@@ -1307,7 +1323,8 @@ k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
         q1 = fma(zn, is31, r1) * inv;               // column 63: z / d (r is 0 there)
         const size_t ro = opaque_uniform((size_t)n * 64);
         if (rg) rg[ro] = r;                         // r~ rows for k_phi (chunk mode)
-        if (ug) { ug[ro] = ut_c; wg[ro] = r * inv; }
+        if (ug) ug[ro] = ut_c;
+        if (wg) wg[ro] = r * inv;
         if (lane == 0) { dg[n] = dn; zg[n] = zn; }
     }
     if (fail) {
@@ -1323,40 +1340,143 @@ k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     }
 }
 
-// k_phi in k_factor7's lane tiling (same arguments and results as k_phi; Jr = 0, Jc <= 31): the
-// closed-loop transition sweep reads half the LDS operands per FMA as well.
+#define GF_MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------
+// Closed-loop transition sweeps of the time-parallel evaluation, W <= 63 (k_phi7: k_factor7's lane tiling,
+// complex terms only; k_phi: one column per lane, any terms), DESIGN.md 4.3:
+//     Phi <- (I - w~ u~^T) Phi  (E Phi at reset rows),  h_n = Phi^T u~_n,
+//     G = sum_n h_n h_n^T / dbar_n,   m = sum_n h_n zbar_n / dbar_n
+// on the rows the nominal pass stored (u~, r-bar, dbar, zbar, reset spans): no row generator here, and the
+// Gram sums are accumulated in the same kernel -- the rows h never leave the chip.
+//   * rows arrive through an LDS ring filled by LDS-DMA five rows ahead of their use (PhiRing); a register
+//     queue two rows deep left every row waiting on HBM once the row arrays outgrew the caches (cfg3: 8.5 GB);
+//   * sixteen rows of h are collected in an LDS tile and folded into the G accumulators as a rank-16
+//     update on v_mfma_f64_16x16x4 (PhiGram: NT (NT + 1) / 2 symmetric tiles of 16 x 16, NT = ceil(W / 16)).
+// ------------------------------------------------------------------------------------
+struct PhiRing {
+    static constexpr int PD = 8;                    // slots; rows are fetched PD - 1 ahead, used PD - 3 later
+    static constexpr int USL = 72, RSL = 64;        // doubles per slot: u~ row + 3 scalar pairs / r-bar row
+    static constexpr int OD = 64, OE = 66, OZ = 68; // dbar / reset span / zbar pair of the row in its u~ slot
+    double u[PD][USL];
+    double r[PD + 1][RSL];                          // slot PD: zeros ("no pending update" of the first row)
+};
+
+// per-lane copy cursors: lanes 0 .. 31 the row's doubles 2 lane, 2 lane + 1; lanes 32 / 33 / 34 of the u~
+// copy the aligned pairs that hold dbar[row] / de[row] / zbar[row]; the other lanes stay out (EXEC)
+struct PhiCursor {
+    uintptr_t cu, cr, mask;
+    unsigned long long ustep;
+    bool in_u, in_r;
+    unsigned lds_u, lds_r;
+    __device__ __forceinline__ void init(PhiRing &R, const int lane, const size_t pb, const double *ut_,
+                                         const double *rbar_, const double *dbar_, const double *de_,
+                                         const double *zbar_) {
+        cu = reinterpret_cast<uintptr_t>(ut_ + pb * 64 + 2 * (lane & 31));
+        cr = reinterpret_cast<uintptr_t>(rbar_ + pb * 64 + 2 * (lane & 31));
+        mask = ~(uintptr_t)0;
+        ustep = 64 * 8;
+        if (lane >= 32) {
+            const double *sp = (lane == 32) ? dbar_ : (lane == 33) ? de_ : zbar_;
+            cu = reinterpret_cast<uintptr_t>(sp + pb);
+            mask = ~(uintptr_t)15;
+            ustep = 8;
+        }
+        in_u = lane < 35;
+        in_r = lane < 32;
+        lds_u = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(&R.u[0][0]));
+        lds_r = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(&R.r[0][0]));
+    }
+    // row m (the cursors stand at it) -> slot m mod PD; two vector-memory operations
+    __device__ __forceinline__ void issue(const int64_t m, const int after) {
+        const unsigned sl = (unsigned)(m & (PhiRing::PD - 1));
+        if (in_u) glds16(reinterpret_cast<const void *>(cu & mask), lds_u + sl * (PhiRing::USL * 8), after);
+        if (in_r) glds16(reinterpret_cast<const void *>(cr), lds_r + sl * (PhiRing::RSL * 8), after);
+        cu += ustep;
+        cr += 64 * 8;
+    }
+};
+
+template <int NT>
+struct PhiGram {
+    static constexpr int LD = 80;                   // tile row stride: rows k, k + 1 land 32 banks apart
+    static constexpr int NACC = NT * (NT + 1) / 2;
+    double hs[16][LD];                              // h of sixteen rows
+    double sv[16];                                  // 1 / dbar of those rows (0: row not there)
+};
+
+// fold the tile into the accumulators: acc(it, jt) += sum_k (h_k[16 it + i] / d_k) h_k[16 jt + j]
+template <int NT>
+__device__ __forceinline__ void phi_gram_flush(PhiGram<NT> &Gm, d4 (&acc)[PhiGram<NT>::NACC], const int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    wave_lds_fence();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int k = 4 * ks + lk;
+        const double sc = Gm.sv[k];
+        double hv[NT];
+#pragma unroll
+        for (int it = 0; it < NT; ++it) hv[it] = Gm.hs[k][16 * it + li];
+        int t = 0;
+#pragma unroll
+        for (int it = 0; it < NT; ++it)
+#pragma unroll
+            for (int jt = it; jt < NT; ++jt, ++t) acc[t] = GF_MFMA64(hv[it] * sc, hv[jt], acc[t]);
+    }
+    wave_lds_fence();
+    if (lane < 16) Gm.sv[lane] = 0.0;               // (a partial last block folds zeros for the missing rows)
+}
+
+// G ([column][row], 64 x 64, zero outside the tiles) and m of one chunk
+template <int NT>
+__device__ __forceinline__ void phi_gram_store(const d4 (&acc)[PhiGram<NT>::NACC], const double macc,
+                                               double *__restrict__ Gg, double *__restrict__ mg, const int lane,
+                                               const int own) {
+    const int li = lane & 15, lk = lane >> 4;
+    for (int e = lane; e < 4096; e += 64) {
+        const int col = e >> 6, row = e & 63;
+        if (col >= 16 * NT || row >= 16 * NT) Gg[e] = 0.0;
+    }
+    int t = 0;
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int jt = it; jt < NT; ++jt, ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * it + lk + 4 * r, col = 16 * jt + li;
+                const double v = acc[t][r];
+                if (jt > it || col >= row) {        // upper triangle, mirrored: exactly symmetric
+                    Gg[(size_t)col * 64 + row] = v;
+                    Gg[(size_t)row * 64 + col] = v;
+                }
+            }
+    mg[own] = macc;
+}
+
 template <int ROWS>
 __global__ void __launch_bounds__(64, 2)
-k_phi7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int nch,
-      const int Jr, const int Jc, const int block_sub, const double gap,
-      const double *__restrict__ ar_, const double *__restrict__ cr_,
-      const double *__restrict__ ac_, const double *__restrict__ bc_,
-      const double *__restrict__ cc_, const double *__restrict__ dc_,
-      const double *__restrict__ cmax_,
-      const double *__restrict__ t_, const int64_t t_bs,
-      const double *__restrict__ dbar_, const double *__restrict__ rbar_,
-      double *__restrict__ h_out, double *__restrict__ Phi_out) {
+k_phi7(const int64_t N, const int64_t chunk_len, const int nch, const int ch0, const int nsel, const int W,
+       const double *__restrict__ c_, const double *__restrict__ de_, const double *__restrict__ dbar_,
+       const double *__restrict__ zbar_, const double *__restrict__ rbar_, const double *__restrict__ ut_,
+       double *__restrict__ Phi_out, double *__restrict__ G_out, double *__restrict__ m_out) {
+    constexpr int NT = (ROWS + 15) / 16, PD = PhiRing::PD;
     const int lane = threadIdx.x;
     const int g = lane >> 5, c = lane & 31, own = 2 * c + g;    // k_factor7's tiling: state columns 2c, 2c + 1
-    const int b = blockIdx.x;                                   // of half the rows; row vectors: column `own`
-    const int pr = b / nch, ch = b - pr * nch;
+    const int sel = blockIdx.x;                                 // of half the rows; row vectors: column `own`
+    const int pr = sel / nsel, ch = ch0 + (sel - pr * nsel);    // chunks ch0 .. ch0 + nsel - 1 of every problem
+    const int b = pr * nch + ch;                                // state slot
     const int64_t c0 = (int64_t)ch * chunk_len;
     const int64_t rows = (N - c0 < chunk_len) ? (N - c0) : chunk_len;
-    const int64_t g0 = n_first + c0;
     const size_t pb = (size_t)pr * N + c0;
-    const double *__restrict__ tg = t_ + (size_t)pr * t_bs + g0;
-    const double *__restrict__ dg = dbar_ + pb;
-    const double *__restrict__ rg = rbar_ + pb * 64 + own;
-    double *__restrict__ hg = h_out + pb * 64 + own;
     double *__restrict__ col0 = Phi_out + (size_t)b * (64 * 64) + (size_t)(2 * c) * 64 + 2 * g;
     double *__restrict__ col1 = col0 + 64;
+    const double cj = (own < W) ? c_[(size_t)pr * W + own] : 0.0;
 
-    RowGen G;
-    G.init(own, pr, Jr, Jc, block_sub, gap, ar_, cr_, ac_, bc_, cc_, dc_, cmax_, tg, g0);
-    const double cj = G.cj;
-
-    __shared__ __attribute__((aligned(16))) double s_w[64], s_u[64], s_e[64];
-    const double2 *pw = (const double2 *)s_w + g, *pu = (const double2 *)s_u + g;
+    __shared__ __attribute__((aligned(16))) PhiRing R;
+    __shared__ __attribute__((aligned(16))) PhiGram<NT> Gm;
+    __shared__ __attribute__((aligned(16))) double s_e[64];
     const double2 *pe = (const double2 *)s_e + g;
     double T[ROWS / 2][2];
 #pragma unroll
@@ -1365,26 +1485,34 @@ k_phi7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const in
         T[m][0] = (row == 2 * c) ? 1.0 : 0.0;
         T[m][1] = (row == 2 * c + 1) ? 1.0 : 0.0;
     }
-    double q0 = 0.0, q1 = 0.0;
-
-    double t_n1 = tg[1], t_n2 = tg[2];
-    double d_n = dg[0], d_n1 = dg[1];               // dbar, rbar are padded by the caller
-    double r_n = rg[0], r_n1 = rg[64];
-    double ut, vt, de;
-    bool rst;
-    G.next(tg[0], g0, ut, vt, rst, de);
-
-    double2 ub[S7_AHEAD + 1], wb[S7_AHEAD + 1];
-    s_w[own] = 0.0;
-    s_u[own] = ut;
+    double q0 = 0.0, q1 = 0.0, macc = 0.0;
+    d4 acc[PhiGram<NT>::NACC];
+#pragma unroll
+    for (int t = 0; t < PhiGram<NT>::NACC; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+    R.r[PD][lane] = 0.0;
+    for (int e = lane; e < 16 * PhiGram<NT>::LD; e += 64) (&Gm.hs[0][0])[e] = 0.0;
+    if (lane < 16) Gm.sv[lane] = 0.0;
+    PhiCursor C;
+    C.init(R, lane, pb, ut_, rbar_, dbar_, de_, zbar_);
+#pragma unroll
+    for (int m = 0; m < PD - 1; ++m) C.issue(m, 0);
+    vm_wait<2 * (PD - 2)>();                        // row 0 has landed
     wave_lds_fence();
+    double2 ub[S7_AHEAD + 1], wb[S7_AHEAD + 1];
+    const double2 *pu = (const double2 *)&R.u[0][0] + g;
+    const double2 *pw = (const double2 *)&R.r[PD][0] + g;
     sweep7_preload<ROWS>(ub, wb, pu, pw);
 
     for (int64_t n = 0; n < rows; ++n) {
-        const double dcur = d_n, rcur = r_n;
-        if (rst) {                          // Phi <- E (Phi + pending): row scaling only
-            const double el = fm_exp(-cj * de);
-            s_e[own] = el;
+        // rows up to n + 1 have landed: behind row n + 1's copies are those of the PD - 3 rows after it
+        vm_wait<2 * (PD - 3)>();
+        const int sl = (int)(n & (PD - 1)), par = (int)((pb + n) & 1);
+        const double dcur = R.u[sl][PhiRing::OD + par], zcur = R.u[sl][PhiRing::OZ + par];
+        const double dev = R.u[sl][PhiRing::OE + par];
+        const double de = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(dev)),
+                                           __builtin_amdgcn_readfirstlane(__double2loint(dev)));
+        if (de >= 0.0) {                    // reset row: Phi <- E (Phi + pending): row scaling only
+            s_e[own] = fm_exp(-cj * de);
             wave_lds_fence();
             double d0, d1;
             sweep7_preload<ROWS>(ub, wb, pe, pw);
@@ -1396,21 +1524,23 @@ k_phi7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const in
         double acc0, acc1;
         sweep7_run<ROWS, false>(T, ub, wb, pu, pw, q0, q1, 0.0, 0.0, acc0, acc1);
         const double h = own_column_sum(acc0, acc1);
-        hg[(size_t)n * 64] = h;
-        G.next(t_n1, g0 + n + 1, ut, vt, rst, de);
-        t_n1 = t_n2;
-        t_n2 = tg[n + 3];
-        d_n = d_n1; r_n = r_n1;
-        d_n1 = dg[n + 2];
-        r_n1 = rg[(size_t)(n + 2) * 64];
-        wave_lds_fence();
-        s_w[own] = rcur;                    // pending: Phi_i -= (r_i / d) h_j
-        s_u[own] = ut;
-        wave_lds_fence();
+        const double rinv = (dcur > 0.0) ? fast_rcp(dcur) : 0.0;
+        Gm.hs[n & 15][own] = h;
+        if (lane == 0) Gm.sv[n & 15] = rinv;
+        macc = fma(h, zcur * rinv, macc);
+        // next row's operands: u~ of row n + 1 (landed), the pending r-bar of row n in its ring slot
+        pu = (const double2 *)&R.u[(int)((n + 1) & (PD - 1))][0] + g;
+        pw = (const double2 *)&R.r[sl][0] + g;
         sweep7_preload<ROWS>(ub, wb, pu, pw);
-        both_halves(-h / dcur, q0, q1);
+        both_halves(-h * rinv, q0, q1);     // pending: Phi_i -= (r_i / d) h_j
+        // row n + PD - 1 into the slot of row n - 1, whose rows this iteration's sweeps were the last to read
+        C.issue(n + PD - 1, __double2loint(h));
+        if ((n & 15) == 15) phi_gram_flush<NT>(Gm, acc, lane);
     }
+    vm_wait<0>();                           // no copy may outlive the wave's LDS allocation
+    if (rows & 15) phi_gram_flush<NT>(Gm, acc, lane);
     wave_lds_fence();
+    const double *s_w = &R.r[(int)((rows - 1) & (PD - 1))][0];
 #pragma unroll
     for (int m = 0; m < ROWS / 2; ++m) {
         const int ro = 4 * (m >> 1) + (m & 1);
@@ -1423,6 +1553,7 @@ k_phi7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const in
         col0[4 * k2] = 0.0; col0[4 * k2 + 1] = 0.0;
         col1[4 * k2] = 0.0; col1[4 * k2 + 1] = 0.0;
     }
+    phi_gram_store<NT>(acc, macc, G_out + (size_t)b * (64 * 64), m_out + (size_t)b * 64, lane, own);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1452,7 +1583,7 @@ k_phi7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const in
 // ------------------------------------------------------------------------------------
 struct FactorWArgs {            // the scalars; the arrays are separate __restrict__ kernel parameters
     int64_t N, n_first, chunk_len, t_bs, diag_bs, y_bs;
-    int nch, Jc, block_sub;
+    int nch, ch0, nsel, Jc, block_sub;
     double gap;
 };
 
@@ -1590,9 +1721,10 @@ k_factorw(const FactorWArgs A,
     constexpr bool PRE = TR <= 20;                  // the w operands of a whole row fit in registers (W <= 80)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int b = blockIdx.x;                       // state slot = problem * nch + chunk
+    const int sel = blockIdx.x;                     // chunks ch0 .. ch0 + nsel - 1 of every problem
+    const int pr = sel / A.nsel, ch = A.ch0 + (sel - pr * A.nsel);
+    const int b = pr * A.nch + ch;                  // state slot = problem * nch + chunk
     if (info[b] != 0) return;                       // (uniform over the workgroup)
-    const int pr = b / A.nch, ch = b - pr * A.nch;
     const int64_t c0 = (int64_t)ch * A.chunk_len;
     const int64_t rows = (A.N - c0 < A.chunk_len) ? (A.N - c0) : A.chunk_len;
     const int64_t g0 = A.n_first + c0;
@@ -1847,19 +1979,6 @@ __device__ __forceinline__ double own_column_sum8(const double a, const double b
     return s;
 }
 
-// One LDS-DMA instruction (global_load_lds_dwordx4): lane l copies 16 bytes from ITS OWN global address to
-// LDS byte `lds_byte` + 16 l -- no VGPR destination, so a deep prefetch costs LDS instead of registers.
-// hipcc does not count it: completion is waited for with vm_wait (vector-memory operations retire in
-// issue order).  `after` is a value that must exist before the copy may issue (keeps the copy behind
-// the reads of the ring slot it overwrites).
-__device__ __forceinline__ void glds16(const void *gsrc, const unsigned lds_byte, const int after) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte), "v"(after) : "memory");
-}
-template <int CNT>
-__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(CNT) : "memory"); }
-
 // D ring slots (a power of two) of NI kilobytes per row vector; rows arrive D - 2 rows ahead of their use
 // (the u~ row, the pivot and the reset span of a row travel in ONE slot: lanes 63 / 62 of the last piece
 // fetch the 16-byte pairs that hold dbar[row] / de[row]).  The register queue this replaces was two rows
@@ -1989,8 +2108,6 @@ k_phiw(const int64_t N, const int64_t chunk_len, const int nch, const int ch0, c
 }
 
 // helpers shared with the archived variants
-#define GF_MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
-typedef double d4 __attribute__((ext_vector_type(4)));
 template <class F, int... K>
 __device__ __forceinline__ void static_for(F &&f, std::integer_sequence<int, K...>) {
     (f(std::integral_constant<int, K>{}), ...);
@@ -2015,155 +2132,81 @@ __device__ __forceinline__ void static_for(F &&f, std::integer_sequence<int, K..
 // ------------------------------------------------------------------------------------
 template <int ROWS>
 __global__ void __launch_bounds__(64, 2)
-k_phi(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int nch,
-      const int Jr, const int Jc, const int block_sub, const double gap,
-      const double *__restrict__ ar_, const double *__restrict__ cr_,
-      const double *__restrict__ ac_, const double *__restrict__ bc_,
-      const double *__restrict__ cc_, const double *__restrict__ dc_,
-      const double *__restrict__ cmax_,
-      const double *__restrict__ t_, const int64_t t_bs,
-      const double *__restrict__ dbar_, const double *__restrict__ rbar_,
-      double *__restrict__ h_out, double *__restrict__ Phi_out) {
+k_phi(const int64_t N, const int64_t chunk_len, const int nch, const int ch0, const int nsel, const int W,
+      const double *__restrict__ c_, const double *__restrict__ de_, const double *__restrict__ dbar_,
+      const double *__restrict__ zbar_, const double *__restrict__ rbar_, const double *__restrict__ ut_,
+      double *__restrict__ Phi_out, double *__restrict__ G_out, double *__restrict__ m_out) {
+    constexpr int NT = (ROWS + 15) / 16, PD = PhiRing::PD;
     const int lane = threadIdx.x;
-    const int b = blockIdx.x;
-    const int pr = b / nch, ch = b - pr * nch;
+    const int sel = blockIdx.x;
+    const int pr = sel / nsel, ch = ch0 + (sel - pr * nsel);
+    const int b = pr * nch + ch;
     const int64_t c0 = (int64_t)ch * chunk_len;
     const int64_t rows = (N - c0 < chunk_len) ? (N - c0) : chunk_len;
-    const int64_t g0 = n_first + c0;
     const size_t pb = (size_t)pr * N + c0;
-    const double *__restrict__ tg = t_ + (size_t)pr * t_bs + g0;
-    const double *__restrict__ dg = dbar_ + pb;
-    const double *__restrict__ rg = rbar_ + pb * 64 + lane;
-    double *__restrict__ hg = h_out + pb * 64 + lane;
     double *__restrict__ Pg = Phi_out + (size_t)b * (64 * 64) + (size_t)lane * 64;
+    const double cj = (lane < W) ? c_[(size_t)pr * W + lane] : 0.0;
 
-    RowGen G;
-    G.init(lane, pr, Jr, Jc, block_sub, gap, ar_, cr_, ac_, bc_, cc_, dc_, cmax_, tg, g0);
-    const double cj = G.cj;
-
-    __shared__ double s_w[64], s_u[64], s_e[64];
+    __shared__ __attribute__((aligned(16))) PhiRing R;
+    __shared__ __attribute__((aligned(16))) PhiGram<NT> Gm;
+    __shared__ __attribute__((aligned(16))) double s_e[64];
     double T[ROWS];
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) T[i] = (i == lane) ? 1.0 : 0.0;      // Phi = I
-    double q = 0.0;
-
-    double t_n1 = tg[1], t_n2 = tg[2];
-    double d_n = dg[0], d_n1 = dg[1];               // dbar, rbar are padded by the caller
-    double r_n = rg[0], r_n1 = rg[64];
-    double ut, vt, de;
-    bool rst;
-    G.next(tg[0], g0, ut, vt, rst, de);
-
-    double ab[SW_AHEAD + 1][SW_BR], wb[SW_AHEAD + 1][SW_BR];
-    s_w[lane] = 0.0;
-    s_u[lane] = ut;
+    double q = 0.0, macc = 0.0;
+    d4 acc[PhiGram<NT>::NACC];
+#pragma unroll
+    for (int t = 0; t < PhiGram<NT>::NACC; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+    R.r[PD][lane] = 0.0;
+    for (int e = lane; e < 16 * PhiGram<NT>::LD; e += 64) (&Gm.hs[0][0])[e] = 0.0;
+    if (lane < 16) Gm.sv[lane] = 0.0;
+    PhiCursor C;
+    C.init(R, lane, pb, ut_, rbar_, dbar_, de_, zbar_);
+#pragma unroll
+    for (int m = 0; m < PD - 1; ++m) C.issue(m, 0);
+    vm_wait<2 * (PD - 2)>();
     wave_lds_fence();
-    sweep_preload<ROWS>(ab, wb, s_u, s_w);
+    double ab[SW_AHEAD + 1][SW_BR], wb[SW_AHEAD + 1][SW_BR];
+    const double *su = &R.u[0][0], *sw = &R.r[PD][0];
+    sweep_preload<ROWS>(ab, wb, su, sw);
 
     for (int64_t n = 0; n < rows; ++n) {
-        const double dcur = d_n, rcur = r_n;
-        if (rst) {                          // Phi <- E (Phi + pending): row scaling only
-            const double el = fm_exp(-cj * de);
-            s_e[lane] = el;
+        vm_wait<2 * (PD - 3)>();
+        const int sl = (int)(n & (PD - 1)), par = (int)((pb + n) & 1);
+        const double dcur = R.u[sl][PhiRing::OD + par], zcur = R.u[sl][PhiRing::OZ + par];
+        const double dev = R.u[sl][PhiRing::OE + par];
+        const double de = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(dev)),
+                                           __builtin_amdgcn_readfirstlane(__double2loint(dev)));
+        if (de >= 0.0) {                    // Phi <- E (Phi + pending): row scaling only
+            s_e[lane] = fm_exp(-cj * de);
             wave_lds_fence();
-            sweep_preload<ROWS>(ab, wb, s_e, s_w);
-            (void)sweep_run<ROWS, true>(T, ab, wb, s_e, s_w, q, 1.0);
-            sweep_preload<ROWS>(ab, wb, s_u, s_w);
+            sweep_preload<ROWS>(ab, wb, s_e, sw);
+            (void)sweep_run<ROWS, true>(T, ab, wb, s_e, sw, q, 1.0);
+            sweep_preload<ROWS>(ab, wb, su, sw);
             q = 0.0;
         }
-        const double h = sweep_run<ROWS, false>(T, ab, wb, s_u, s_w, q, 0.0);
-        hg[(size_t)n * 64] = h;
-        G.next(t_n1, g0 + n + 1, ut, vt, rst, de);
-        t_n1 = t_n2;
-        t_n2 = tg[n + 3];
-        d_n = d_n1; r_n = r_n1;
-        d_n1 = dg[n + 2];
-        r_n1 = rg[(size_t)(n + 2) * 64];
-        wave_lds_fence();
-        s_w[lane] = rcur;                   // pending: Phi_i -= (r_i / d) h_j
-        s_u[lane] = ut;
-        wave_lds_fence();
-        sweep_preload<ROWS>(ab, wb, s_u, s_w);
-        q = -h / dcur;
+        const double h = sweep_run<ROWS, false>(T, ab, wb, su, sw, q, 0.0);
+        const double rinv = (dcur > 0.0) ? fast_rcp(dcur) : 0.0;
+        Gm.hs[n & 15][lane] = h;
+        if (lane == 0) Gm.sv[n & 15] = rinv;
+        macc = fma(h, zcur * rinv, macc);
+        su = &R.u[(int)((n + 1) & (PD - 1))][0];
+        sw = &R.r[sl][0];
+        sweep_preload<ROWS>(ab, wb, su, sw);
+        q = -h * rinv;                      // pending: Phi_i -= (r_i / d) h_j
+        C.issue(n + PD - 1, __double2loint(h));
+        if ((n & 15) == 15) phi_gram_flush<NT>(Gm, acc, lane);
     }
+    vm_wait<0>();
+    if (rows & 15) phi_gram_flush<NT>(Gm, acc, lane);
     wave_lds_fence();
+    const double *s_w = &R.r[(int)((rows - 1) & (PD - 1))][0];
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) Pg[i] = fma(s_w[i], q, T[i]);
 #pragma unroll
     for (int i = ROWS; i < 64; ++i) Pg[i] = 0.0;
+    phi_gram_store<NT>(acc, macc, G_out + (size_t)b * (64 * 64), m_out + (size_t)b * 64, lane, lane);
 }
-
-// G[i][j] = sum_n h_n[i] h_n[j] / dbar_n ;  m[i] = sum_n h_n[i] zbar_n / dbar_n   per chunk.
-// k_gram_mfma: the same sums on the FP64 matrix pipe (a pure rank-k update: 32 FMAs per loaded
-// double instead of 2 with 4x4 register blocks, which ran LDS-bound at 14 TFLOP/s).  One wave per
-// (problem, chunk); four rows per step: A[i][k] = h(row0 + k, 16 it + i) in lane (i, k),
-// B[k][j] = the same register divided by d(row0 + k); G as 10 accumulator tiles (it <= jt, G is
-// symmetric); operands come straight from global memory, prefetched one step ahead.
-__global__ void __launch_bounds__(64)
-k_gram_mfma(const int64_t N, const int64_t chunk_len, const int nch,
-            const double *__restrict__ h_, const double *__restrict__ dbar_,
-            const double *__restrict__ zbar_, double *__restrict__ G_out, double *__restrict__ m_out) {
-    const int lane = threadIdx.x, b = blockIdx.x;
-    const int pr = b / nch, ch = b - pr * nch;
-    const int64_t c0 = (int64_t)ch * chunk_len;
-    const int64_t rows = (N - c0 < chunk_len) ? (N - c0) : chunk_len;
-    const size_t pb = (size_t)pr * N + c0;
-    const double *__restrict__ hg = h_ + pb * 64;
-    const double *__restrict__ dg = dbar_ + pb;
-    const double *__restrict__ zg = zbar_ + pb;
-    const int i = lane & 15, k = lane >> 4;
-    d4 acc[4][4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) acc[it][jt] = d4{0.0, 0.0, 0.0, 0.0};
-    double macc[4] = {0.0, 0.0, 0.0, 0.0};
-    double an[4], dn = 1.0, zn = 0.0;
-    auto fetch = [&](int64_t r0) {                  // row r0 + k of this lane (zeros past the end)
-        const int64_t r = r0 + k;
-        const bool ok = r < rows;
-        const int64_t rr = ok ? r : (rows - 1);
-        dn = dg[rr];
-        zn = ok ? zg[rr] : 0.0;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) { const double v = hg[(size_t)rr * 64 + 16 * it + i]; an[it] = ok ? v : 0.0; }
-    };
-    fetch(0);
-    for (int64_t r0 = 0; r0 < rows; r0 += 4) {
-        double a[4], bq[4];
-        const double dinv = fast_rcp(dn), zd = zn * dinv;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) { a[it] = an[it]; bq[it] = a[it] * dinv; macc[it] = fma(a[it], zd, macc[it]); }
-        if (r0 + 4 < rows) fetch(r0 + 4);           // wave-uniform; in flight during the MFMAs
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-#pragma unroll
-            for (int jt = it; jt < 4; ++jt) acc[it][jt] = GF_MFMA64(a[it], bq[jt], acc[it][jt]);
-    }
-    // tile (it, jt), register r, lane (j, g):  G(16 it + g + 4 r, 16 jt + j); layout [col][row]
-    double *Gg = G_out + (size_t)b * (64 * 64);
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-        for (int jt = it; jt < 4; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * it + k + 4 * r, col = 16 * jt + i;
-                const double v = acc[it][jt][r];
-                Gg[(size_t)col * 64 + row] = v;
-                if (jt > it) Gg[(size_t)row * 64 + col] = v;
-            }
-    // m(16 it + i) = sum over the four k-slices
-    __shared__ double sm[4][64];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) sm[it][lane] = macc[it];
-    wave_lds_fence();
-    {
-        const int it = lane >> 4;                   // lane = 16 it + i
-        m_out[(size_t)b * 64 + lane] = (sm[it][i] + sm[it][i + 16]) + (sm[it][i + 32] + sm[it][i + 48]);
-    }
-}
-
 
 // ---- dense 64x64 helpers for the chunk combines (one workgroup of 256 threads) ---------------
 // LDS matrices are row-major with leading dimension CB_LD (conflict-free rows); global
@@ -4856,7 +4899,7 @@ static bool sweep_tiled(int variant, int Jr, int Jc) {
     return variant != GF_SWEEP_COLUMN && Jr == 0 && Jc <= 31;
 }
 
-#define GF_F3_ARGS dim3(B * nch), dim3(64), 0, st, N, n_first, chunk_len, nch, Jr, Jc, (block | (gen_period << 8)), gap, ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out, Ut_out, Wt_out, de_out, S_state, F_state, info
+#define GF_F3_ARGS dim3(B * chunk_count), dim3(64), 0, st, N, n_first, chunk_len, nch, chunk_first, chunk_count, Jr, Jc, (block | (gen_period << 8)), gap, ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out, Ut_out, Wt_out, de_out, S_state, F_state, info
 #define GF_F3_CASE(R) case R: if (tiled) hipLaunchKernelGGL((k_factor7<R>), GF_F3_ARGS); else hipLaunchKernelGGL((k_factor3<R>), GF_F3_ARGS); break;
 
 static int check_sweep_options(const char *who, int gen_period, int variant, int Jr, int Jc) {
@@ -4870,6 +4913,7 @@ static int check_sweep_options(const char *who, int gen_period, int variant, int
 }
 
 static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int64_t chunk_len, int nch,
+                        int chunk_first, int chunk_count,
                         int Jr, int Jc, int block, int gen_period, int variant,
                         const double *ar, const double *cr, const double *ac,
                         const double *bc, const double *cc, const double *dc,
@@ -4881,9 +4925,9 @@ static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int6
                         int32_t *info, void *stream) {
     const int W = Jr + 2 * Jc;
     if (B < 1 || N < 1) return set_err("%s: empty problem (N=%lld)", who, N);
-    // (the wide sweep stores u~ / reset spans and w~ independently: its nominal pass needs no w~ rows)
-    if ((Ut_out != nullptr) != (de_out != nullptr) || (Wt_out && !Ut_out) || (W <= 63 && Ut_out && !Wt_out))
-        return set_err("%s: Ut_out, Wt_out, de_out go together (Wt_out optional for W > 63)", who);
+    // (u~ rows / reset spans and the w~ rows are stored independently: a nominal pass needs no w~ rows)
+    if ((Ut_out != nullptr) != (de_out != nullptr) || (Wt_out && !Ut_out))
+        return set_err("%s: Ut_out and de_out go together, Wt_out needs them", who);
     if (!gf_fused_supported(Jr, Jc))
         return set_err("%s: width %lld unsupported (1..63 any terms; 64..176 complex terms only)", who, W);
     if (block < 1 || block > 64 || (block & (block - 1))) return set_err("%s: block=%lld must be a power of two in 1..64", who, block);
@@ -4891,15 +4935,18 @@ static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int6
     if (nch < 1 || chunk_len < 1 || (nch > 1 && (chunk_len % block) != 0) || (int64_t)nch * chunk_len < N
         || (int64_t)(nch - 1) * chunk_len >= N)
         return set_err("%s: bad chunking (chunk_len=%lld, nch=%lld)", who, chunk_len, nch);
+    if (chunk_first < 0 || chunk_count < 0 || chunk_first + chunk_count > nch)
+        return set_err("%s: bad chunk range (first=%lld, count=%lld)", who, chunk_first, chunk_count);
     if (!t || !y || !d || !z || !S_state || (!F_state && W <= 63) || !info || !diag_add || !cmax)
         return set_err("%s: null pointer", who);
     if (check_sweep_options(who, gen_period, W > 63 ? GF_SWEEP_AUTO : variant, Jr, Jc)) return -1;
+    if (chunk_count == 0) return 0;
     const bool tiled = sweep_tiled(variant, Jr, Jc);
     const double gap = (block > 1) ? SC_SPAN / (double)(block - 1) : 0.0;
     hipStream_t st = (hipStream_t)stream;
     if (W > 63) {                       // wide kernels: one workgroup per (problem, chunk), k_factorw
         FactorWArgs A;
-        A.N = N; A.n_first = n_first; A.chunk_len = chunk_len; A.nch = nch; A.Jc = Jc;
+        A.N = N; A.n_first = n_first; A.chunk_len = chunk_len; A.nch = nch; A.ch0 = chunk_first; A.nsel = chunk_count; A.Jc = Jc;
         A.block_sub = block | (gen_period << 8); A.gap = gap;
         A.t_bs = t_bs; A.diag_bs = diag_bs; A.y_bs = y_bs;
         FactorWPtrs P;
@@ -4907,7 +4954,7 @@ static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int6
         P.t = t; P.diag = diag; P.y = y;
         P.d = d; P.z = z; P.r_out = r_out; P.Ut_out = Ut_out; P.Wt_out = Wt_out; P.de_out = de_out;
         P.S_state = S_state; P.info = info;
-        if (dispatch_factorw(A, P, W, B * nch, st)) return set_err("%s: internal dispatch error (wide)", who);
+        if (dispatch_factorw(A, P, W, B * chunk_count, st)) return set_err("%s: internal dispatch error (wide)", who);
         return check_launch(who);
     }
     const int rows = (W + 3) / 4 * 4;
@@ -4929,13 +4976,13 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
                      const double *y, int64_t y_bs,
                      double *d, double *z, double *S_state, double *F_state,
                      int32_t *info, void *stream) {
-    return fused_launch("gf_loglike_fused", B, N, n_first, N, 1, Jr, Jc, block, gen_period, variant, ar, cr, ac, bc, cc, dc,
+    return fused_launch("gf_loglike_fused", B, N, n_first, N, 1, 0, 1, Jr, Jc, block, gen_period, variant, ar, cr, ac, bc, cc, dc,
                         diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, nullptr,
                         nullptr, nullptr, nullptr, S_state, F_state, info, stream);
 }
 
-int gf_chunk_sweep(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc, int block,
-                   int gen_period, int variant,
+int gf_chunk_sweep(int B, int64_t N, int64_t chunk_len, int nch, int chunk_first, int chunk_count,
+                   int Jr, int Jc, int block, int gen_period, int variant,
                    const double *ar, const double *cr, const double *ac,
                    const double *bc, const double *cc, const double *dc,
                    const double *diag_add, const double *cmax,
@@ -4944,34 +4991,31 @@ int gf_chunk_sweep(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc,
                    double *d, double *z, double *r_out, double *Ut_out, double *Wt_out,
                    double *de_out, double *S_state, double *F_state,
                    int32_t *info, void *stream) {
-    return fused_launch("gf_chunk_sweep", B, N, 0, chunk_len, nch, Jr, Jc, block, gen_period, variant, ar, cr, ac, bc, cc, dc,
+    return fused_launch("gf_chunk_sweep", B, N, 0, chunk_len, nch, chunk_first, chunk_count, Jr, Jc, block, gen_period, variant, ar, cr, ac, bc, cc, dc,
                         diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out,
                         Ut_out, Wt_out, de_out, S_state, F_state, info, stream);
 }
 
-#define GF_PHI_ARGS dim3(B * nch), dim3(64), 0, st, N, (int64_t)0, chunk_len, nch, Jr, Jc, (block | (gen_period << 8)), gap, ar, cr, ac, bc, cc, dc, cmax, t, t_bs, dbar, rbar, h_out, Phi_out
+#define GF_PHI_ARGS dim3(B * chunk_count), dim3(64), 0, st, N, chunk_len, nch, chunk_first, chunk_count, W, c, de, dbar, zbar, rbar, Ut, Phi_out, G_out, m_out
 #define GF_PHI_CASE(R) case R: if (tiled) hipLaunchKernelGGL((k_phi7<R>), GF_PHI_ARGS); else hipLaunchKernelGGL((k_phi<R>), GF_PHI_ARGS); break;
 
-int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc, int block,
-                        int gen_period, int variant,
-                        const double *ar, const double *cr, const double *ac,
-                        const double *bc, const double *cc, const double *dc,
-                        const double *cmax, const double *t, int64_t t_bs,
-                        const double *dbar, const double *zbar, const double *rbar,
-                        double *h_out, double *Phi_out, double *G_out, double *m_out,
-                        void *stream) {
+int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int chunk_first, int chunk_count,
+                        int Jr, int Jc, int variant, const double *c, const double *de, const double *dbar,
+                        const double *zbar, const double *rbar, const double *Ut,
+                        double *Phi_out, double *G_out, double *m_out, void *stream) {
     const int W = Jr + 2 * Jc;
     if (B < 1 || N < 1) return set_err("gf_chunk_transition: empty problem (N=%s%lld)", "", N);
     if (W < 1 || W > 63) return set_err("gf_chunk_transition: width %s%lld unsupported (1..63)", "", W);
-    if (block < 1 || block > 64 || (block & (block - 1))) return set_err("gf_chunk_transition: bad block %s%lld", "", block);
-    if (nch < 1 || chunk_len < 1 || (nch > 1 && (chunk_len % block) != 0) || (int64_t)nch * chunk_len < N
+    if (nch < 1 || chunk_len < 1 || (nch > 1 && (chunk_len % 64) != 0) || (int64_t)nch * chunk_len < N
         || (int64_t)(nch - 1) * chunk_len >= N)
         return set_err("gf_chunk_transition: bad chunking (chunk_len=%s%lld, nch=%lld)", "", chunk_len, nch);
-    if (!t || !dbar || !zbar || !rbar || !h_out || !Phi_out || !G_out || !m_out || !cmax)
+    if (chunk_first < 0 || chunk_count < 0 || chunk_first + chunk_count > nch)
+        return set_err("gf_chunk_transition: bad chunk range (first=%s%lld, count=%lld)", "", chunk_first, chunk_count);
+    if (!c || !de || !dbar || !zbar || !rbar || !Ut || !Phi_out || !G_out || !m_out)
         return set_err("gf_chunk_transition: null pointer%s", "");
-    if (check_sweep_options("gf_chunk_transition", gen_period, variant, Jr, Jc)) return -1;
+    if (check_sweep_options("gf_chunk_transition", 1, variant, Jr, Jc)) return -1;
+    if (chunk_count == 0) return 0;
     const bool tiled = sweep_tiled(variant, Jr, Jc);
-    const double gap = (block > 1) ? SC_SPAN / (double)(block - 1) : 0.0;
     hipStream_t st = (hipStream_t)stream;
     const int rows = (W + 3) / 4 * 4;
     switch (rows) {
@@ -4980,7 +5024,6 @@ int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int Jr, in
         GF_PHI_CASE(52) GF_PHI_CASE(56) GF_PHI_CASE(60) GF_PHI_CASE(64)
         default: return set_err("gf_chunk_transition: internal dispatch error%s", "");
     }
-    hipLaunchKernelGGL(k_gram_mfma, dim3(B * nch), dim3(64), 0, st, N, chunk_len, nch, h_out, dbar, zbar, G_out, m_out);
     return check_launch("gf_chunk_transition");
 }
 

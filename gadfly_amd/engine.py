@@ -479,7 +479,7 @@ class WideFactor:
             S = torch.zeros((B, int(lib.gf_fused_state_size(owner.Jr, owner.Jc))), **f64)
             bs = owner._bs
             rc = lib.gf_chunk_sweep(
-                B, N, N, 1, owner.Jr, owner.Jc, block, int(owner.generator_period), _lib.GF_SWEEP_AUTO,
+                B, N, N, 1, 0, 1, owner.Jr, owner.Jc, block, int(owner.generator_period), _lib.GF_SWEEP_AUTO,
                 p(real[0]), p(real[1]), p(comp[0]), p(comp[1]), p(comp[2]), p(comp[3]),
                 p(diag_add), p(cmax), p(owner.t), bs(owner.t), p(owner.diag),
                 0 if owner.diag is None else bs(owner.diag), p(owner.y), bs(owner.y),
@@ -1020,7 +1020,8 @@ class StreamingBatch:
             # B * nch ~ 2048 waves = 2 per SIMD, the occupancy the sweep kernels are built for
             # (measured optimum for B = 1 ... 128 at N = 2.6e5 ... 1e6, W = 60: DESIGN.md 4.3);
             # below ~512 rows per chunk the extra tree levels cost more than the sweeps save
-            nch = max(1, 2048 // B)
+            # (+ 1: the last chunk sits out the nominal pass, the first one the final pass)
+            nch = max(1, 2048 // B) + 1
             chunk_len = max(512, -(-N // nch))
         chunk_len = max(block, (int(chunk_len) + 63) // 64 * 64)
         return chunk_len, -(-N // chunk_len)
@@ -1044,17 +1045,19 @@ class StreamingBatch:
                 S=torch.empty((B * nch, 4096), **f64), F=torch.empty((B * nch, 64), **f64),
                 Phi=torch.empty((B * nch, 4096), **f64), G=torch.empty((B * nch, 4096), **f64),
                 m=torch.empty((B * nch, 64), **f64),
-                d=torch.zeros((B * N + 2,), **f64), z=torch.zeros((B * N + 2,), **f64),
-                r=torch.zeros((B * N + 2, 64), **f64), h=torch.empty((B * N, 64), **f64),
+                # (eight spare rows: the transition sweep fetches r-bar / d-bar rows ahead, unconditionally)
+                d=torch.zeros((B * N + 8,), **f64), z=torch.zeros((B * N + 8,), **f64),
+                r=torch.zeros((B * N + 8, 64), **f64),
+                Un=torch.zeros((B * N + 8, 64), **f64), den=torch.zeros((B * N + 8,), **f64),
                 info=torch.zeros((B * nch,), dtype=torch.int32, device=self.device),
                 work=torch.empty((B * int(lib.gf_reduce_work(N)),), **f64),
                 acc=torch.empty((B, 3), **f64))
             self._tp_key = key
         w = self._tp
         if store and "Ut" not in w:
-            w["Ut"] = torch.empty((B * N, 64), **f64)
+            w["Ut"] = torch.zeros((B * N + 8, 64), **f64)
             w["Wt"] = torch.empty((B * N, 64), **f64)
-            w["de"] = torch.empty((B * N,), **f64)
+            w["de"] = torch.zeros((B * N + 8,), **f64)
             # the factor's own copy of the chunk transitions: a later non-storing evaluation
             # (log_likelihood of another y) refills "Phi" with the NOMINAL pass' transitions
             w["PhiT"] = torch.empty((B * nch, 4096), **f64)
@@ -1064,39 +1067,55 @@ class StreamingBatch:
         tyd = (p(self.t), self._bs(self.t), p(self.diag),
                0 if self.diag is None else self._bs(self.diag), p(self.y), self._bs(self.y))
         none3 = (None, None, None)
+        ci = w["info"].view(B, nch)
 
-        def transition(phi="Phi"):
-            rc = lib.gf_chunk_transition(B, N, chunk_len, nch, self.Jr, self.Jc, block, *opts, *coeffs,
-                                         p(cmax), p(self.t), self._bs(self.t), p(w["d"]),
-                                         p(w["z"]), p(w["r"]), p(w["h"]), p(w[phi]),
-                                         p(w["G"]), p(w["m"]), st)
+        def transition(first, count, Ut, de, phi="Phi"):
+            rc = lib.gf_chunk_transition(B, N, chunk_len, nch, first, count, self.Jr, self.Jc,
+                                         int(self.sweep_variant), p(self._pack[3]), p(de), p(w["d"]), p(w["z"]),
+                                         p(w["r"]), p(Ut), p(w[phi]), p(w["G"]), p(w["m"]), st)
             _lib.check(rc, "gf_chunk_transition")
 
+        # chunk 0 starts from the zero state: its nominal pass IS its final pass (not when the factor is
+        # stored: the final pass also writes the w~ rows)
+        skip_first = nch > 1 and not store
+        ci0 = None
         if nch > 1:
-            rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, self.Jr, self.Jc, block, *opts, *coeffs,
+            # nominal pass (u~ rows and reset spans stored for the transition sweep).  Nothing of the LAST
+            # chunk's map is ever needed: it is left out
+            rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, 0, nch - 1, self.Jr, self.Jc, block, *opts, *coeffs,
                                     p(diag_add), p(cmax), *tyd, p(w["d"]), p(w["z"]), p(w["r"]),
-                                    *none3, p(w["S"]), p(w["F"]), p(w["info"]), st)
+                                    p(w["Un"]), None, p(w["den"]), p(w["S"]), p(w["F"]), p(w["info"]), st)
             _lib.check(rc, "gf_chunk_sweep")
-            transition()
+            # transitions and Gram sums of the chunks 1 .. nch - 2; from a zero start state the first chunk's
+            # map acts through its end state alone (Phi = G = m = 0 for the combine), the last one's not at all
+            transition(1, nch - 2, w["Un"], w["den"])
+            for k, n in (("Phi", 4096), ("G", 4096), ("m", 64)):
+                v = w[k].view(B, nch, n)
+                v[:, 0].zero_()
+                v[:, nch - 1].zero_()
             self._tp_combine(w, nch, st)
             # a nominal pass (zero start state: pivots >= the true ones) can only fail at or after
-            # the true failing row; the final pass decides, from exact start states up to there
+            # the true failing row; the final pass decides, from exact start states up to there --
+            # except for chunk 0, whose nominal pass is exact
+            ci0 = ci[:, 0].clone()
             w["info"].zero_()
         stores = (p(w["Ut"]), p(w["Wt"]), p(w["de"])) if store else none3
-        rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, self.Jr, self.Jc, block, *opts, *coeffs,
+        f0 = 1 if skip_first else 0         # (chunk 0's d, z rows stay where the nominal pass wrote them)
+        rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, f0, nch - f0, self.Jr, self.Jc, block, *opts, *coeffs,
                                 p(diag_add), p(cmax), *tyd, p(w["d"]), p(w["z"]),
                                 p(w["r"]) if (store and nch > 1) else None, *stores,
                                 p(w["S"]), p(w["F"]), p(w["info"]), st)
         _lib.check(rc, "gf_chunk_sweep")
+        if skip_first:
+            ci[:, 0] = ci0
         if store and nch > 1:
-            transition("PhiT")              # on the TRUE rows: the true chunk transitions
+            transition(0, nch, w["Ut"], w["de"], "PhiT")    # on the TRUE rows: the true chunk transitions
         rc = lib.gf_reduce_tile(B, N, p(w["d"]), p(w["z"]), p(w["work"]), p(w["acc"]), 1, st)
         _lib.check(rc, "gf_reduce_tile")
         # a chunk that failed marks its problem with the FIRST non-positive pivot (celerite2 and the
         # sequential sweep stop there; chunks after a failed one ran from meaningless start states)
-        ci = w["info"].view(B, nch)
         big = torch.iinfo(torch.int32).max
-        first = torch.where(ci != 0, ci, torch.full_like(ci, big)).min(dim=1).values
+        first = torch.where(ci > 0, ci, torch.full_like(ci, big)).min(dim=1).values
         self.info.copy_(torch.where(first == big, torch.zeros_like(first), first))
         out = torch.empty((B,), **f64)
         rc = lib.gf_loglike_finish(B, N, p(w["acc"]), p(self.info), p(out), None, st)
@@ -1232,8 +1251,8 @@ class StreamingBatch:
         tyd = (p(self.t), self._bs(self.t), p(self.diag),
                0 if self.diag is None else self._bs(self.diag), p(self.y), self._bs(self.y))
 
-        def sweep(dd, zz, r_out, st_rows):
-            rc = lib.gf_chunk_sweep(B, N, L, nch, self.Jr, self.Jc, block, *opts, *coeffs,
+        def sweep(first, count, dd, zz, r_out, st_rows):
+            rc = lib.gf_chunk_sweep(B, N, L, nch, first, count, self.Jr, self.Jc, block, *opts, *coeffs,
                                     p(diag_add), p(cmax), *tyd, p(dd), p(zz), r_out, *st_rows,
                                     p(S), None, p(cinfo), st)
             _lib.check(rc, "gf_chunk_sweep")
@@ -1245,9 +1264,8 @@ class StreamingBatch:
         ci0 = None
         if nch > 1:
             # 1. nominal pass: zero start states; d-bar, z-bar, r-bar, u~ rows, reset spans.  Nothing of the LAST
-            #    chunk's map is ever needed (gf_wide_combine): its slots are marked done and exit at once
-            ci[:, nch - 1] = -1
-            sweep(dbar, zbar, p(rbar), (p(Ut), None, p(de)))
+            #    chunk's map is ever needed (gf_wide_combine): it is left out
+            sweep(0, nch - 1, dbar, zbar, p(rbar), (p(Ut), None, p(de)))
             # 2. closed-loop transitions and the rows h (not for the first chunk either: from a zero start
             #    state its map acts through its end state alone)
             rc = lib.gf_chunk_transition_wide(B, N, L, nch, 1, nch - 2, self.Jc, p(c), p(de), p(dbar),
@@ -1266,8 +1284,8 @@ class StreamingBatch:
             L0 = min(L, N)
             dd[:B * N].view(B, N)[:, :L0] = dbar[:B * N].view(B, N)[:, :L0]
             zz[:B * N].view(B, N)[:, :L0] = zbar[:B * N].view(B, N)[:, :L0]
-            ci[:, 0] = -1
-        sweep(dd, zz, p(rbar) if keep else None,     # (the TRUE factor's r rows replace the nominal ones)
+        f0 = 1 if skip_first else 0
+        sweep(f0, nch - f0, dd, zz, p(rbar) if keep else None,     # (the TRUE factor's r rows replace the nominal ones)
               (p(Ut), p(Wt), p(de)) if stores is not None else (None, None, None))
         if skip_first:
             ci[:, 0] = ci0

@@ -177,9 +177,14 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
  * concurrently, then stitched with an exact linear-fractional combine:
  *   1. gf_chunk_sweep      nominal pass: S_state/F_state [B*nch] zeroed by the caller; every chunk
  *                          starts from the zero state; outputs dbar, zbar [B][N], rbar [B][N][64]
- *                          (pass r_out) and the nominal end states in S_state/F_state.
- *   2. gf_chunk_transition closed-loop transition Phi [B*nch][64*64], the rows h [B][N][64], and
- *                          G [B*nch][64*64], m [B*nch][64] of every chunk.
+ *                          (pass r_out), the rows u~ [B][N][64] and reset spans de [B][N] (pass Ut_out,
+ *                          de_out; Wt_out may stay NULL) and the nominal end states in S_state/F_state.
+ *   2. gf_chunk_transition closed-loop transition Phi [B*nch][64*64] and the Gram sums G [B*nch][64*64],
+ *                          m [B*nch][64] of the chunks chunk_first .. chunk_first + chunk_count - 1 of
+ *                          every problem, from those rows (c [B][W]: the columns' decay rates).  The
+ *                          start states never depend on the last chunk's map, and on the first chunk's
+ *                          only through its end state: callers sweep the chunks 1 .. nch - 2 and hand
+ *                          the combine zeros for the first chunk's Phi, G, m.
  *   3. gf_chunk_combine    sequential LFT combine over the chunks (64x64 pivoted solves in LDS):
  *                          S_state/F_state slot c <- TRUE start state of chunk c.
  *      gf_chunk_combine_tree  the same result in 2 log2(P) levels (Blelloch scan over the chunk
@@ -192,14 +197,17 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
  *                          sequential result to rounding; reduce with gf_reduce_tile.  With
  *                          Ut_out, Wt_out [B][N][64] and de_out [B][N] the pass also stores the
  *                          factor in scaled form (rows u~, w~ = r/d and the reset spans) for
- *                          gf_chunk_linear.  (Wide kernels, W > 63: Wt_out may be NULL with Ut_out,
- *                          de_out given -- the nominal pass of their combine needs no w~ rows.)
+ *                          gf_chunk_linear.
  * Same argument conventions (gen_period and variant included: pass the SAME values to all
- * calls of one evaluation) and padding rules as gf_loglike_fused; dbar and rbar must be
- * readable two rows past the end.  Width 1..63, phases |d t| < 3e9.
+ * calls of one evaluation) and padding rules as gf_loglike_fused; the row arrays gf_chunk_transition
+ * reads (Ut, rbar, dbar, zbar, de) must be readable EIGHT rows past the end (they are fetched ahead by
+ * LDS-DMA).  Width 1..63, phases |d t| < 3e9.  gf_chunk_sweep works on the chunks chunk_first ..
+ * chunk_first + chunk_count - 1 of every problem (state slots and rows of the others are left alone): the
+ * nominal pass leaves out the last chunk, a final pass that stores no factor the first one (whose nominal
+ * pass was exact).  A slot whose info entry is non-zero on entry is skipped as well.
  */
-int gf_chunk_sweep(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc, int block,
-                   int gen_period, int variant,
+int gf_chunk_sweep(int B, int64_t N, int64_t chunk_len, int nch, int chunk_first, int chunk_count,
+                   int Jr, int Jc, int block, int gen_period, int variant,
                    const double *ar, const double *cr, const double *ac,
                    const double *bc, const double *cc, const double *dc,
                    const double *diag_add, const double *cmax,
@@ -208,14 +216,10 @@ int gf_chunk_sweep(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc,
                    double *d, double *z, double *r_out, double *Ut_out, double *Wt_out,
                    double *de_out, double *S_state, double *F_state,
                    int32_t *info, void *stream);
-int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int Jr, int Jc, int block,
-                        int gen_period, int variant,
-                        const double *ar, const double *cr, const double *ac,
-                        const double *bc, const double *cc, const double *dc,
-                        const double *cmax, const double *t, int64_t t_bs,
-                        const double *dbar, const double *zbar, const double *rbar,
-                        double *h_out, double *Phi_out, double *G_out, double *m_out,
-                        void *stream);
+int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int chunk_first, int chunk_count,
+                        int Jr, int Jc, int variant, const double *c, const double *de, const double *dbar,
+                        const double *zbar, const double *rbar, const double *Ut,
+                        double *Phi_out, double *G_out, double *m_out, void *stream);
 /*
  * The stored rows as a factor for gf_solve (any width the fused sweeps take, in particular the wide
  * kernels, which have no chunk-parallel sweeps): gf_fused_row_stride is the leading dimension of
