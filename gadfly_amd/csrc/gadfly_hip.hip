@@ -1196,7 +1196,9 @@ __device__ __forceinline__ void sweep7_run(double (&T)[ROWS / 2][2], double2 (&u
     o1 = a01 + a11;
 }
 
-template <int ROWS>
+// ROWSTORE = false: no row is stored (r_out, Ut_out, Wt_out, de_out all null: the streamed log-likelihood
+// and the plain final pass) -- their tests, pointer arithmetic and exec-mask switches leave the row loop
+template <int ROWS, bool ROWSTORE>
 __global__ void __launch_bounds__(64, 2)
 k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const int nch,
           const int ch0, const int nsel, const int Jr, const int Jc, const int block_sub, const double gap,
@@ -1229,10 +1231,10 @@ k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     double *__restrict__ zg = z_ + pb;
     const int own = 2 * c + g;                      // the column whose row-vector entries this lane carries
     // chunk-mode row stores: loop-invariant per-lane pointers, indexed with opaque_uniform(row)
-    double *__restrict__ rg = r_out ? r_out + pb * 64 + own : nullptr;
-    double *__restrict__ ug = Ut_out ? Ut_out + pb * 64 + own : nullptr;
-    double *__restrict__ wg = Wt_out ? Wt_out + pb * 64 + own : nullptr;
-    double *__restrict__ eg = de_out ? de_out + pb : nullptr;
+    double *__restrict__ rg = (ROWSTORE && r_out) ? r_out + pb * 64 + own : nullptr;
+    double *__restrict__ ug = (ROWSTORE && Ut_out) ? Ut_out + pb * 64 + own : nullptr;
+    double *__restrict__ wg = (ROWSTORE && Wt_out) ? Wt_out + pb * 64 + own : nullptr;
+    double *__restrict__ eg = (ROWSTORE && de_out) ? de_out + pb : nullptr;
     double *__restrict__ Sg = S_state + (size_t)b * (64 * 64);     // [column][row]
     double *__restrict__ Fg = F_state + (size_t)b * 64;
     const double diag_add = diag_add_[pr];
@@ -1278,7 +1280,7 @@ k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     for (int64_t n = 0; n < rows; ++n) {
         const double a_n = (has_g ? g_n : 0.0) + diag_add, yy = y_n;
         const double ut_c = ut, vt_c = vt;
-        if (eg && lane == 0) eg[n] = rst ? de : -1.0;
+        if constexpr (ROWSTORE) { if (eg && lane == 0) eg[n] = rst ? de : -1.0; }
         if (rst) {                          // wave-uniform: fold the pending update, then decay
             const double el = fm_exp(-cj * de);     // pad columns: cj = 0 -> 1
             s_e[own] = el;
@@ -1321,10 +1323,12 @@ k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
         const double inv = fast_rcp(dn);
         q0 = r0 * inv;                              // multipliers of this lane's two state columns;
         q1 = fma(zn, is31, r1) * inv;               // column 63: z / d (r is 0 there)
-        const size_t ro = opaque_uniform((size_t)n * 64);
-        if (rg) rg[ro] = r;                         // r~ rows for k_phi (chunk mode)
-        if (ug) ug[ro] = ut_c;
-        if (wg) wg[ro] = r * inv;
+        if constexpr (ROWSTORE) {
+            const size_t ro = opaque_uniform((size_t)n * 64);
+            if (rg) rg[ro] = r;                     // r~ rows for k_phi (chunk mode)
+            if (ug) ug[ro] = ut_c;
+            if (wg) wg[ro] = r * inv;
+        }
         if (lane == 0) { dg[n] = dn; zg[n] = zn; }
     }
     if (fail) {
@@ -1985,7 +1989,7 @@ __device__ __forceinline__ double own_column_sum8(const double a, const double b
 // deep: with row arrays beyond the caches (a shard of cfg4: 3 x 9.8 GB) a row cost 0.9 us, all of it
 // memory latency at eight waves per CU.
 template <int TR, int D, int NI>
-__global__ void __launch_bounds__(64, (TR <= 12 && D <= 4) ? 4 : 2)
+__global__ void __launch_bounds__(64, (TR <= 12 && NI == 1) ? 4 : 2)
 k_phiw(const int64_t N, const int64_t chunk_len, const int nch, const int ch0, const int nsel, const int W,
        const int CP,
        const double *__restrict__ c_, const double *__restrict__ de_, const double *__restrict__ dbar_,
@@ -4900,7 +4904,7 @@ static bool sweep_tiled(int variant, int Jr, int Jc) {
 }
 
 #define GF_F3_ARGS dim3(B * chunk_count), dim3(64), 0, st, N, n_first, chunk_len, nch, chunk_first, chunk_count, Jr, Jc, (block | (gen_period << 8)), gap, ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out, Ut_out, Wt_out, de_out, S_state, F_state, info
-#define GF_F3_CASE(R) case R: if (tiled) hipLaunchKernelGGL((k_factor7<R>), GF_F3_ARGS); else hipLaunchKernelGGL((k_factor3<R>), GF_F3_ARGS); break;
+#define GF_F3_CASE(R) case R: if (tiled && rowstore) hipLaunchKernelGGL((k_factor7<R, true>), GF_F3_ARGS); else if (tiled) hipLaunchKernelGGL((k_factor7<R, false>), GF_F3_ARGS); else hipLaunchKernelGGL((k_factor3<R>), GF_F3_ARGS); break;
 
 static int check_sweep_options(const char *who, int gen_period, int variant, int Jr, int Jc) {
     if (gen_period < 1 || gen_period > 64 || (gen_period & (gen_period - 1)))
@@ -4958,6 +4962,7 @@ static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int6
         return check_launch(who);
     }
     const int rows = (W + 3) / 4 * 4;
+    const bool rowstore = r_out || Ut_out || Wt_out || de_out;
     switch (rows) {
         GF_F3_CASE(4) GF_F3_CASE(8) GF_F3_CASE(12) GF_F3_CASE(16) GF_F3_CASE(20) GF_F3_CASE(24)
         GF_F3_CASE(28) GF_F3_CASE(32) GF_F3_CASE(36) GF_F3_CASE(40) GF_F3_CASE(44) GF_F3_CASE(48)

@@ -10,6 +10,10 @@ independent oracles --
   * oracle/seq.py   : the celerite recurrences run in 80-bit np.longdouble
 and are stored only when the two agree (gates below).  PARITY UNPINNED at the reference level.
 
+The coefficient vectors of every case come from the oracle's own algebra (oracle/terms_ref.py), so the
+product's SHOTerm / TermSum / TermConvolution (gadfly_amd/terms.py) is checked by something it did not
+write (tests/test_terms.py compares the two).
+
 Each file holds inputs (coefficient vectors, t, diag_user, diag_shift, y, normal draws n,
 prediction times ts) and expected outputs (loglike, logdet, alpha = K^-1 y, Ln = L D^1/2 n,
 mean at t (t=None), mean/var at ts), or info for the not-positive-definite case.
@@ -22,7 +26,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-from oracle import dense, seq            # noqa: E402
+from oracle import dense, seq, terms_ref # noqa: E402
 from tests import util                   # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
@@ -42,10 +46,20 @@ CASES = {
 }
 
 
+def oracle_coefficients(k):
+    """Celerite coefficients of a test kernel from the ORACLE's algebra (oracle/terms_ref.py, real-arithmetic
+    restatement of SURVEY A.1 - A.3), not from the product's: the kernel object only supplies its
+    parameters -- the (S0, w0, Q) triples and the exposure."""
+    delta = getattr(k, "delta", None)
+    base = k.term if delta is not None else k
+    triples = [(s.S0, s.w0, s.Q) for s in base.terms]
+    return terms_ref.kernel_coefficients(triples, delta)
+
+
 def build(name, kind, kw):
     prob = util.solar_problem(**kw) if kind == "solar" else util.generic_problem(**kw)
     k, t, y, du = prob["kernel"], prob["t"], prob["y"], prob["diag_user"]
-    ar, cr, ac, bc, cc, dc, shift = k.get_device_coefficients()
+    ar, cr, ac, bc, cc, dc, shift = oracle_coefficients(k)
     co = (ar, cr, ac, bc, cc, dc)
     diag = du + shift
     N = len(t)
@@ -94,9 +108,9 @@ def build(name, kind, kw):
 def build_failing():
     prob = util.generic_problem("mixed", 200)
     k, t, y = prob["kernel"], prob["t"], prob["y"]
-    ar, cr, ac, bc, cc, dc, shift = k.get_device_coefficients()
+    ar, cr, ac, bc, cc, dc, shift = oracle_coefficients(k)
     du = prob["diag_user"].copy()
-    du[120:] = -3.0 * k.get_value(np.zeros(1))[0]
+    du[120:] = -3.0 * (np.sum(ar) + np.sum(ac) + shift)      # k(0), from the oracle's coefficients
     c, a, U, V = seq.celerite_matrices((ar, cr, ac, bc, cc, dc), t, du + shift)
     _, _, info = seq.factor(t, c, a, U, V)
     assert info == 121

@@ -187,3 +187,121 @@ def test_broomhall_known_frequencies(example_freq):
     assert len(nu) == len(ell) == 81 and set(ell) <= {0, 1, 2, 3}
     closest = nu[np.argmin(np.abs(nu - example_freq))]
     np.testing.assert_allclose(example_freq, closest)
+
+
+# ---------------------------------------------------------------------------------------------
+# pinned to the reference: outputs of /root/reference/gadfly/core.py's own statements
+# (tests/golden/reference/make_core_golden.py ran them in the build container)
+# ---------------------------------------------------------------------------------------------
+def _core_fixture():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "reference", "core_functions.npz"))
+
+
+def test_sho_psd_matches_the_reference_function():
+    """`_sho_psd` (reference core.py:33-41) -- the product's copy, SHOTerm.get_psd, the generic coefficient
+    PSD of the celerite form, and the oracle's restatement all reproduce the reference's outputs."""
+    from gadfly_amd.core import _sho_psd
+    from gadfly_amd.terms import Term
+    from oracle import terms_ref
+    fx = _core_fixture()
+    omega, want = fx["omega"], fx["sho_psd"]
+    for (S0, w0, Q), ref in zip(fx["sho_params"], want):
+        np.testing.assert_allclose(_sho_psd(omega, S0, w0, Q), ref, rtol=1e-15, atol=0.0)
+        np.testing.assert_allclose(SHOTerm(S0=S0, w0=w0, Q=Q).get_psd(omega), ref, rtol=4e-15, atol=0.0)
+        np.testing.assert_allclose(terms_ref.sho_psd(omega, S0, w0, Q), ref, rtol=1e-15, atol=0.0)
+        # the PSD computed from the celerite coefficients (what a TermSum / TermConvolution with delta = 0
+        # evaluates): exact for Q >= 1/2 up to the cancellation in w^4 + 2 (c^2 - d^2) w^2 + (c^2 + d^2)^2
+        # (at Q = 1/2 celerite2's SHOTerm regularises f = sqrt(max(4 Q^2 - 1, eps = 1e-5)): O(eps) in the PSD)
+        if Q >= 0.5:
+            got = Term.get_psd(SHOTerm(S0=S0, w0=w0, Q=Q), omega)
+            # (and the coefficient form cancels in its numerator far above w0: compared up to 30 w0)
+            rtol = 1e-4 if 4 * Q * Q - 1 < 1e-3 else 1e-7 * max(1.0, Q)
+            near = omega <= 30.0 * w0
+            np.testing.assert_allclose(got[near], ref[near], rtol=rtol, atol=0.0)
+
+
+def test_kepler_noise_amplitude_matches_the_reference_statements():
+    """ShotNoiseKernel.kepler_mag_to_noise_amplitude (reference core.py:522-544: Jenkins et al. 2010): the
+    fixture holds sigma_lower, sigma_upper from the reference's own assignment statements; the function
+    returns 1e6 [sigma_lower, sigma_upper] (in ppm^2: the reference tags the unit on its return line)."""
+    fx = _core_fixture()
+    for m, sig in zip(fx["kepler_mag"], fx["sigma"]):
+        got = gadfly_amd.ShotNoiseKernel.kepler_mag_to_noise_amplitude(float(m))
+        np.testing.assert_allclose(np.asarray(got, dtype=float), 1e6 * sig, rtol=1e-15, atol=0.0)
+    got = gadfly_amd.ShotNoiseKernel.kepler_mag_to_noise_amplitude(fx["kepler_mag"])
+    np.testing.assert_allclose(np.asarray(got[0], dtype=float), 1e6 * fx["sigma_array_form"][:, 0], rtol=1e-15)
+    np.testing.assert_allclose(np.broadcast_to(got[1], fx["kepler_mag"].shape),
+                               1e6 * fx["sigma_array_form"][:, 1], rtol=1e-15)
+
+
+# ---------------------------------------------------------------------------------------------
+# the product's coefficient algebra against the oracle's independent restatement (oracle/terms_ref.py:
+# real arithmetic, SURVEY A.1 - A.3) -- the golden vectors take their coefficient inputs from the oracle
+# ---------------------------------------------------------------------------------------------
+def _against_oracle(kernel, triples, delta):
+    from oracle import terms_ref
+    got = kernel.get_device_coefficients()
+    want = terms_ref.kernel_coefficients(triples, delta)
+    # exposure integration: both formulations take cosh(z delta) - 1 at |z delta| << 1 (the real form as
+    # celerite2 writes it, the product's in complex arithmetic): each is good to ~eps / |z delta|^2, which is
+    # what they may differ by -- 1e-10 for the slowest granulation term at a one-minute exposure
+    rtol = 2e-13
+    if delta is not None:
+        raw = terms_ref.sum_coefficients(triples)
+        x2 = min([float(np.min((raw[1] * delta) ** 2))] if len(raw[1]) else []
+                 + [float(np.min((raw[4] ** 2 + raw[5] ** 2) * delta ** 2))] if len(raw[4]) else [1.0])
+        rtol = max(rtol, 20 * 2.3e-16 / min(x2, 1.0))
+    for g, w in zip(got[:6], want[:6]):
+        assert np.shape(g) == np.shape(w)
+        if np.size(w):
+            np.testing.assert_allclose(g, w, rtol=rtol, atol=0.0)
+    # the diagonal correction is a difference of nearly equal terms (x - sinh x at x = c delta << 1): both
+    # formulations carry ~1e-9 of ITSELF, i.e. ~1e-12 of the variance k(0) it corrects
+    raw0 = terms_ref.sum_coefficients(triples)
+    k0 = float(np.sum(np.abs(raw0[0])) + np.sum(np.abs(raw0[2])))
+    assert abs(got[6] - want[6]) <= 1e-11 * k0 + 1e-13 * abs(want[6])
+
+
+@pytest.mark.parametrize("J", [1, 5, 6, 20, 30, 40, 86])
+def test_stellar_kernel_coefficients_against_oracle(J):
+    hp = solar_like_hyperparameters(min(J, 40)) if J < 86 else None
+    if hp is None:
+        k = gadfly_amd.SolarOscillatorKernel(texp=60.0, bandpass="SOHO VIRGO")
+        hp = k.hyperparameters
+    else:
+        k = gadfly_amd.StellarOscillatorKernel(hp, texp=60.0)
+    triples = [tuple(p["hyperparameters"][q] for q in ("S0", "w0", "Q")) for p in hp]
+    _against_oracle(k, triples, k.delta)
+
+
+def test_random_and_edge_kernels_against_oracle():
+    rng = np.random.default_rng(5)
+    cases = [[(1.0, 2 * np.pi * 3.0, 100.0)], [(2.0, 1.5, 0.3)], [(1.0, 2.0, 0.5)],
+             [(1.0, 3.0, 5.0), (0.5, 1.0, 0.3), (2.0, 0.7, 0.6)]]
+    for _ in range(20):
+        n = int(rng.integers(1, 8))
+        cases.append([(10 ** rng.uniform(-3, 2), 10 ** rng.uniform(-1, 3), 10 ** rng.uniform(-0.6, 3))
+                      for _ in range(n)])
+    for triples in cases:
+        # (overdamped terms come first in the oracle's concatenation only if they do in the product's: both
+        # concatenate per term, real parts and complex parts separately, in term order)
+        for delta in (None, 0.01, 0.3):
+            base = TermSum(*[SHOTerm(S0=a, w0=b, Q=c) for a, b, c in triples])
+            k = base if delta is None else TermConvolution(base, delta)
+            _against_oracle(k, triples, delta)
+
+
+def test_golden_inputs_come_from_the_oracle():
+    """The committed golden vectors carry the oracle's coefficients (tests/golden/make_golden.py), so the HIP
+    path is checked on inputs the product did not compute."""
+    import os
+    from tests import util
+    from tests.golden.make_golden import CASES, oracle_coefficients
+    for name, (kind, kw) in CASES.items():
+        prob = util.solar_problem(**kw) if kind == "solar" else util.generic_problem(**kw)
+        want = oracle_coefficients(prob["kernel"])
+        fx = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+        for key, w in zip(("ar", "cr", "ac", "bc", "cc", "dc"), want[:6]):
+            assert np.array_equal(fx[key], w), (name, key)
+        assert float(fx["diag_shift"]) == want[6]
