@@ -246,16 +246,20 @@ def _against_oracle(kernel, triples, delta):
     # exposure integration: both formulations take cosh(z delta) - 1 at |z delta| << 1 (the real form as
     # celerite2 writes it, the product's in complex arithmetic): each is good to ~eps / |z delta|^2, which is
     # what they may differ by -- 1e-10 for the slowest granulation term at a one-minute exposure
-    rtol = 2e-13
-    if delta is not None:
-        raw = terms_ref.sum_coefficients(triples)
-        x2 = min([float(np.min((raw[1] * delta) ** 2))] if len(raw[1]) else []
-                 + [float(np.min((raw[4] ** 2 + raw[5] ** 2) * delta ** 2))] if len(raw[4]) else [1.0])
-        rtol = max(rtol, 20 * 2.3e-16 / min(x2, 1.0))
-    for g, w in zip(got[:6], want[:6]):
+    raw = terms_ref.sum_coefficients(triples)
+    eps = 2.3e-16
+
+    def tol(x2):                        # per term: eps / |z delta|^2, at least a few ulps
+        return np.maximum(2e-13, 20 * eps / np.minimum(x2, 1.0)) if delta is not None else np.full(x2.shape, 2e-13)
+
+    tol_r, tol_c = tol((raw[1] * (delta or 1.0)) ** 2), tol((raw[4] ** 2 + raw[5] ** 2) * (delta or 1.0) ** 2)
+    for k, (g, w) in enumerate(zip(got[:6], want[:6])):
         assert np.shape(g) == np.shape(w)
         if np.size(w):
-            np.testing.assert_allclose(g, w, rtol=rtol, atol=0.0)
+            rt = tol_r if k < 2 else tol_c
+            # (a' and b' of a complex term are compared on the scale of the pair: either may nearly cancel)
+            scale = np.abs(w) + ((np.abs(want[2]) + np.abs(want[3])) if k in (2, 3) else 0.0)
+            assert np.all(np.abs(g - w) <= rt * scale), (k, g, w)
     # the diagonal correction is a difference of nearly equal terms (x - sinh x at x = c delta << 1): both
     # formulations carry ~1e-9 of ITSELF, i.e. ~1e-12 of the variance k(0) it corrects
     raw0 = terms_ref.sum_coefficients(triples)
