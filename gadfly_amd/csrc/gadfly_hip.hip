@@ -3269,7 +3269,7 @@ k_segment_transition(const int nch, const int seg_len, const double *__restrict_
 //   A, B and X move through an LDS tile of 32 rows so that global accesses are contiguous (lanes
 //   along a row); lane = row gathers of a row-major matrix cost more than the elimination.
 // Singular systems (maps of chunks after a failed pivot) produce garbage, never a fault.
-constexpr int DS_WAVES = 16, DS_NR = 4;             // 64 right-hand sides per workgroup
+constexpr int DS_WAVES = 16;                        // 16 NR right-hand sides per workgroup (NR: template parameter)
 constexpr int DS_TROWS = 32, DS_LDT = 193;          // LDS tile: 32 rows, odd leading dimension
 
 template <int RS>
@@ -3323,11 +3323,11 @@ __device__ __forceinline__ void ds_pivot_row(double (&pe)[NS], const double (&R)
     }
 }
 
-// phase Q of the elimination: steps k = 16 Q ... 16 Q + 15 (< n), slots [Q, NA + DS_NR)
-template <int RS, int NA, int Q>
-__device__ __forceinline__ void ds_phase(DenseSolveShared<RS> &sh, double (&R)[RS][NA + DS_NR], unsigned &used,
+// phase Q of the elimination: steps k = 16 Q ... 16 Q + 15 (< n), slots [Q, NA + NR)
+template <int RS, int NA, int NR, int Q>
+__device__ __forceinline__ void ds_phase(DenseSolveShared<RS> &sh, double (&R)[RS][NA + NR], unsigned &used,
                                          const int n, const int wave, const int lane) {
-    constexpr int NS = NA + DS_NR;
+    constexpr int NS = NA + NR;
     const int kend = (n - DS_WAVES * Q < DS_WAVES) ? n - DS_WAVES * Q : DS_WAVES;
     for (int kk = 0; kk < kend; ++kk) {
         const int k = DS_WAVES * Q + kk, buf = k & 1;
@@ -3367,10 +3367,12 @@ __device__ __forceinline__ void ds_phase(DenseSolveShared<RS> &sh, double (&R)[R
     }
 }
 
-template <int RS, int NA>
+// NR right-hand-side slots per wave: 4 (64 per workgroup) for many systems; 1 when few systems leave the chip
+// empty -- every workgroup eliminates its own copy of A, so narrower slices only shorten the step
+template <int RS, int NA, int NR>
 __global__ void __launch_bounds__(64 * DS_WAVES)
 k_dense_solve(const int n, const int nrhs, const double *__restrict__ A_, double *__restrict__ B_) {
-    constexpr int NS = NA + DS_NR, NT = 64 * DS_WAVES, BC = DS_WAVES * DS_NR;
+    constexpr int NS = NA + NR, NT = 64 * DS_WAVES, BC = DS_WAVES * NR;
     const int b = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const double *Ab = A_ + (size_t)b * n * n;
@@ -3406,7 +3408,7 @@ k_dense_solve(const int n, const int nrhs, const double *__restrict__ A_, double
         __syncthreads();
         if (half == (t & 1)) {
 #pragma unroll
-            for (int lr = 0; lr < DS_NR; ++lr) R[r][NA + lr] = sh.tile[l32 * DS_LDT + wave + DS_WAVES * lr];
+            for (int lr = 0; lr < NR; ++lr) R[r][NA + lr] = sh.tile[l32 * DS_LDT + wave + DS_WAVES * lr];
         }
         __syncthreads();
     }, std::make_integer_sequence<int, 2 * RS>{});
@@ -3421,7 +3423,7 @@ k_dense_solve(const int n, const int nrhs, const double *__restrict__ A_, double
         for (int r = 0; r < RS; ++r) C[r] = R[r][0];
         ds_search<RS>(sh, C, used, 0, lane);
     }
-    static_for([&](auto q) { ds_phase<RS, NA, decltype(q)::value>(sh, R, used, n, wave, lane); },
+    static_for([&](auto q) { ds_phase<RS, NA, NR, decltype(q)::value>(sh, R, used, n, wave, lane); },
                std::make_integer_sequence<int, NA>{});
     __syncthreads();
     // row 64 r + lane solved variable rowk[...]: X(rowk, :) = its B slots / pivot, through the tile
@@ -3431,7 +3433,7 @@ k_dense_solve(const int n, const int nrhs, const double *__restrict__ A_, double
         myk[r] = sh.rowk[64 * r + lane];
         const double pinv = sh.rowpinv[64 * r + lane];
 #pragma unroll
-        for (int lr = 0; lr < DS_NR; ++lr) R[r][NA + lr] *= pinv;
+        for (int lr = 0; lr < NR; ++lr) R[r][NA + lr] *= pinv;
     }
     for (int row0 = 0; row0 < n; row0 += DS_TROWS) {
 #pragma unroll
@@ -3439,7 +3441,7 @@ k_dense_solve(const int n, const int nrhs, const double *__restrict__ A_, double
             const int rel = myk[r] - row0;
             if (rel >= 0 && rel < DS_TROWS) {
 #pragma unroll
-                for (int lr = 0; lr < DS_NR; ++lr) sh.tile[rel * DS_LDT + wave + DS_WAVES * lr] = R[r][NA + lr];
+                for (int lr = 0; lr < NR; ++lr) sh.tile[rel * DS_LDT + wave + DS_WAVES * lr] = R[r][NA + lr];
             }
         }
         __syncthreads();
@@ -5235,8 +5237,13 @@ int gf_dense_solve(int batch, int n, int nrhs, const double *A, double *B, void 
     if (n > 192) return set_err("gf_dense_solve: n=%s%lld unsupported (max %lld)", "", n, 192);
     if (!A || !B) return set_err("gf_dense_solve: null pointer%s", "");
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(batch, (nrhs + DS_WAVES * DS_NR - 1) / (DS_WAVES * DS_NR));
-#define GF_DS(RSv, NAv) hipLaunchKernelGGL((k_dense_solve<RSv, NAv>), grid, dim3(64 * DS_WAVES), 0, st, n, nrhs, A, B)
+    // few systems: 16 right-hand sides per workgroup (more, shorter-stepping workgroups); else 64
+    const int slices4 = (nrhs + DS_WAVES * 4 - 1) / (DS_WAVES * 4);
+    const bool narrow = (long long)batch * slices4 <= 64;
+    const int per = DS_WAVES * (narrow ? 1 : 4);
+    const dim3 grid(batch, (nrhs + per - 1) / per);
+#define GF_DS(RSv, NAv) do { if (narrow) hipLaunchKernelGGL((k_dense_solve<RSv, NAv, 1>), grid, dim3(64 * DS_WAVES), 0, st, n, nrhs, A, B); \
+                             else hipLaunchKernelGGL((k_dense_solve<RSv, NAv, 4>), grid, dim3(64 * DS_WAVES), 0, st, n, nrhs, A, B); } while (0)
     if (n <= 64) GF_DS(1, 4);
     else if (n <= 96) GF_DS(2, 6);
     else if (n <= 128) GF_DS(2, 8);

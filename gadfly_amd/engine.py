@@ -455,12 +455,13 @@ class WideFactor:
         B, N = self.B, self.N
         self.ld = int(lib.gf_fused_row_stride(owner.Jr, owner.Jc))
         f64 = dict(dtype=torch.float64, device=self.device)
-        # (eight spare rows: the transition sweep fetches its rows ahead, unconditionally)
-        self.Ut = torch.zeros((B * N + 8, self.ld), **f64)[:B * N].view(B, N, self.ld)
+        # (eight spare rows: the transition sweep fetches its rows ahead, unconditionally -- what it reads
+        # there is never used, so nothing is zeroed: every row and column that IS used is written by the sweep)
+        self.Ut = torch.empty((B * N + 8, self.ld), **f64)[:B * N].view(B, N, self.ld)
         self.Wt = torch.empty((B, N, self.ld), **f64)
-        self.de = torch.zeros((B * N + 8,), **f64)[:B * N].view(B, N)
-        self.d = torch.zeros((B * N + 8,), **f64)[:B * N].view(B, N)
-        self.z = torch.zeros((B * N + 8,), **f64)[:B * N].view(B, N)
+        self.de = torch.empty((B * N + 8,), **f64)[:B * N].view(B, N)
+        self.d = torch.empty((B * N + 8,), **f64)[:B * N].view(B, N)
+        self.z = torch.empty((B * N + 8,), **f64)[:B * N].view(B, N)
         real, comp, diag_add, c, cmax, block, _ = owner._pack
         self.c, self.t = c, owner.t
         self.info = torch.zeros((B,), dtype=torch.int32, device=self.device)
@@ -1204,8 +1205,8 @@ class StreamingBatch:
             f64 = dict(dtype=torch.float64, device=self.device)
             rows = B * N + 8
             ws = dict(key=key, ld=ld, nS=nS,
-                      dbar=torch.zeros((rows,), **f64), zbar=torch.zeros((rows,), **f64),
-                      rbar=torch.zeros((rows, ld), **f64), h=torch.zeros((rows, ld), **f64),
+                      dbar=torch.empty((rows,), **f64), zbar=torch.empty((rows,), **f64),
+                      rbar=torch.empty((rows, ld), **f64), h=torch.empty((rows, ld), **f64),
                       S=torch.empty((B * nch, nS), **f64), Phi=torch.empty((B * nch, nS), **f64),
                       cinfo=torch.zeros((B * nch,), dtype=torch.int32, device=self.device),
                       work=torch.empty((max(1, int(lib.gf_wide_combine_work(B, max(nch, 2), self.Jc))),), **f64),
@@ -1217,7 +1218,7 @@ class StreamingBatch:
             """row buffer `name` of the workspace, allocated on first use"""
             if name not in ws:
                 shape = (self.B * self.N + 8, ws["ld"]) if name == "Ut" else (self.B * self.N + 8,)
-                ws[name] = torch.zeros(shape, dtype=torch.float64, device=self.device)
+                ws[name] = torch.empty(shape, dtype=torch.float64, device=self.device)
             return ws[name]
 
         ws["rows"] = rows
