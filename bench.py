@@ -423,10 +423,10 @@ def main():
         fused = eng._fused_ok()
         tiled = fused and eng.sweep_variant != _lib.GF_SWEEP_COLUMN and eng.Jr == 0 and eng.Jc <= 31
         # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE per the
-        # guide's gfx950 correction; profiles/r02_traffic.json, else r01), scaled to this launch
+        # guide's gfx950 correction; profiles/r03_traffic.json, else earlier rounds), scaled to this launch
         # shape: a constant measured on this kernel, not a counter of this run
         traffic, traffic_src = None, None
-        for name in ("r02_traffic.json", "r01_traffic.json"):
+        for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:
                 tr = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if tr.get("W") == W and fused:
