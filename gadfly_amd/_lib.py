@@ -59,9 +59,12 @@ SIGNATURES = {
     "gf_chunk_linear_combine": (_int, [_int, _int, _i64, _i64, _int, _int, _int] + [_vp] * 5
                                 + [_vp]),
     "gf_dense_solve": (_int, [_int, _int, _int] + [_vp] * 2 + [_vp]),
+    "gf_dense_solve_logdet": (_int, [_int, _int, _int] + [_vp] * 3 + [_vp]),
     "gf_dense_width": (_int, [_int]),
     "gf_wide_combine_work": (_i64, [_int, _int, _int]),
-    "gf_wide_combine": (_int, [_int, _i64, _i64, _int, _int] + [_vp] * 6 + [_vp]),
+    "gf_wide_combine": (_int, [_int, _i64, _i64, _int, _int] + [_vp] * 7 + [_vp]),
+    "gf_chunk_corrections_work": (_i64, [_int, _int]),
+    "gf_chunk_corrections": (_int, [_int, _int, _int, _int] + [_vp] * 6 + [_vp]),
     "gf_wide_gram": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int] + [_vp] * 5 + [_vp]),
     "gf_lft_tree_work": (_i64, [_int, _int, _int]),
     "gf_lft_tree_scan": (_int, [_int, _int, _int] + [_vp] * 8 + [_vp]),

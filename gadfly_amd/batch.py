@@ -73,6 +73,23 @@ def sho_coefficient_pack(S0, w0, Q, delta, eps=1e-5):
     return Jr, Jc, real, comp, diag_add, c
 
 
+class _Pack(tuple):
+    """A coefficient pack of the engine that remembers whether its kernels are positive semi-definite by
+    construction (sums of SHO terms with positive S0, w0, Q, possibly exposure-integrated)."""
+    psd_safe = False
+
+
+def _sho_only(kernel):
+    """True for the kernels gadfly builds: [TermConvolution of] a sum of SHO terms with S0, w0, Q > 0 -- a
+    covariance function, so K + diag(>= 0) is positive semi-definite whatever the hyperparameters."""
+    from .terms import SHOTerm, TermConvolution
+    base = kernel.term if isinstance(kernel, TermConvolution) else kernel
+    terms = getattr(base, "terms", None)
+    if terms is None:
+        terms = (base,)
+    return len(terms) > 0 and all(type(t) is SHOTerm and t.S0 > 0.0 and t.w0 > 0.0 and t.Q > 0.0 for t in terms)
+
+
 class BatchedLogLikelihood:
     """Reusable evaluator: device buffers are allocated once; each :meth:`evaluate` with new
     kernels costs an O(B J) coefficient upload plus the device work."""
@@ -97,6 +114,12 @@ class BatchedLogLikelihood:
         self.engine = StreamingBatch([k.get_device_coefficients() for k in kernels], t,
                                      y - mean, diag=d, tile_rows=tile_rows, device=device,
                                      overlap_build=overlap_build)
+        #: the time-parallel route may drop its final pass (engine.two_sweep) when the matrix is positive
+        #: semi-definite by construction: SHO kernels and a non-negative diagonal.  A non-finite result of such
+        #: an evaluation (rounding can still break a pivot) is repeated with the final pass by :meth:`resolve`
+        self._diag_nonneg = d is None or bool(np.all(np.asarray(d) >= 0.0))
+        self._init_safe = self._diag_nonneg and all(_sho_only(k) for k in kernels)
+        self.two_sweep = True
         #: keep the row generator's share of the relative log-likelihood error below this by
         #: choosing its re-anchoring period from the measured conditioning
         self.generator_target = 1e-9
@@ -112,8 +135,9 @@ class BatchedLogLikelihood:
         return self.engine.B
 
     def pack(self, kernels):
-        return self.engine.pack_coefficients(
-            [k.get_device_coefficients() for k in kernels])
+        pk = _Pack(self.engine.pack_coefficients([k.get_device_coefficients() for k in kernels]))
+        pk.psd_safe = all(_sho_only(k) for k in kernels)
+        return pk
 
     def pack_parameters(self, S0, w0, Q, delta):
         """Coefficient pack straight from (B, J) hyperparameter arrays (:func:`sho_coefficient_pack`):
@@ -122,7 +146,10 @@ class BatchedLogLikelihood:
         eng = self.engine
         if (Jr, Jc) != (eng.Jr, eng.Jc) or real.shape[1] != eng.B:
             raise ValueError("coefficient pack does not match the batch structure")
-        return eng._make_pack(real, comp, diag_add, c)
+        pk = _Pack(eng._make_pack(real, comp, diag_add, c))
+        pk.psd_safe = bool(np.all(np.asarray(S0) > 0.0) and np.all(np.asarray(w0) > 0.0)
+                           and np.all(np.asarray(Q) > 0.0))
+        return pk
 
     def evaluate_device(self, pack=None):
         """Enqueue one evaluation per problem; returns the (B,) device tensor (no host sync).
@@ -140,18 +167,30 @@ class BatchedLogLikelihood:
         eng = self.engine
         if pack is not None:
             eng.use_coefficients(pack)
+            self._safe = self._diag_nonneg and bool(getattr(pack, "psd_safe", False))
+        elif not hasattr(self, "_safe"):
+            self._safe = self._init_safe
+        eng.two_sweep = bool(self.two_sweep and self._safe)
         # small batches of long series are chunked in time as well (exact, see engine.evaluate)
         out = eng.evaluate()[0]
         period = int(eng.generator_period)
         if eng._fused_ok() or eng._wide_ok():
+            torch = eng.torch
             acc = eng.last_acc()
             amax = eng._pack[2] if eng.diag is None else eng._pack[2] + eng._diag_amax
             # min pivot and largest diagonal of THIS evaluation (what calibrate() looks at; the
             # engine's own state may belong to a guard rerun of an older pack by then)
             self._last_cond = (acc[:, 2].clone(), amax)
+            flag = None
             if period > 1:
                 # a non-positive pivot (failed factorisation: -inf either way) is not an accuracy case
                 flag = (eng.GEN_ERR * period * amax > self.generator_target * acc[:, 2]) & (acc[:, 2] > 0)
+            if getattr(eng, "_two_sweep_used", False):
+                # no final pass ran: a pivot that rounding pushed below zero inside a chunk shows up as a
+                # non-finite value (det(I - X G) <= 0) -- repeated with the final pass by resolve()
+                bad = ~torch.isfinite(out)
+                flag = bad if flag is None else (flag | bad)
+            if flag is not None:
                 self._unresolved.append((out, flag, eng._pack, period))
                 if len(self._unresolved) > 64:      # bound the backlog of a caller that never resolves
                     self.resolve()
@@ -168,7 +207,7 @@ class BatchedLogLikelihood:
         pending, self._unresolved = self._unresolved, []
         flags = torch.stack([f for _, f, _, _ in pending]).cpu().numpy()      # the sync
         redone = 0
-        keep_pack, keep_period = eng._pack, eng.generator_period
+        keep_pack, keep_period, keep_two = eng._pack, eng.generator_period, eng.two_sweep
         for (out, flag, pack, _), hit in zip(pending, flags):
             if not hit.any():
                 continue
@@ -176,10 +215,11 @@ class BatchedLogLikelihood:
             # construction-time coefficient list, which the stored-factor classes still need)
             eng._pack = pack
             eng.generator_period = 1
+            eng.two_sweep = False           # the repeat is the reference formulation: exact rows, final pass
             exact = eng.evaluate()[0]
             out.copy_(torch.where(flag, exact, out))
             redone += int(hit.sum())
-        eng._pack, eng.generator_period = keep_pack, keep_period
+        eng._pack, eng.generator_period, eng.two_sweep = keep_pack, keep_period, keep_two
         self.guard_reruns += redone
         return redone
 

@@ -667,6 +667,73 @@ int tree_scan(const TreePlan &T, const Maps &M0, double *Xs0, double *Ys0, doubl
     return gf_internal_check_launch("gf_lft_tree_scan");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Log-likelihood of a chunked series WITHOUT a final pass.  With (X, Y) the true start state of a chunk and
+// (G, m) its Gram sums from the nominal pass (zero start), the chunk's sums over its rows satisfy
+//     sum log d_n     = sum log dbar_n        + log det(I - X G)
+//     sum z_n^2 / d_n = sum zbar_n^2 / dbar_n + e^T G v - 2 m^T e - m^T X m,   e = Y - X m,  v = (I - X G)^-1 e
+// (row by row: d = dbar det(I - Delta u u^T / dbar); the determinants telescope through the closed-loop
+// transitions exactly as the Gram sums do -- verified against the sequential recurrence in 80-bit numpy and
+// by tests/test_gpu_configs.py).  det(I - X G) <= 0 means a non-positive pivot somewhere in the chunk: the
+// correction is then NaN and the caller repeats the evaluation with a final pass.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_corr_finish(const int P, const int first, const int count, const int WP, const double *__restrict__ Y,
+              const double *__restrict__ m, const double *__restrict__ e, const double *__restrict__ u1,
+              const double *__restrict__ ld, double *__restrict__ acc) {
+    const int pr = blockIdx.x, tid = threadIdx.x;
+    __shared__ double red[2][256];
+    double sl = 0.0, sq = 0.0;
+    for (int c = first; c < first + count; ++c) {
+        const size_t mp = (size_t)pr * P + c;
+        for (int i = tid; i < WP; i += 256) {
+            const size_t k = mp * WP + i;
+            sq += e[k] * u1[k] - 2.0 * m[k] * e[k] - m[k] * (Y[k] - e[k]);
+        }
+        if (tid == 0) sl += ld[mp];
+    }
+    red[0][tid] = sl;
+    red[1][tid] = sq;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {         // fixed-shape tree: deterministic
+        if (tid < st) { red[0][tid] += red[0][tid + st]; red[1][tid] += red[1][tid + st]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        acc[3 * pr + 0] += red[0][0];
+        acc[3 * pr + 1] += red[1][0];
+    }
+}
+
+// corrections of the chunks first .. first + count - 1 of every problem, added to acc [B][3] (sum log d,
+// sum z^2 / d, min d: the accumulators of gf_reduce_tile); maps [B * P][WP x WP] / [B * P][WP]; work:
+// n (WP^2 + 18 WP + 1) doubles for n = B P
+size_t corrections_work(size_t n, int WP) { return n * ((size_t)WP * WP + 18 * (size_t)WP + 1); }
+
+int chunk_corrections(int B, int P, int WP, int first, int count, const double *X, const double *Y,
+                      const double *G, const double *m, double *acc, double *work, hipStream_t st) {
+    if (count < 1) return 0;
+    const long long n = (long long)B * P, msz = (long long)WP * WP;
+    double *A = work, *R = A + n * msz, *ev = R + n * WP * 16, *u1 = ev + n * WP, *ld = u1 + n * WP;
+    const long long sR = (long long)WP * 16;
+    {   // A = I - X G ; e = Y - X m (X symmetric: the coalesced mat-vec form), once as the right-hand side
+        JobBuilder jb;
+        jb.gemm(0, 0, EPI_IMINUS, WP, WP, WP, X, WP, msz, G, WP, msz, nullptr, 0, 0, A, WP, msz);
+        jb.matvec(1, WP, WP, -1.0, X, WP, msz, m, 1, WP, Y, WP, R, 16, sR);
+        jb.matvec(1, WP, WP, -1.0, X, WP, msz, m, 1, WP, Y, WP, ev, 1, WP);
+        jb.copy(WP, 15, nullptr, 0, 0, R + 1, 16, sR);
+        jb.launch(n, st);
+    }
+    if (gf_dense_solve_logdet((int)n, WP, 16, A, R, ld, st)) return -1;
+    {   // u1 = G v  (G symmetric)
+        JobBuilder jb;
+        jb.matvec(1, WP, WP, 1.0, G, WP, msz, R, 16, sR, nullptr, 0, u1, 1, WP);
+        jb.launch(n, st);
+    }
+    hipLaunchKernelGGL(k_corr_finish, dim3(B), dim3(256), 0, st, P, first, count, WP, Y, m, ev, u1, ld, acc);
+    return 0;
+}
+
 bool pow2(int x) { return x >= 1 && (x & (x - 1)) == 0; }
 
 template <int NT>
@@ -759,11 +826,29 @@ int64_t gf_wide_combine_work(int B, int nch, int Jc) {
     if (B < 1 || nch < 1 || W <= 63 || WP > 176) return -1;
     const int P = tree_P(nch);
     const size_t n = (size_t)B * P, msz = (size_t)WP * WP;
-    return (int64_t)(n * (3 * msz + 2 * WP) + n * (msz + WP) + TreePlan(B, P, WP).total);
+    const size_t tree = TreePlan(B, P, WP).total, corr = corrections_work(n, WP);
+    return (int64_t)(n * (3 * msz + 2 * WP) + n * (msz + WP) + (tree > corr ? tree : corr));
+}
+
+int64_t gf_chunk_corrections_work(int B, int nch) { return (B < 1 || nch < 1) ? -1 : (int64_t)corrections_work((size_t)B * nch, 64); }
+
+int gf_chunk_corrections(int B, int nch, int chunk_first, int chunk_count, const double *S_state,
+                         const double *F_state, const double *G, const double *m, double *acc, double *work,
+                         void *stream) {
+    if (B < 1 || nch < 1) return gf_internal_error(-1, "gf_chunk_corrections: empty problem (B=%d, nch=%d)", B, nch);
+    if (chunk_first < 0 || chunk_count < 0 || chunk_first + chunk_count > nch)
+        return gf_internal_error(-1, "gf_chunk_corrections: bad chunk range (first=%d, count=%d)", chunk_first, chunk_count);
+    if ((long long)B * nch > 65535) return gf_internal_error(-1, "gf_chunk_corrections: too many chunks (B*nch=%lld)", (long long)B * nch);
+    if (!S_state || !F_state || !G || !m || !acc || !work) return gf_internal_error(-1, "gf_chunk_corrections: null pointer");
+    // the 64 x 64 state slots are stored [column][row]: X and G are symmetric, so they ARE dense row-major maps
+    if (chunk_corrections(B, nch, 64, chunk_first, chunk_count, S_state, F_state, G, m, acc, work, (hipStream_t)stream))
+        return -1;
+    return gf_internal_check_launch("gf_chunk_corrections");
 }
 
 int gf_wide_combine(int B, int64_t N, int64_t chunk_len, int nch, int Jc, const double *h, const double *dbar,
-                    const double *zbar, const double *Phi_state, double *S_state, double *work, void *stream) {
+                    const double *zbar, const double *Phi_state, double *S_state, double *acc, double *work,
+                    void *stream) {
     const int W = 2 * Jc, WP = gf_dense_width(W);
     const int CP = gf_fused_row_stride(0, Jc);
     if (B < 1 || N < 1) return gf_internal_error(-1, "gf_wide_combine: empty problem (N=%lld)", (long long)N);
@@ -781,11 +866,16 @@ int gf_wide_combine(int B, int64_t N, int64_t chunk_len, int nch, int Jc, const 
     double *Xs = M0.m + n * WP, *Ys = Xs + n * msz, *tw = Ys + n * WP;
     hipLaunchKernelGGL(k_lft_pack, dim3((unsigned)n, (unsigned)((WP + 31) / 32)), dim3(256), 0, st, nch, P, W, WP, CP, RP, S_state, Phi_state,
                        M0.Ph, M0.X, M0.Y, M0.G, M0.m);
-    // (the maps of the first and the last chunk are not needed: see k_lft_pack)
-    if (dispatch_gram(WP, B, N, chunk_len, nch, 1, nch - 2, P, CP, h, dbar, zbar, M0.G, M0.m, st))
+    // (the maps of the first and the last chunk are not needed for the start states: see k_lft_pack; with
+    // `acc` the last chunk's Gram sums are: its log-likelihood correction uses them)
+    if (dispatch_gram(WP, B, N, chunk_len, nch, 1, acc ? nch - 1 : nch - 2, P, CP, h, dbar, zbar, M0.G, M0.m, st))
         return gf_internal_error(-1, "gf_wide_combine: internal dispatch error");
     TreePlan T(B, P, WP);
     if (tree_scan(T, M0, Xs, Ys, tw, st)) return -1;
+    if (acc) {      // log-likelihood without a final pass: corrections of the chunks 1 .. nch - 1 (chunk 0 starts from zero)
+        if ((long long)B * P > 65535) return gf_internal_error(-1, "gf_wide_combine: too many chunks for the corrections (B*P=%lld)", (long long)B * P);
+        if (chunk_corrections(B, P, WP, 1, nch - 1, Xs, Ys, M0.G, M0.m, acc, tw, st)) return -1;
+    }
     hipLaunchKernelGGL(k_lft_unpack, dim3((unsigned)(B * nch), 8), dim3(256), 0, st, nch, P, W, WP, CP, RP, Xs, Ys, S_state);
     return gf_internal_check_launch("gf_wide_combine");
 }

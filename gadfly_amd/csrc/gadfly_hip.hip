@@ -3278,6 +3278,7 @@ struct DenseSolveShared {
     double f[2][RS][64];                            // multipliers of step k, buffer k & 1
     double rowpinv[64 * RS];
     int pl[2], rs[2], rowk[64 * RS];
+    int seen[64 * RS];                              // (log-determinant: cycle walk of the row -> pivot map)
 };
 
 // pivot search on column k (values C of this wave's rows) by its owner; publishes into buffer k & 1
@@ -3371,7 +3372,8 @@ __device__ __forceinline__ void ds_phase(DenseSolveShared<RS> &sh, double (&R)[R
 // empty -- every workgroup eliminates its own copy of A, so narrower slices only shorten the step
 template <int RS, int NA, int NR>
 __global__ void __launch_bounds__(64 * DS_WAVES)
-k_dense_solve(const int n, const int nrhs, const double *__restrict__ A_, double *__restrict__ B_) {
+k_dense_solve(const int n, const int nrhs, const double *__restrict__ A_, double *__restrict__ B_,
+              double *__restrict__ logdet_out) {
     constexpr int NS = NA + NR, NT = 64 * DS_WAVES, BC = DS_WAVES * NR;
     const int b = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -3450,6 +3452,47 @@ k_dense_solve(const int n, const int nrhs, const double *__restrict__ A_, double
             if (row0 + rr < n && cc < ncol) Bb[(size_t)(row0 + rr) * nrhs + cc] = sh.tile[rr * DS_LDT + cc];
         }
         __syncthreads();
+    }
+    // log det A = sum over the pivots of log |pivot|, when det A > 0 (sign of the pivots' product times the
+    // parity of the row -> pivot-step permutation); NaN otherwise (det <= 0, a row never chosen, not finite)
+    if (logdet_out != nullptr && sl == 0 && wave == 0) {
+        double acc = 0.0;
+        int neg = 0;
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const int row = 64 * r + lane;
+            if (row < n) {
+                const double pinv = sh.rowpinv[row];
+                const int kk = sh.rowk[row];
+                bad = bad || kk < 0 || kk >= n || !(fabs(pinv) > 0.0) || !(fabs(pinv) < 1.79e308);
+                acc -= log(fabs(pinv));
+                neg += (pinv < 0.0) ? 1 : 0;
+            }
+            sh.seen[row] = 0;
+        }
+        acc = wave_sum(acc);
+        neg = (int)__popcll(__ballot(neg & 1));     // parity of the number of negative pivots
+        const bool anybad = __ballot(bad) != 0ull;
+        wave_lds_fence();
+        if (lane == 0) {
+            int swaps = 0, steps = 0;
+            bool ok = !anybad;
+            for (int s0 = 0; ok && s0 < n; ++s0) {      // cycles of row -> rowk[row]; every walk is bounded by n
+                if (sh.seen[s0]) continue;
+                int j = s0, len = 0;
+                do {
+                    sh.seen[j] = 1;
+                    j = sh.rowk[j];
+                    ++len;
+                    ++steps;
+                } while (j != s0 && j >= 0 && j < n && !sh.seen[j] && steps <= n);
+                ok = ok && j == s0;                 // (anything else: not a permutation)
+                swaps += len - 1;
+            }
+            const bool positive = ok && (((neg + swaps) & 1) == 0) && (acc == acc);
+            logdet_out[b] = positive ? acc : __longlong_as_double(0x7ff8000000000000LL);
+        }
     }
 }
 
@@ -5232,7 +5275,7 @@ int gf_chunk_linear_combine_seg(int mode, int B, int nch, int seg_len, int R, co
     return check_launch("gf_chunk_linear_combine_seg");
 }
 
-int gf_dense_solve(int batch, int n, int nrhs, const double *A, double *B, void *stream) {
+int gf_dense_solve_logdet(int batch, int n, int nrhs, const double *A, double *B, double *logdet_out, void *stream) {
     if (batch < 1 || n < 1 || nrhs < 1) return set_err("gf_dense_solve: empty problem (n=%s%lld, nrhs=%lld)", "", n, nrhs);
     if (n > 192) return set_err("gf_dense_solve: n=%s%lld unsupported (max %lld)", "", n, 192);
     if (!A || !B) return set_err("gf_dense_solve: null pointer%s", "");
@@ -5242,8 +5285,8 @@ int gf_dense_solve(int batch, int n, int nrhs, const double *A, double *B, void 
     const bool narrow = (long long)batch * slices4 <= 64;
     const int per = DS_WAVES * (narrow ? 1 : 4);
     const dim3 grid(batch, (nrhs + per - 1) / per);
-#define GF_DS(RSv, NAv) do { if (narrow) hipLaunchKernelGGL((k_dense_solve<RSv, NAv, 1>), grid, dim3(64 * DS_WAVES), 0, st, n, nrhs, A, B); \
-                             else hipLaunchKernelGGL((k_dense_solve<RSv, NAv, 4>), grid, dim3(64 * DS_WAVES), 0, st, n, nrhs, A, B); } while (0)
+#define GF_DS(RSv, NAv) do { if (narrow) hipLaunchKernelGGL((k_dense_solve<RSv, NAv, 1>), grid, dim3(64 * DS_WAVES), 0, st, n, nrhs, A, B, logdet_out); \
+                             else hipLaunchKernelGGL((k_dense_solve<RSv, NAv, 4>), grid, dim3(64 * DS_WAVES), 0, st, n, nrhs, A, B, logdet_out); } while (0)
     if (n <= 64) GF_DS(1, 4);
     else if (n <= 96) GF_DS(2, 6);
     else if (n <= 128) GF_DS(2, 8);
@@ -5251,6 +5294,10 @@ int gf_dense_solve(int batch, int n, int nrhs, const double *A, double *B, void 
     else GF_DS(3, 12);
 #undef GF_DS
     return check_launch("gf_dense_solve");
+}
+
+int gf_dense_solve(int batch, int n, int nrhs, const double *A, double *B, void *stream) {
+    return gf_dense_solve_logdet(batch, n, nrhs, A, B, nullptr, stream);
 }
 
 int64_t gf_reduce_work(int64_t N) { return RED_NACC * (int64_t)red_groups(N); }

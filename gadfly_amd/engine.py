@@ -776,6 +776,11 @@ class StreamingBatch:
         # 16, which reaches 1e-8 there), 1 = exact generation every row (float64-class accuracy,
         # 15 % slower)
         self.generator_period = 4
+        # time-parallel log-likelihood WITHOUT a final pass (nominal sums + per-chunk corrections from the
+        # start states: gf_chunk_corrections / gf_wide_combine(acc)); off by default -- the rows d, z then hold
+        # the NOMINAL values and a non-positive pivot shows up as NaN, which the caller must resolve with a
+        # final pass (BatchedLogLikelihood does, for kernels that are positive semi-definite by construction)
+        self.two_sweep = False
         T = int(min(max(int(tile_rows), 1), self.N))
         if T < self.N:
             T = max(64, T // 64 * 64)         # tiles start on a reset row (any block <= 64)
@@ -924,6 +929,7 @@ class StreamingBatch:
         self.F_state.zero_()
         self.info.zero_()
         self._tp_used, self._last_wide_tp = False, False     # (whose `acc` the last evaluation filled)
+        self._two_sweep_used = False
         if self._fused_ok() or self._wide_ok():
             return self._log_likelihood_fused(main)
         if self.bufs is None:
@@ -1021,8 +1027,9 @@ class StreamingBatch:
             # B * nch ~ 2048 waves = 2 per SIMD, the occupancy the sweep kernels are built for
             # (measured optimum for B = 1 ... 128 at N = 2.6e5 ... 1e6, W = 60: DESIGN.md 4.3);
             # below ~512 rows per chunk the extra tree levels cost more than the sweeps save
-            # (+ 1: the last chunk sits out the nominal pass, the first one the final pass)
-            nch = max(1, 2048 // B) + 1
+            # (+ 1: the last chunk sits out the nominal pass, the first one the final pass; the two-sweep
+            # log-likelihood sweeps all chunks in its nominal pass)
+            nch = max(1, 2048 // B) + (0 if self.two_sweep else 1)
             chunk_len = max(512, -(-N // nch))
         chunk_len = max(block, (int(chunk_len) + 63) // 64 * 64)
         return chunk_len, -(-N // chunk_len)
@@ -1076,6 +1083,8 @@ class StreamingBatch:
                                          p(w["r"]), p(Ut), p(w[phi]), p(w["G"]), p(w["m"]), st)
             _lib.check(rc, "gf_chunk_transition")
 
+        if self.two_sweep and not store and nch > 1 and B * nch <= 65535:
+            return self._tp_two_sweep(w, chunk_len, nch, opts, coeffs, tyd, transition, st)
         # chunk 0 starts from the zero state: its nominal pass IS its final pass (not when the factor is
         # stored: the final pass also writes the w~ rows)
         skip_first = nch > 1 and not store
@@ -1121,7 +1130,43 @@ class StreamingBatch:
         out = torch.empty((B,), **f64)
         rc = lib.gf_loglike_finish(B, N, p(w["acc"]), p(self.info), p(out), None, st)
         _lib.check(rc, "gf_loglike_finish")
-        self._tp_used, self._last_wide_tp = True, False
+        self._tp_used, self._last_wide_tp, self._two_sweep_used = True, False, False
+        return out, chunk_len, nch
+
+    def _tp_two_sweep(self, w, chunk_len, nch, opts, coeffs, tyd, transition, st):
+        """Log-likelihood from TWO sweeps: the nominal pass over all chunks (its rows reduced as they are), the
+        transition sweep of the chunks 1 ... nch - 1, the combine for the start states, and per chunk the
+        corrections  log det(I - X G)  and  e^T G v - 2 m^T e - m^T X m  (gf_chunk_corrections) -- no final pass."""
+        torch = self.torch
+        lib, p = self.lib, _lib.ptr
+        N, B = self.N, self.B
+        real, comp, diag_add, _, cmax, block, _ = self._pack
+        rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, 0, nch, self.Jr, self.Jc, block, *opts, *coeffs,
+                                p(diag_add), p(cmax), *tyd, p(w["d"]), p(w["z"]), p(w["r"]),
+                                p(w["Un"]), None, p(w["den"]), p(w["S"]), p(w["F"]), p(w["info"]), st)
+        _lib.check(rc, "gf_chunk_sweep")
+        rc = lib.gf_reduce_tile(B, N, p(w["d"]), p(w["z"]), p(w["work"]), p(w["acc"]), 1, st)
+        _lib.check(rc, "gf_reduce_tile")
+        transition(1, nch - 1, w["Un"], w["den"])
+        for k, n in (("Phi", 4096), ("G", 4096), ("m", 64)):
+            w[k].view(B, nch, n)[:, 0].zero_()
+        self._tp_combine(w, nch, st)
+        if "corr" not in w:
+            w["corr"] = torch.empty((int(lib.gf_chunk_corrections_work(B, nch)),), dtype=torch.float64,
+                                    device=self.device)
+        rc = lib.gf_chunk_corrections(B, nch, 1, nch - 1, p(w["S"]), p(w["F"]), p(w["G"]), p(w["m"]),
+                                      p(w["acc"]), p(w["corr"]), st)
+        _lib.check(rc, "gf_chunk_corrections")
+        # a chunk of the nominal pass that failed: the first such row (exact for chunk 0; later chunks start
+        # from zero, where pivots are never smaller than the true ones: the caller's final pass decides)
+        ci = w["info"].view(B, nch)
+        big = torch.iinfo(torch.int32).max
+        first = torch.where(ci > 0, ci, torch.full_like(ci, big)).min(dim=1).values
+        self.info.copy_(torch.where(first == big, torch.zeros_like(first), first))
+        out = torch.empty((B,), dtype=torch.float64, device=self.device)
+        rc = lib.gf_loglike_finish(B, N, p(w["acc"]), p(self.info), p(out), None, st)
+        _lib.check(rc, "gf_loglike_finish")
+        self._tp_used, self._last_wide_tp, self._two_sweep_used = True, False, True
         return out, chunk_len, nch
 
     #: chunk counts above this use the log-depth tree combine (2 log2 P levels of ~0.13 ms)
@@ -1261,6 +1306,29 @@ class StreamingBatch:
         S.zero_()
         cinfo.zero_()
         ci = cinfo.view(B, nch)
+        if self.two_sweep and stores is None and nch > 1:
+            # log-likelihood from TWO sweeps: nominal pass over all chunks (its rows reduced as they are),
+            # transitions of the chunks 1 ... nch - 1, the combine with the per-chunk corrections added to the
+            # accumulators (gf_wide_combine with acc) -- no final pass
+            acc = ws["acc"]
+            sweep(0, nch, dbar, zbar, p(rbar), (p(Ut), None, p(de)))
+            _lib.check(lib.gf_reduce_tile(B, N, p(dbar), p(zbar), p(ws["red"]), p(acc), 1, st), "gf_reduce_tile")
+            rc = lib.gf_chunk_transition_wide(B, N, L, nch, 1, nch - 1, self.Jc, p(c), p(de), p(dbar),
+                                              p(rbar), p(Ut), p(h), p(Phi), st)
+            _lib.check(rc, "gf_chunk_transition_wide")
+            rc = lib.gf_wide_combine(B, N, L, nch, self.Jc, p(h), p(dbar), p(zbar), p(Phi), p(S), p(acc),
+                                     p(ws["work"]), st)
+            _lib.check(rc, "gf_wide_combine")
+            big = torch.iinfo(torch.int32).max
+            first = torch.where(ci > 0, ci, torch.full_like(ci, big)).min(dim=1).values
+            self.info.copy_(torch.where(first == big, torch.zeros_like(first), first))
+            out = torch.empty((B,), dtype=torch.float64, device=self.device)
+            logdet = torch.empty_like(out)
+            _lib.check(lib.gf_loglike_finish(B, N, p(acc), p(self.info), p(out), p(logdet), st),
+                       "gf_loglike_finish")
+            self._wide_tp = dict(d=dbar, z=zbar, acc=acc, chunk_len=L, nch=nch)
+            self._last_wide_tp, self._tp_used, self._two_sweep_used = True, False, True
+            return out, logdet, L, nch
         skip_first = nch > 1 and stores is None     # chunk 0 starts from zero: its nominal pass IS its final pass
         ci0 = None
         if nch > 1:
@@ -1273,7 +1341,7 @@ class StreamingBatch:
                                               p(rbar), p(Ut), p(h), p(Phi), st)
             _lib.check(rc, "gf_chunk_transition_wide")
             # 3. chunk maps (Phi, G, Xbar, Ybar, m) and their tree combine: S <- true start states
-            rc = lib.gf_wide_combine(B, N, L, nch, self.Jc, p(h), p(dbar), p(zbar), p(Phi), p(S),
+            rc = lib.gf_wide_combine(B, N, L, nch, self.Jc, p(h), p(dbar), p(zbar), p(Phi), p(S), None,
                                      p(ws["work"]), st)
             _lib.check(rc, "gf_wide_combine")
             ci0 = ci[:, 0].clone()      # (a nominal pass can only fail at or after the true failing row: the
@@ -1305,7 +1373,7 @@ class StreamingBatch:
         _lib.check(lib.gf_loglike_finish(B, N, p(acc), p(self.info), p(out), p(logdet), st),
                    "gf_loglike_finish")
         self._wide_tp = dict(d=dd, z=zz, acc=acc, chunk_len=L, nch=nch)
-        self._last_wide_tp, self._tp_used = True, False
+        self._last_wide_tp, self._tp_used, self._two_sweep_used = True, False, False
         return out, logdet, L, nch
 
     @_on_device

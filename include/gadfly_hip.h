@@ -291,6 +291,10 @@ int gf_chunk_linear_combine_seg(int mode, int B, int nch, int seg_len, int R, co
  * is sequential: celerite2.driver.factor, /root/reference/gadfly/gp.py:202).
  */
 int gf_dense_solve(int batch, int n, int nrhs, const double *A, double *B, void *stream);
+/* The same solve, with logdet_out [batch] <- log det A where det A > 0 (sum of log |pivot|; the sign from the
+ * pivots' signs and the parity of the row permutation), NaN where det A <= 0 or A is singular / not finite. */
+int gf_dense_solve_logdet(int batch, int n, int nrhs, const double *A, double *B, double *logdet_out,
+                          void *stream);
 
 /*
  * The dense combine of the time-parallel factorisation of a WIDE kernel (64 <= W <= 176), all of it in
@@ -325,7 +329,25 @@ int gf_dense_width(int W);
 int64_t gf_wide_combine_work(int B, int nch, int Jc);
 int gf_wide_combine(int B, int64_t N, int64_t chunk_len, int nch, int Jc,
                     const double *h, const double *dbar, const double *zbar,
-                    const double *Phi_state, double *S_state, double *work, void *stream);
+                    const double *Phi_state, double *S_state, double *acc, double *work, void *stream);
+/*
+ * Log-likelihood of a chunked series WITHOUT a final pass ("two sweeps").  With (X, Y) the true start state of
+ * a chunk and (G, m) its Gram sums from the nominal pass,
+ *     sum log d_n     = sum log dbar_n        + log det(I - X G)
+ *     sum z_n^2 / d_n = sum zbar_n^2 / dbar_n + e^T G v - 2 m^T e - m^T X m,  e = Y - X m,  v = (I - X G)^-1 e,
+ * so the caller reduces the NOMINAL rows (gf_reduce_tile on dbar, zbar of all chunks) and adds these
+ * corrections: acc [B][3] (gf_reduce_tile's accumulators) += the sums over the chunks chunk_first ..
+ * chunk_first + chunk_count - 1.  The nominal pass and the Gram sums must then cover the LAST chunk too
+ * (gf_wide_combine with acc != NULL takes the Gram sums of chunks 1 .. nch - 1; pass NULL for the start
+ * states alone).  det(I - X G) <= 0 -- a non-positive pivot inside the chunk -- makes the correction NaN:
+ * the caller repeats such an evaluation with a final pass (which also names the failing row).
+ * gf_chunk_corrections: the W <= 63 route (state slots [B*nch][64*64] / [B*nch][64] after gf_chunk_combine[_tree]);
+ * work: gf_chunk_corrections_work(B, nch) doubles; B * nch <= 65535.
+ */
+int64_t gf_chunk_corrections_work(int B, int nch);
+int gf_chunk_corrections(int B, int nch, int chunk_first, int chunk_count, const double *S_state,
+                         const double *F_state, const double *G, const double *m, double *acc, double *work,
+                         void *stream);
 int gf_wide_gram(int B, int64_t N, int64_t chunk_len, int nch, int chunk_first, int chunk_count, int P, int Jc,
                  const double *h, const double *dbar, const double *zbar,
                  double *G_out, double *m_out, void *stream);

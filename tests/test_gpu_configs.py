@@ -168,6 +168,81 @@ def test_cfg4_shape_time_parallel_every_entry(hip, N, L):
     assert np.max(np.abs(llb[ok] - ll[ok]) / np.abs(ll[ok])) <= 1e-10
 
 
+@pytest.mark.parametrize("shape", ["cfg3", "cfg4"])
+def test_two_sweep_log_likelihood(hip, shape):
+    """Time-parallel log-likelihood WITHOUT a final pass (engine.two_sweep): nominal sums + per-chunk corrections
+    log det(I - X G) and e^T G v - 2 m^T e - m^T X m from the start states.  Every entry against the oracle at
+    1e-8 and against the three-sweep evaluation of the same engine at 1e-11, at cfg3's shape (W = 40, own t / y /
+    yerr per problem, sequential and tree combine) and cfg4's (W = 80, the dense combine)."""
+    import gadfly_amd
+    from gadfly_amd.engine import StreamingBatch
+    B = 9
+    if shape == "cfg3":
+        N = 2600
+        kernels, t, y, yerr = _cfg3_problem(B, N)
+        diag = yerr ** 2
+        chunkings = (256, 64)               # 11 chunks: sequential combine; 41 chunks: tree combine
+    else:
+        N = 3000
+        kernels, t, y = _cfg4_problem(B, N)
+        diag = np.full(N, 900.0)
+        chunkings = (256, 640)
+    eng = StreamingBatch([k.get_device_coefficients() for k in kernels], t, y, diag=diag)
+    eng.generator_period = 1
+    refs = [_ref_ll(k, t[i] if shape == "cfg3" else t, diag[i] if shape == "cfg3" else diag,
+                    y[i] if shape == "cfg3" else y) for i, k in enumerate(kernels)]
+    for L in chunkings:
+        eng.two_sweep = False
+        ll3 = eng.log_likelihood_time_parallel(chunk_len=L).cpu().numpy()
+        assert not eng._two_sweep_used
+        eng.two_sweep = True
+        ll2 = eng.log_likelihood_time_parallel(chunk_len=L).cpu().numpy()
+        assert eng._two_sweep_used
+        for i, ref in enumerate(refs):
+            assert abs(ll2[i] - ref) <= RTOL_LL * abs(ref), (shape, L, i, ll2[i], ref)
+            assert abs(ll2[i] - ll3[i]) <= 1e-11 * abs(ref), (shape, L, i, ll2[i], ll3[i])
+    # a matrix that is not positive definite: the two-sweep value is not finite (never a wrong finite number
+    # here: the nominal pass meets the negative diagonal itself), and BatchedLogLikelihood does not take the
+    # route at all for a negative diagonal
+    bad = np.array(np.broadcast_to(diag, (B, N)))
+    bad[4, N // 2:] = -2.0 * kernels[4].get_value(np.zeros(1))[0]
+    engb = StreamingBatch([k.get_device_coefficients() for k in kernels], t, y, diag=bad)
+    engb.generator_period, engb.two_sweep = 1, True
+    llb = engb.log_likelihood_time_parallel(chunk_len=chunkings[0]).cpu().numpy()
+    assert not np.isfinite(llb[4]) and np.all(np.isfinite(np.delete(llb, 4)))
+    ev = gadfly_amd.BatchedLogLikelihood(kernels, t, y, diag=bad)
+    ev.engine.wide_tp_min_rows = 1024
+    got = ev.evaluate()
+    assert not ev.engine.two_sweep and got[4] == -np.inf and int(ev.engine.info[4]) == N // 2 + 1
+
+
+def test_two_sweep_is_the_batched_default_and_resolves_broken_pivots(hip):
+    """BatchedLogLikelihood takes the two-sweep route for SHO kernels with a non-negative diagonal; an entry
+    whose value comes out non-finite is repeated with the final pass by resolve()."""
+    import gadfly_amd
+    B, N = 6, 20_000
+    kernels, t, y = _cfg4_problem(B, N)
+    ev = gadfly_amd.BatchedLogLikelihood(kernels, t, y, yerr=30.0)
+    ll = ev.evaluate()
+    eng = ev.engine
+    assert eng.two_sweep and eng._two_sweep_used and eng._last_wide_tp
+    for i in (0, B - 1):
+        ref = _ref_ll(kernels[i], t, np.full(N, 900.0), y)
+        assert abs(ll[i] - ref) <= RTOL_LL * abs(ref)
+    # poison one entry as a broken two-sweep evaluation would leave it: resolve() must repair exactly that one
+    out = ev.evaluate_device()
+    keep = out.clone()
+    out[2] = float("nan")
+    ev._unresolved[-1] = (out,) + (ev._unresolved[-1][1] | ~out.isfinite(),) + ev._unresolved[-1][2:] \
+        if ev._unresolved else None
+    if not ev._unresolved or ev._unresolved[-1] is None:
+        ev._unresolved = [(out, ~out.isfinite(), eng._pack, int(eng.generator_period))]
+    assert ev.resolve() >= 1
+    got = out.cpu().numpy()
+    assert np.all(np.isfinite(got)) and abs(got[2] - keep.cpu().numpy()[2]) <= 1e-10 * abs(got[2])
+    assert eng.two_sweep                                # the setting survives the repair
+
+
 def test_evaluate_picks_the_wide_time_parallel_route(hip):
     """ONE long series with a wide kernel through evaluate() / BatchedLogLikelihood (no route argument):
     the exact time-parallel evaluation must be the route taken, and the condition estimate afterwards

@@ -182,3 +182,33 @@ def test_wide_gram(hip, B, J, N, L):
             assert np.abs(g[:W, :W] - Gr).max() <= 1e-12 * np.abs(Gr).max() * L
             assert np.abs(m[b * P + c, :W] - mr).max() <= 1e-12 * np.abs(mr).max() * L
             assert np.array_equal(g, g.T) and not g[W:].any() and not m[b * P + c, W:].any()
+
+
+@pytest.mark.parametrize("n", [5, 64, 80, 172, 176])
+def test_dense_solve_logdet(hip, n):
+    """gf_dense_solve_logdet: log det A where det A > 0 (pivots' signs x parity of the row permutation), NaN
+    where det A <= 0 or A is singular; the solution itself as gf_dense_solve."""
+    import torch
+    lib, p = hip.load(), hip.ptr
+    rng = np.random.default_rng(n)
+    batch, nrhs = 12, 16
+    A = np.eye(n) + 0.4 * rng.normal(size=(batch, n, n)) / np.sqrt(n)
+    A[1] = np.eye(n)[rng.permutation(n)] + 0.05 * rng.normal(size=(n, n))     # row exchanges: parity matters
+    A[2, :, 0] *= -1.0                                                          # flips the sign of det
+    A[3] = 0.0                                                                  # singular
+    A[4, :, 3] = np.nan
+    B = rng.normal(size=(batch, n, nrhs))
+    Ad, Bd = torch.as_tensor(A).cuda(), torch.as_tensor(B).cuda()
+    ld = torch.full((batch,), 123.0, dtype=torch.float64, device="cuda")
+    hip.check(lib.gf_dense_solve_logdet(batch, n, nrhs, p(Ad), p(Bd), p(ld), None), "gf_dense_solve_logdet")
+    got, X = ld.cpu().numpy(), Bd.cpu().numpy()
+    for b in range(batch):
+        if b in (3, 4):
+            assert np.isnan(got[b]), b
+            continue
+        sign, ref = np.linalg.slogdet(A[b])
+        if sign > 0:
+            assert abs(got[b] - ref) <= 1e-10 * max(1.0, abs(ref)), (b, got[b], ref)
+        else:
+            assert np.isnan(got[b]), (b, sign, got[b])
+        assert np.abs(X[b] - np.linalg.solve(A[b], B[b])).max() <= 1e-9 * np.abs(X[b]).max()
