@@ -179,12 +179,16 @@ class BatchedLogLikelihood:
             acc = eng.last_acc()
             amax = eng._pack[2] if eng.diag is None else eng._pack[2] + eng._diag_amax
             # min pivot and largest diagonal of THIS evaluation (what calibrate() looks at; the
-            # engine's own state may belong to a guard rerun of an older pack by then)
-            self._last_cond = (acc[:, 2].clone(), amax)
+            # engine's own state may belong to a guard rerun of an older pack by then); a two-sweep
+            # evaluation has the nominal pass' pivots only: margin (engine.TWO_SWEEP_MARGIN)
+            dmin = acc[:, 2].clone()
+            if getattr(eng, "_two_sweep_used", False):
+                dmin = dmin / eng.TWO_SWEEP_MARGIN
+            self._last_cond = (dmin, amax)
             flag = None
             if period > 1:
                 # a non-positive pivot (failed factorisation: -inf either way) is not an accuracy case
-                flag = (eng.GEN_ERR * period * amax > self.generator_target * acc[:, 2]) & (acc[:, 2] > 0)
+                flag = (eng.GEN_ERR * period * amax > self.generator_target * dmin) & (dmin > 0)
             if getattr(eng, "_two_sweep_used", False):
                 # no final pass ran: a pivot that rounding pushed below zero inside a chunk shows up as a
                 # non-finite value (det(I - X G) <= 0) -- repeated with the final pass by resolve()

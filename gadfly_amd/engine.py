@@ -846,10 +846,17 @@ class StreamingBatch:
             return self._wide_tp["acc"]
         return self._tp["acc"] if getattr(self, "_tp_used", False) else self.acc
 
+    #: a two-sweep evaluation knows the pivots of its NOMINAL pass only (every chunk from a zero start: never
+    #: smaller than the true ones, and within a few per cent of them a few dozen rows into a chunk): its
+    #: condition estimates are scaled by this margin
+    TWO_SWEEP_MARGIN = 1.5
+
     def condition_estimate(self):
         """max(a) / min(d) over all problems of the LAST evaluation (synchronises): the factor by
         which rounding in the generator rows shows up in the log-likelihood."""
         dmin = float(self.last_acc()[:, 2].min().item())
+        if getattr(self, "_two_sweep_used", False):
+            dmin /= self.TWO_SWEEP_MARGIN
         amax = float(self._pack[2].max().item())
         if self.diag is not None:
             amax += float(self.diag.max().item())

@@ -128,6 +128,7 @@ def test_generator_calibration(hip):
     y = np.random.default_rng(1).normal(size=len(t)) * 80.0
     ev = gadfly_amd.BatchedLogLikelihood([k, k], t, y, yerr=30.0)
     assert ev.engine.generator_period == 4                  # until something has been measured
+    ev.two_sweep = False                                    # (an evaluation with a final pass: the true pivots)
     ev.evaluate()
     co = k.get_device_coefficients()
     c, a, U, V = seq.celerite_matrices(co[:6], t, np.full(len(t), 900.0) + co[6])
@@ -135,6 +136,13 @@ def test_generator_calibration(hip):
     cond_ref = float(a.max() / d_ref.min())
     assert abs(ev.engine.condition_estimate() - cond_ref) <= 1e-6 * cond_ref
     assert ev.engine.generator_period == 64 and cond_ref < 1e3
+    # the two-sweep evaluation (the batched default) sees the nominal pass' pivots only -- never smaller than
+    # the true ones -- and scales its estimate by a margin: not below the true condition, at most 1.5 x above
+    ev.two_sweep = True
+    ev.evaluate()
+    assert ev.engine._two_sweep_used
+    est = ev.engine.condition_estimate()
+    assert cond_ref <= est <= 1.5 * cond_ref * (1 + 1e-12) and ev.engine.generator_period == 64
 
     prob = _problem(1127)
     co = prob["kernel"].get_device_coefficients()
