@@ -2644,7 +2644,7 @@ __global__ void __launch_bounds__(64) k_lin1(const LinArgs A) {
     double *__restrict__ Fg = A.F_state + (size_t)b * 64;
     const double cj = (lane < A.W) ? A.c[(size_t)pr * A.W + lane] : 0.0;
     const bool up = A.mode == GF_SOLVE_UPPER, mm = A.mode == GF_MATMUL_LOWER;
-    double F = Fg[lane];
+    double F = A.store ? Fg[lane] : 0.0;            // (the local pass starts from zero)
     // Rows are fetched LIN1_AHEAD rows ahead of their use, LIN1_AHEAD at a time (the loads used to sit at
     // their point of use: one memory round trip per row, 1.1 us -- the sweep itself is a DPP reduction and
     // two FMAs per row).
@@ -2745,7 +2745,7 @@ __global__ void __launch_bounds__(64) k_linR(const LinArgs A) {
     __shared__ double s_a[64], s_b[64], s_e[64];
     double F[ROWS];
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) F[i] = rok ? Fg[(size_t)i * R + r] : 0.0;
+    for (int i = 0; i < ROWS; ++i) F[i] = (rok && A.store) ? Fg[(size_t)i * R + r] : 0.0;
     double carry = 0.0;
     s_a[lane] = 0.0;                                // pending push row (w~_{n-1} or u~_{n+1})
     double de_cross = -1.0;
@@ -2854,8 +2854,8 @@ __global__ void __launch_bounds__(64, 2) k_linR7(const LinArgs A) {
 #pragma unroll
     for (int m2 = 0; m2 < ROWS / 2; ++m2) {
         const int i = 4 * (m2 >> 1) + 2 * g + (m2 & 1);
-        T[m2][0] = (r0 < R) ? Fg[(size_t)i * R + r0] : 0.0;
-        T[m2][1] = (r0 + 1 < R) ? Fg[(size_t)i * R + r0 + 1] : 0.0;
+        T[m2][0] = (r0 < R && A.store) ? Fg[(size_t)i * R + r0] : 0.0;
+        T[m2][1] = (r0 + 1 < R && A.store) ? Fg[(size_t)i * R + r0 + 1] : 0.0;
     }
     double q0 = 0.0, q1 = 0.0, carry = 0.0;
     s_a[lane] = 0.0;                                // pending push row (w~_{n-1} or u~_{n+1})
@@ -2953,10 +2953,11 @@ __global__ void __launch_bounds__(64, 2) k_linR7(const LinArgs A) {
 // slice at their point of use.  Taking the operands from global in their MFMA layout instead cost more than
 // the MFMAs: a lane-per-row pattern is 64 separate sectors per load instruction (the texture addresser
 // serialises them), and a masked load in a branch of its own gets its own s_waitcnt (30 round trips per block).
-template <int MT, bool NODOT>
-__global__ void __launch_bounds__(64, 1) k_mmR_mfma(const LinArgs A) {
-    constexpr int KS = 4 * MT, T = 4, LDT = 66;
-    const int lane = threadIdx.x, i = lane & 15, k = lane >> 4;
+template <int MT, bool NODOT, int NWV>
+__global__ void __launch_bounds__(64 * NWV, (NWV == 1 && !NODOT) ? 1 : 2) k_mmR_mfma(const LinArgs A) {
+    constexpr int KS = 4 * MT, T = 2, LDT = 66, NQ = 8 / NWV;
+    const int lane = threadIdx.x & 63, i = lane & 15, k = lane >> 4;
+    const int wv = (NWV > 1) ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
     const int b = blockIdx.x, rt = blockIdx.y;
     const int pr = b / A.nch, ch = b - pr * A.nch;
     const int R = A.R;
@@ -2970,14 +2971,16 @@ __global__ void __launch_bounds__(64, 1) k_mmR_mfma(const LinArgs A) {
     const double *__restrict__ Yg = A.Y + pb * R;
     double *__restrict__ Zg = A.Z + pb * R;
     double *__restrict__ Fg = A.F_state + (size_t)b * 64 * R;      // [state][R]
-    __shared__ double s_c[64];                      // decay rates (read at reset rows only; 0 beyond W)
-    __shared__ __attribute__((aligned(16))) double s_u[NODOT ? 2 : 16 * LDT], s_w[16 * LDT];
-    s_c[lane] = (lane < A.W) ? A.c[(size_t)pr * A.W + lane] : 0.0;
+    __shared__ double s_e[NWV][64];                 // decays of the states at a reset row
+    const double c_lane = (lane < A.W) ? A.c[(size_t)pr * A.W + lane] : 0.0;
+    // the block's rows, two buffers: a wave that runs ahead stashes block n + 1 while its partner still
+    // reads block n (one barrier per block)
+    __shared__ __attribute__((aligned(16))) double s_u[NODOT ? 2 : 2 * 16 * LDT], s_w[2 * 16 * LDT];
     int rhs[T], rhc[T];                             // (rhc: clamped, loads are unconditional; masks come after)
     bool rok[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        rhs[t] = rt * 16 * T + 16 * t + i; rok[t] = rhs[t] < R; rhc[t] = rok[t] ? rhs[t] : R - 1;
+        rhs[t] = (rt * NWV + wv) * 16 * T + 16 * t + i; rok[t] = rhs[t] < R; rhc[t] = rok[t] ? rhs[t] : R - 1;
     }
     d4 F[T][MT];                                    // F[t][mt][r] = state 16 mt + k + 4 r, rhs[t]
 #pragma unroll
@@ -2985,33 +2988,34 @@ __global__ void __launch_bounds__(64, 1) k_mmR_mfma(const LinArgs A) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                F[t][mt][r] = Fg[(size_t)(16 * mt + k + 4 * r) * R + rhc[t]];
+            for (int r = 0; r < 4; ++r)     // (the local pass starts from zero)
+                F[t][mt][r] = NODOT ? 0.0 : Fg[(size_t)(16 * mt + k + 4 * r) * R + rhc[t]];
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) F[t][mt][r] = rok[t] ? F[t][mt][r] : 0.0;
-    // one block of inputs, as loaded (rows clamped to the chunk; no branch around any load)
-    double pux[NODOT ? 1 : 8], puy[NODOT ? 1 : 8], pwx[8], pwy[8];
-    double e_raw, yraw[T][4], draw[4];
+    // one block of inputs, as loaded (rows clamped to the chunk; no branch around any load); the waves of
+    // the workgroup share the copy of the u~ / w~ rows (row 2 NWV q + 2 wv + (lane >> 5) of the tile)
+    double pux[NODOT ? 1 : NQ], puy[NODOT ? 1 : NQ], pwx[NQ], pwy[NQ];
+    double e_raw, d_raw, yraw[T][4];
 #define GF_MM_FETCH(N0)                                                                             \
     do {                                                                                            \
         const int f_n0 = (N0);                                                                      \
         const int f_lim = (rows - f_n0 < 16) ? rows - f_n0 : 16;                                    \
         e_raw = eg[f_n0 + ((lane < f_lim) ? lane : f_lim - 1)];                                     \
+        d_raw = dg[f_n0 + (((lane & 15) < f_lim) ? (lane & 15) : f_lim - 1)];                       \
         _Pragma("unroll")                                                                           \
         for (int s4 = 0; s4 < 4; ++s4) {                                                            \
             const int f_row = 4 * s4 + k;                                                           \
             const size_t f_n = (size_t)(f_n0 + ((f_row < f_lim) ? f_row : f_lim - 1));              \
-            draw[s4] = dg[f_n];                                                                     \
             _Pragma("unroll")                                                                       \
             for (int t = 0; t < T; ++t) yraw[t][s4] = Yg[f_n * R + rhc[t]];                         \
         }                                                                                           \
         _Pragma("unroll")                                                                           \
-        for (int q = 0; q < 8; ++q) {   /* flat copy: element 2 lane + 128 q of the 16 x 64 tile */ \
-            const int f_row = 2 * q + (lane >> 5);                                                  \
+        for (int q = 0; q < NQ; ++q) {  /* flat copy: 16-byte pieces of the 16 x 64 tile */         \
+            const int f_row = 2 * NWV * q + 2 * wv + (lane >> 5);                                   \
             const size_t f_off = (size_t)(f_n0 + ((f_row < f_lim) ? f_row : f_lim - 1)) * 64 + 2 * (lane & 31); \
             const double2 f_w = *reinterpret_cast<const double2 *>(Wg + f_off);                     \
             pwx[q] = f_w.x; pwy[q] = f_w.y;                                                         \
@@ -3022,50 +3026,54 @@ __global__ void __launch_bounds__(64, 1) k_mmR_mfma(const LinArgs A) {
         }                                                                                           \
     } while (0)
     GF_MM_FETCH(0);
-    for (int n0 = 0; n0 < rows;) {
+    int buf = 0;
+    for (int n0 = 0; n0 < rows; buf ^= 1) {
         const int lim = (rows - n0 < 16) ? rows - n0 : 16;
-        wave_lds_fence();                           // (the previous block's operand reads are done)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int at = (2 * q + (lane >> 5)) * LDT + 2 * (lane & 31);
-            *reinterpret_cast<double2 *>(&s_w[at]) = double2{pwx[q], pwy[q]};
-            if constexpr (!NODOT) *reinterpret_cast<double2 *>(&s_u[at]) = double2{pux[q], puy[q]};
-        }
+        const double *su = s_u + (NODOT ? 0 : buf * 16 * LDT), *sw = s_w + buf * 16 * LDT;
+        if (NWV == 1) wave_lds_fence();             // (the block before the previous one has been read)
         // the block: rows n0 .. n0 + cnt - 1, cut at the first reset row after n0
         const double e_l = (lane < lim) ? e_raw : -1.0;
         const unsigned long long inner = __ballot(e_l >= 0.0 && lane >= 1);
         const int cnt = inner ? (int)__ffsll((long long)inner) - 1 : lim;
         const double de0 = read_lane(e_l, 0);
-        const bool rowA = i < cnt;                  // this lane's row as an A operand (row n0 + i)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {              // (rows past the cut enter the tile as zeros: no operand masks)
+            const int row = 2 * NWV * q + 2 * wv + (lane >> 5);
+            const int at = buf * 16 * LDT + row * LDT + 2 * (lane & 31);
+            const bool in = row < cnt;
+            *reinterpret_cast<double2 *>(&s_w[at]) = double2{in ? pwx[q] : 0.0, in ? pwy[q] : 0.0};
+            if constexpr (!NODOT) *reinterpret_cast<double2 *>(&s_u[at]) = double2{in ? pux[q] : 0.0, in ? puy[q] : 0.0};
+        }
         double yv[T][4];                            // rows n0 + 4 s + k (B operand of slice s; C rows of Z_b)
         bool okK[4];
+        const double sq = A.scale ? sqrt(d_raw) : 1.0;      // lane l: sqrt(d) of row n0 + (l & 15)
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             okK[s4] = 4 * s4 + k < cnt;
-            const double sc = A.scale ? sqrt(draw[s4]) : 1.0;
+            const double sc = A.scale ? __shfl(sq, 4 * s4 + k) : 1.0;
 #pragma unroll
             for (int t = 0; t < T; ++t) yv[t][s4] = (okK[s4] && rok[t]) ? yraw[t][s4] * sc : 0.0;
         }
-        wave_lds_fence();
+        if (NWV == 1) wave_lds_fence(); else wg_lds_barrier();
         // the next block's loads fly under this block's MFMAs (past the chunk's end: the last row again,
         // never used -- an unconditional fetch keeps the staging registers out of scratch)
         GF_MM_FETCH((n0 + cnt < rows) ? n0 + cnt : rows - 1);
         if (de0 >= 0.0) {
-            // reset row: F <- E o F before the block's products -- as diag(E) F on the matrix pipe too (a
-            // vector multiply would pull the 128 accumulator registers of F into the vector file at every
-            // reset: the allocator then keeps them there and spills the rest)
+            // reset row: F <- E o F before the block's products.  Lane l forms the decay of state l, the
+            // lanes pick theirs (state 16 mt + k + 4 r) up from LDS: one exponential and 8 T multiplies per
+            // lane.  (As diag(E) F on the matrix pipe -- the form this kernel had while F lived in accumulator
+            // registers -- the decay cost 16 T MFMAs per reset: half the local pass when every 16-row block
+            // starts on one, as with the solar-like kernels at one-minute cadence.)
+            s_e[wv][lane] = fm_exp(-c_lane * de0);
+            wave_lds_fence();
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const double e = fm_exp(-s_c[16 * mt + i] * de0);
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    d4 Fn = {0.0, 0.0, 0.0, 0.0};
+                for (int r = 0; r < 4; ++r) {
+                    const double e = s_e[wv][16 * mt + k + 4 * r];
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4)      // A[i][4 s + k] = E_i [i == 4 s + k]
-                        Fn = GF_MFMA64((i == 4 * s4 + k) ? e : 0.0, F[t][mt][s4], Fn);
-                    F[t][mt] = Fn;
+                    for (int t = 0; t < T; ++t) F[t][mt][r] *= e;
                 }
-            }
         }
         if constexpr (!NODOT) {
             d4 G = {0.0, 0.0, 0.0, 0.0};            // G^T = W_b U_b^T: lane (i, k) gets u~_i . w~_{k + 4 r}
@@ -3074,8 +3082,7 @@ __global__ void __launch_bounds__(64, 1) k_mmR_mfma(const LinArgs A) {
             for (int t = 0; t < T; ++t) Z[t] = d4{yv[t][0], yv[t][1], yv[t][2], yv[t][3]};
 #pragma unroll
             for (int s = 0; s < KS; ++s) {          // u~, w~[n0 + i][4 s + k]
-                const double uv = s_u[i * LDT + 4 * s + k], wv = s_w[i * LDT + 4 * s + k];
-                const double ua = rowA ? uv : 0.0, wa = rowA ? wv : 0.0;
+                const double ua = su[i * LDT + 4 * s + k], wa = sw[i * LDT + 4 * s + k];
                 G = GF_MFMA64(wa, ua, G);
 #pragma unroll
                 for (int t = 0; t < T; ++t) Z[t] = GF_MFMA64(ua, F[t][s >> 2][s & 3], Z[t]);
@@ -3098,8 +3105,7 @@ __global__ void __launch_bounds__(64, 1) k_mmR_mfma(const LinArgs A) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {        // w~[n0 + 4 s + k][16 mt + i]
-                const double wv = s_w[(4 * s4 + k) * LDT + 16 * mt + i];
-                const double wt = okK[s4] ? wv : 0.0;
+                const double wt = sw[(4 * s4 + k) * LDT + 16 * mt + i];
 #pragma unroll
                 for (int t = 0; t < T; ++t) F[t][mt] = GF_MFMA64(wt, yv[t][s4], F[t][mt]);
             }
@@ -5212,13 +5218,17 @@ int gf_chunk_linear(int mode, int B, int64_t N, int64_t chunk_len, int nch, int 
         hipLaunchKernelGGL(k_lin1, dim3(B * nch), dim3(64), 0, st, A);
     } else if (mode == GF_MATMUL_LOWER && R >= 16) {
         // no feedback in this mode: blocks of 16 rows as matrix products (k_mmR_mfma)
-        const dim3 grid(B * nch, (R + 63) / 64);
-#define GF_MM_CASE(MTv) case MTv: if (store) hipLaunchKernelGGL((k_mmR_mfma<MTv, false>), grid, dim3(64), 0, st, A); \
-                                  else hipLaunchKernelGGL((k_mmR_mfma<MTv, true>), grid, dim3(64), 0, st, A); break;
+        // two waves per workgroup share the block's rows (32 right-hand sides each); one when R <= 32
+        const int nwv = (R > 32) ? 2 : 1;
+        const dim3 grid(B * nch, (R + 32 * nwv - 1) / (32 * nwv));
+#define GF_MM_LAUNCH(MTv, ND, NWVv) hipLaunchKernelGGL((k_mmR_mfma<MTv, ND, NWVv>), grid, dim3(64 * NWVv), 0, st, A)
+#define GF_MM_CASE(MTv) case MTv: if (store) { if (nwv == 2) GF_MM_LAUNCH(MTv, false, 2); else GF_MM_LAUNCH(MTv, false, 1); } \
+                                  else { if (nwv == 2) GF_MM_LAUNCH(MTv, true, 2); else GF_MM_LAUNCH(MTv, true, 1); } break;
         switch ((W + 15) / 16) {
             GF_MM_CASE(1) GF_MM_CASE(2) GF_MM_CASE(3) GF_MM_CASE(4)
             default: return set_err("gf_chunk_linear: internal dispatch error%s", "");
         }
+#undef GF_MM_LAUNCH
 #undef GF_MM_CASE
     } else {
         const int rows = (W + 3) / 4 * 4;

@@ -353,7 +353,10 @@ class ScaledFactor:
             # chunking: cut the series finer than the factorisation did (two waves per SIMD; the chunks
             # of the factor leave half the SIMDs without a wave when there is one RHS tile)
             chunk_len, nch = self._mm_chunking(R)
-        F = torch.zeros((B * nch, 64 * R), **f64)
+        # (every local pass starts from zero by itself, but only dot_tril's diagonal combine keeps the state
+        # rows apart: the solves' combine multiplies the padding rows >= W, which no pass writes, by zeros)
+        lazy = nch > 1 and mode == _lib.GF_MATMUL_LOWER
+        F = (torch.empty if lazy else torch.zeros)((B * nch, 64 * R), **f64)
         st = torch.cuda.current_stream(self.device).cuda_stream
         args = (mode, B, N, chunk_len, nch, self.W, R)
         rows = (p(self.c), p(self.Ut), p(self.Wt), p(self.d), p(self.de))

@@ -252,8 +252,8 @@ int gf_chunk_combine_tree(int B, int P, double *Phi, double *G, double *m, doubl
 
 /*
  * Triangular sweeps on the stored scaled factor, time-parallel (same modes as gf_solve):
- *   gf_chunk_linear(store=0)   local pass: every chunk from F_state (zeroed by the caller),
- *                              leaves its end state there; nothing else is written.
+ *   gf_chunk_linear(store=0)   local pass: every chunk from a ZERO state (F_state need not be
+ *                              initialised), leaves its end state there; nothing else is written.
  *   gf_chunk_linear_combine    F_state slot c <- true start state of chunk c.  GF_SOLVE_LOWER /
  *                              GF_SOLVE_UPPER need Phi [B*nch][64*64], the chunk transitions of the
  *                              TRUE factor (gf_chunk_transition run on the final pass' d, z, r
