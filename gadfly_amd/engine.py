@@ -333,7 +333,7 @@ class ScaledFactor:
         self.t = owner.t
         self.info = owner.info
         self._v1 = None
-        self._D = None
+        self._D, self._D_key = None, None
         self._Psi = None
 
     @_on_device
@@ -363,8 +363,10 @@ class ScaledFactor:
         if nch > 1:
             rc = lib.gf_chunk_linear(*args, int(scale), 0, *rows, p(Y), p(Z), p(F), st)
             _lib.check(rc, "gf_chunk_linear")
-            if mode == _lib.GF_MATMUL_LOWER and (self._D is None or self._D.shape[0] != B * nch):
-                self._D = torch.empty((B * nch, 64), **f64)
+            fresh_D = False
+            if mode == _lib.GF_MATMUL_LOWER and (self._D is None or self._D_key != (chunk_len, nch)):
+                # the chunks' diagonal transitions belong to the factor and this chunking: formed once
+                self._D, self._D_key, fresh_D = torch.empty((B * nch, 64), **f64), (chunk_len, nch), True
             seg = self._segments() if mode != _lib.GF_MATMUL_LOWER else None
             if seg is not None:         # long series: two-level combine on the composed transitions
                 seg_len, Psi = seg
@@ -372,6 +374,8 @@ class ScaledFactor:
                 rc = lib.gf_chunk_linear_combine_seg(mode, B, nch, seg_len, R, p(self.Phi), p(Psi),
                                                      p(F), p(V), st)
                 _lib.check(rc, "gf_chunk_linear_combine_seg")
+            elif mode == _lib.GF_MATMUL_LOWER and not fresh_D:
+                _lib.check(lib.gf_chunk_diag_scan(B, nch, 64, R, p(self._D), p(F), st), "gf_chunk_diag_scan")
             else:
                 rc = lib.gf_chunk_linear_combine(
                     *args, p(self.c), p(self.de),

@@ -18,7 +18,10 @@ kernels = [gadfly_amd.StellarOscillatorKernel(hp, texp=texp) for hp in hps]
 ev = gadfly_amd.BatchedLogLikelihood(kernels, t, y, yerr=yerr)
 ev.evaluate()
 eng = ev.engine
-print("period", eng.generator_period)
+# two sweeps (nominal pass over all chunks + transitions of chunks 1 ... nch - 1) as
+# BatchedLogLikelihood runs it, or TWO_SWEEP=0: three sweeps with the final pass
+eng.two_sweep = os.environ.get("TWO_SWEEP", "1") != "0"
+print("period", eng.generator_period, "two_sweep", eng.two_sweep)
 for L in [int(a) for a in sys.argv[1:]]:
     for rep in range(3):
         torch.cuda.synchronize()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Reduce a rocprofv3 --pmc counter_collection CSV to per-row averages of one kernel.
-Usage: python tools/pmc_rows.py <counter_collection.csv> <kernel substring> <rows*evals>"""
+Usage: python tools/pmc_rows.py <counter_collection.csv> <kernel substring> <rows x problems swept by ONE launch>"""
 import csv
 import sys
 from collections import defaultdict
@@ -13,4 +13,4 @@ with open(path) as fh:
             tot[row["Counter_Name"]] += float(row["Counter_Value"])
             calls[row["Counter_Name"]] += 1
 for k in sorted(tot):
-    print(f"{k:28s} total {tot[k]:.4g}  launches {calls[k]}  per row and evaluation {tot[k] / work:10.3f}")
+    print(f"{k:28s} total {tot[k]:.4g}  launches {calls[k]}  per row and problem {tot[k] / (work * calls[k]):10.3f}")

@@ -34,14 +34,16 @@ bench)
   f=$(pmc fetch FETCH_SIZE $BA); g=$(pmc write WRITE_SIZE $BA)
   python3 $R/tools/pmc_traffic.py $f $g k_factor7 8192 2048 60 $O/r03_traffic.json
   rm -f $O/r03_sq_k_factor7.txt
-  sq $O/r03_sq_k_factor7.txt k_factor7 $((131072*2048)) $BA
+  sq $O/r03_sq_k_factor7.txt k_factor7 $((8192*2048)) $BA
   ;;
 cfg3)
   echo "== cfg3"; prof cfg3 tools/configs.py cfg3
   rm -f $O/r03_sq_cfg3_factor7.txt $O/r03_sq_cfg3_phi7.txt
-  sq $O/r03_sq_cfg3_factor7.txt "k_factor7<40" $((65000*256)) tools/cfg3_chunks.py 7232
-  sq $O/r03_sq_cfg3_phi7.txt "k_phi7<40" $((65000*256)) tools/cfg3_chunks.py 7232
-  f=$(pmc fetch FETCH_SIZE tools/cfg3_chunks.py 7232); g=$(pmc write WRITE_SIZE tools/cfg3_chunks.py 7232)
+  # two sweeps at 8 chunks of 8128 rows (what bench.py's cfg3 leg runs): the nominal pass sweeps every row,
+  # the transition sweep the chunks 1 ... 7
+  sq $O/r03_sq_cfg3_factor7.txt "k_factor7<40" $((65000*256)) tools/cfg3_chunks.py 8128
+  sq $O/r03_sq_cfg3_phi7.txt "k_phi7<40" $(((65000-8128)*256)) tools/cfg3_chunks.py 8128
+  f=$(pmc fetch FETCH_SIZE tools/cfg3_chunks.py 8128); g=$(pmc write WRITE_SIZE tools/cfg3_chunks.py 8128)
   python3 $R/tools/pmc_bytes.py $f $g $O/r03_cfg3_traffic.json "k_factor7<40, true" "k_factor7<40, false" "k_phi7<40" k_combine
   ;;
 cfg4s)
@@ -50,7 +52,7 @@ cfg4s)
 cfg5)
   echo "== cfg5"; prof cfg5 tools/configs.py cfg5
   f=$(pmc fetch FETCH_SIZE tools/configs.py cfg5); g=$(pmc write WRITE_SIZE tools/configs.py cfg5)
-  python3 $R/tools/pmc_bytes.py $f $g $O/r03_cfg5_traffic.json "k_mmR_mfma<4, true" "k_mmR_mfma<4, false" k_lincombine_mm k_chunk_decay
+  python3 $R/tools/pmc_bytes.py $f $g $O/r03_cfg5_traffic.json "k_mmR_mfma<4, true" "k_mmR_mfma<4, false" k_lincombine_mm
   ;;
 solar)
   echo "== solar"; prof solar tools/solar_latency.py 100000
