@@ -24,6 +24,7 @@ ev.engine.force_streaming = os.environ.get("ROUTE", "stream") == "stream"     # 
 if os.environ.get("CHUNK_LEN"):                 # time-parallel route with a given chunk length
     ev.engine.force_streaming = False
     ev.engine.wide_tp_min_rows = 0
+    ev.engine._wide_tp_ok = lambda: True        # (whatever the batch size)
     _len = int(os.environ["CHUNK_LEN"])
     ev.engine._wide_chunking = (lambda chunk_len, _orig=ev.engine._wide_chunking: _orig(_len))
 ev.engine.generator_period = int(os.environ.get("GEN_PERIOD", "64"))
