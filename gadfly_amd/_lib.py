@@ -20,6 +20,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "gadfly_hip.h")
 
 GF_SOLVE_LOWER, GF_SOLVE_UPPER, GF_MATMUL_LOWER = 0, 1, 2
 GF_SWEEP_AUTO, GF_SWEEP_COLUMN, GF_SWEEP_TILED = 0, 1, 2
+GF_SWEEP_ZERO_START = 0x100
 GF_MAX_WIDTH = 256
 
 _lib = None

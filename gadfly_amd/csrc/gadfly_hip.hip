@@ -827,7 +827,7 @@ struct RowGen {
         jthr = read_lane(2e-6 / wmax, 0);
         jthr1 = read_lane(1.4e-9 / wmax, 0);
         block = block_sub & 0xff;           // (block <= 64) | (sub-anchor period << 8)
-        sub_mask = (block_sub >> 8) - 1;
+        sub_mask = ((block_sub >> 8) & 0xff) - 1;  // (bit 30: zero start, see the sweeps)
         cu = 1.0; su = 0.0; irho2 = 1.0; Er = 1.0; Ei = 0.0; G2 = 1.0; dt_ref = -1.0; dt_last = -2.0;
         // reference time of the block that precedes the first row (for its decay); tg points
         // at the first row, earlier rows are at negative indices
@@ -1015,8 +1015,9 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     const double not63 = fl ? 0.0 : 1.0, is63 = fl ? 1.0 : 0.0;
 
     double T[ROWS];
+    const bool zero_start = (block_sub >> 30) & 1;  // nominal pass: the state slots are outputs only
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) T[i] = fl ? Fg[i] : Sg[i];
+    for (int i = 0; i < ROWS; ++i) T[i] = zero_start ? 0.0 : (fl ? Fg[i] : Sg[i]);
     double q = 0.0;
     int32_t fail = 0;
 
@@ -1094,6 +1095,10 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     for (int i = 0; i < ROWS; ++i) {
         const double v = fma(s_w[i], q, T[i]);
         if (fl) Fg[i] = v; else Sg[i] = v;
+    }
+    if (zero_start) {                               // the slot is an output only: its padding rows too,
+        for (int i = ROWS; i < 64; ++i) { if (fl) Fg[i] = 0.0; else Sg[i] = 0.0; }
+        if (fl) for (int i = 0; i < 64; ++i) Sg[i] = 0.0;          // and S's own column 63 (lane 63 carries F~)
     }
 }
 
@@ -1256,10 +1261,11 @@ k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     double *__restrict__ col0 = Sg + (size_t)(2 * c) * 64 + 2 * g;
     double *__restrict__ col1 = (f31 ? Fg : Sg + (size_t)(2 * c + 1) * 64) + 2 * g;
     double T[ROWS / 2][2];
+    const bool zero_start = (block_sub >> 30) & 1;  // nominal pass: the state slots are outputs only
 #pragma unroll
     for (int m = 0; m < ROWS / 2; ++m) {
-        T[m][0] = col0[4 * (m >> 1) + (m & 1)];
-        T[m][1] = col1[4 * (m >> 1) + (m & 1)];
+        T[m][0] = zero_start ? 0.0 : col0[4 * (m >> 1) + (m & 1)];
+        T[m][1] = zero_start ? 0.0 : col1[4 * (m >> 1) + (m & 1)];
     }
     double q0 = 0.0, q1 = 0.0;
     int32_t fail = 0;
@@ -1341,6 +1347,14 @@ k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
         const double w = s_w[2 * g + 4 * (m >> 1) + (m & 1)];
         col0[4 * (m >> 1) + (m & 1)] = fma(w, q0, T[m][0]);
         col1[4 * (m >> 1) + (m & 1)] = fma(w, q1, T[m][1]);
+    }
+    if (zero_start) {                               // the slot is an output only: its padding rows too
+        for (int m = ROWS / 2; m < 32; ++m) {
+            col0[4 * (m >> 1) + (m & 1)] = 0.0;
+            col1[4 * (m >> 1) + (m & 1)] = 0.0;
+        }
+        if (f31)                                    // S's own column 63 (these lanes' second column is F~)
+            for (int m = 0; m < 32; ++m) Sg[63 * 64 + 2 * g + 4 * (m >> 1) + (m & 1)] = 0.0;
     }
 }
 
@@ -1851,10 +1865,11 @@ k_factorw(const FactorWArgs A,
     double *__restrict__ col0 = Sg + (size_t)(2 * cb) * RP + 2 * g;
     double *__restrict__ col1 = col0 + RP;
     double T[TR][2];
+    const bool zero_start = (A.block_sub >> 30) & 1;        // nominal pass: the state slots are outputs only
 #pragma unroll
     for (int m = 0; m < TR; ++m) {
-        T[m][0] = col0[8 * (m >> 1) + (m & 1)];
-        T[m][1] = col1[8 * (m >> 1) + (m & 1)];
+        T[m][0] = zero_start ? 0.0 : col0[8 * (m >> 1) + (m & 1)];
+        T[m][1] = zero_start ? 0.0 : col1[8 * (m >> 1) + (m & 1)];
     }
     double q0 = 0.0, q1 = 0.0;
     sh.w[0][own] = 0.0;
@@ -4954,7 +4969,7 @@ static bool sweep_tiled(int variant, int Jr, int Jc) {
     return variant != GF_SWEEP_COLUMN && Jr == 0 && Jc <= 31;
 }
 
-#define GF_F3_ARGS dim3(B * chunk_count), dim3(64), 0, st, N, n_first, chunk_len, nch, chunk_first, chunk_count, Jr, Jc, (block | (gen_period << 8)), gap, ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out, Ut_out, Wt_out, de_out, S_state, F_state, info
+#define GF_F3_ARGS dim3(B * chunk_count), dim3(64), 0, st, N, n_first, chunk_len, nch, chunk_first, chunk_count, Jr, Jc, (block | (gen_period << 8) | zero_start), gap, ar, cr, ac, bc, cc, dc, diag_add, cmax, t, t_bs, diag, diag_bs, y, y_bs, d, z, r_out, Ut_out, Wt_out, de_out, S_state, F_state, info
 #define GF_F3_CASE(R) case R: if (tiled && rowstore) hipLaunchKernelGGL((k_factor7<R, true>), GF_F3_ARGS); else if (tiled) hipLaunchKernelGGL((k_factor7<R, false>), GF_F3_ARGS); else hipLaunchKernelGGL((k_factor3<R>), GF_F3_ARGS); break;
 
 static int check_sweep_options(const char *who, int gen_period, int variant, int Jr, int Jc) {
@@ -4994,6 +5009,8 @@ static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int6
         return set_err("%s: bad chunk range (first=%lld, count=%lld)", who, chunk_first, chunk_count);
     if (!t || !y || !d || !z || !S_state || (!F_state && W <= 63) || !info || !diag_add || !cmax)
         return set_err("%s: null pointer", who);
+    const int zero_start = (variant & GF_SWEEP_ZERO_START) ? (1 << 30) : 0;
+    variant &= ~GF_SWEEP_ZERO_START;
     if (check_sweep_options(who, gen_period, W > 63 ? GF_SWEEP_AUTO : variant, Jr, Jc)) return -1;
     if (chunk_count == 0) return 0;
     const bool tiled = sweep_tiled(variant, Jr, Jc);
@@ -5002,7 +5019,7 @@ static int fused_launch(const char *who, int B, int64_t N, int64_t n_first, int6
     if (W > 63) {                       // wide kernels: one workgroup per (problem, chunk), k_factorw
         FactorWArgs A;
         A.N = N; A.n_first = n_first; A.chunk_len = chunk_len; A.nch = nch; A.ch0 = chunk_first; A.nsel = chunk_count; A.Jc = Jc;
-        A.block_sub = block | (gen_period << 8); A.gap = gap;
+        A.block_sub = block | (gen_period << 8) | zero_start; A.gap = gap;
         A.t_bs = t_bs; A.diag_bs = diag_bs; A.y_bs = y_bs;
         FactorWPtrs P;
         P.ac = ac; P.bc = bc; P.cc = cc; P.dc = dc; P.diag_add = diag_add; P.cmax = cmax;

@@ -1084,7 +1084,9 @@ class StreamingBatch:
             # (log_likelihood of another y) refills "Phi" with the NOMINAL pass' transitions
             w["PhiT"] = torch.empty((B * nch, 4096), **f64)
         st = torch.cuda.current_stream(self.device).cuda_stream
-        w["S"].zero_(); w["F"].zero_(); w["info"].zero_()
+        w["info"].zero_()
+        # nominal passes start every chunk from zero by themselves: the state slots are outputs only
+        zopts = (opts[0], opts[1] | _lib.GF_SWEEP_ZERO_START)
         coeffs = (p(real[0]), p(real[1]), p(comp[0]), p(comp[1]), p(comp[2]), p(comp[3]))
         tyd = (p(self.t), self._bs(self.t), p(self.diag),
                0 if self.diag is None else self._bs(self.diag), p(self.y), self._bs(self.y))
@@ -1098,7 +1100,7 @@ class StreamingBatch:
             _lib.check(rc, "gf_chunk_transition")
 
         if self.two_sweep and not store and nch > 1 and B * nch <= 65535:
-            return self._tp_two_sweep(w, chunk_len, nch, opts, coeffs, tyd, transition, st)
+            return self._tp_two_sweep(w, chunk_len, nch, zopts, coeffs, tyd, transition, st)
         # chunk 0 starts from the zero state: its nominal pass IS its final pass (not when the factor is
         # stored: the final pass also writes the w~ rows)
         skip_first = nch > 1 and not store
@@ -1106,10 +1108,12 @@ class StreamingBatch:
         if nch > 1:
             # nominal pass (u~ rows and reset spans stored for the transition sweep).  Nothing of the LAST
             # chunk's map is ever needed: it is left out
-            rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, 0, nch - 1, self.Jr, self.Jc, block, *opts, *coeffs,
+            rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, 0, nch - 1, self.Jr, self.Jc, block, *zopts, *coeffs,
                                     p(diag_add), p(cmax), *tyd, p(w["d"]), p(w["z"]), p(w["r"]),
                                     p(w["Un"]), None, p(w["den"]), p(w["S"]), p(w["F"]), p(w["info"]), st)
             _lib.check(rc, "gf_chunk_sweep")
+            w["S"].view(B, nch, -1)[:, nch - 1].zero_()
+            w["F"].view(B, nch, -1)[:, nch - 1].zero_()
             # transitions and Gram sums of the chunks 1 .. nch - 2; from a zero start state the first chunk's
             # map acts through its end state alone (Phi = G = m = 0 for the combine), the last one's not at all
             transition(1, nch - 2, w["Un"], w["den"])
@@ -1125,7 +1129,8 @@ class StreamingBatch:
             w["info"].zero_()
         stores = (p(w["Ut"]), p(w["Wt"]), p(w["de"])) if store else none3
         f0 = 1 if skip_first else 0         # (chunk 0's d, z rows stay where the nominal pass wrote them)
-        rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, f0, nch - f0, self.Jr, self.Jc, block, *opts, *coeffs,
+        rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, f0, nch - f0, self.Jr, self.Jc, block,
+                                *(zopts if nch == 1 else opts), *coeffs,
                                 p(diag_add), p(cmax), *tyd, p(w["d"]), p(w["z"]),
                                 p(w["r"]) if (store and nch > 1) else None, *stores,
                                 p(w["S"]), p(w["F"]), p(w["info"]), st)
@@ -1311,13 +1316,14 @@ class StreamingBatch:
         tyd = (p(self.t), self._bs(self.t), p(self.diag),
                0 if self.diag is None else self._bs(self.diag), p(self.y), self._bs(self.y))
 
-        def sweep(first, count, dd, zz, r_out, st_rows):
-            rc = lib.gf_chunk_sweep(B, N, L, nch, first, count, self.Jr, self.Jc, block, *opts, *coeffs,
-                                    p(diag_add), p(cmax), *tyd, p(dd), p(zz), r_out, *st_rows,
+        def sweep(first, count, dd, zz, r_out, st_rows, zero_start=False):
+            # (zero_start: a nominal pass -- the state slots are outputs only, nothing has to be cleared)
+            variant = opts[1] | (_lib.GF_SWEEP_ZERO_START if zero_start else 0)
+            rc = lib.gf_chunk_sweep(B, N, L, nch, first, count, self.Jr, self.Jc, block, opts[0], variant,
+                                    *coeffs, p(diag_add), p(cmax), *tyd, p(dd), p(zz), r_out, *st_rows,
                                     p(S), None, p(cinfo), st)
             _lib.check(rc, "gf_chunk_sweep")
 
-        S.zero_()
         cinfo.zero_()
         ci = cinfo.view(B, nch)
         if self.two_sweep and stores is None and nch > 1:
@@ -1325,7 +1331,7 @@ class StreamingBatch:
             # transitions of the chunks 1 ... nch - 1, the combine with the per-chunk corrections added to the
             # accumulators (gf_wide_combine with acc) -- no final pass
             acc = ws["acc"]
-            sweep(0, nch, dbar, zbar, p(rbar), (p(Ut), None, p(de)))
+            sweep(0, nch, dbar, zbar, p(rbar), (p(Ut), None, p(de)), zero_start=True)
             _lib.check(lib.gf_reduce_tile(B, N, p(dbar), p(zbar), p(ws["red"]), p(acc), 1, st), "gf_reduce_tile")
             rc = lib.gf_chunk_transition_wide(B, N, L, nch, 1, nch - 1, self.Jc, p(c), p(de), p(dbar),
                                               p(rbar), p(Ut), p(h), p(Phi), st)
@@ -1348,7 +1354,8 @@ class StreamingBatch:
         if nch > 1:
             # 1. nominal pass: zero start states; d-bar, z-bar, r-bar, u~ rows, reset spans.  Nothing of the LAST
             #    chunk's map is ever needed (gf_wide_combine): it is left out
-            sweep(0, nch - 1, dbar, zbar, p(rbar), (p(Ut), None, p(de)))
+            sweep(0, nch - 1, dbar, zbar, p(rbar), (p(Ut), None, p(de)), zero_start=True)
+            S.view(B, nch, -1)[:, nch - 1].zero_()
             # 2. closed-loop transitions and the rows h (not for the first chunk either: from a zero start
             #    state its map acts through its end state alone)
             rc = lib.gf_chunk_transition_wide(B, N, L, nch, 1, nch - 2, self.Jc, p(c), p(de), p(dbar),
@@ -1369,7 +1376,7 @@ class StreamingBatch:
             zz[:B * N].view(B, N)[:, :L0] = zbar[:B * N].view(B, N)[:, :L0]
         f0 = 1 if skip_first else 0
         sweep(f0, nch - f0, dd, zz, p(rbar) if keep else None,     # (the TRUE factor's r rows replace the nominal ones)
-              (p(Ut), p(Wt), p(de)) if stores is not None else (None, None, None))
+              (p(Ut), p(Wt), p(de)) if stores is not None else (None, None, None), zero_start=nch == 1)
         if skip_first:
             ci[:, 0] = ci0
         self._wide_tp_bufs = dict(r=rbar, h=h, Phi=Phi) if keep else None

@@ -52,6 +52,9 @@ extern "C" {
 #define GF_SWEEP_AUTO    0      /* lane-tiled sweep where the term structure allows it, else by column */
 #define GF_SWEEP_COLUMN  1      /* k_factor3 / k_phi: one state column per lane, any mix of terms */
 #define GF_SWEEP_TILED   2      /* k_factor7 / k_phi7: 2 x 32 lane tiling; needs Jr = 0, Jc <= 31 */
+/* OR-ed into gf_chunk_sweep's `variant`: every chunk of the call starts from a ZERO state (a nominal pass);
+ * the S_state / F_state slots are then outputs only and need not be initialised. */
+#define GF_SWEEP_ZERO_START 0x100
 
 int gf_version(void);
 const char *gf_last_error(void);
@@ -175,8 +178,9 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
  * Exact time-parallel evaluation of ONE long series (or a few): the N rows are cut into nch
  * chunks of chunk_len rows (a multiple of `block`; the last chunk may be shorter) that are swept
  * concurrently, then stitched with an exact linear-fractional combine:
- *   1. gf_chunk_sweep      nominal pass: S_state/F_state [B*nch] zeroed by the caller; every chunk
- *                          starts from the zero state; outputs dbar, zbar [B][N], rbar [B][N][64]
+ *   1. gf_chunk_sweep      nominal pass: every chunk starts from the zero state -- S_state/F_state
+ *                          [B*nch] zeroed by the caller, or variant | GF_SWEEP_ZERO_START (the slots
+ *                          are then outputs only); outputs dbar, zbar [B][N], rbar [B][N][64]
  *                          (pass r_out), the rows u~ [B][N][64] and reset spans de [B][N] (pass Ut_out,
  *                          de_out; Wt_out may stay NULL) and the nominal end states in S_state/F_state.
  *   2. gf_chunk_transition closed-loop transition Phi [B*nch][64*64] and the Gram sums G [B*nch][64*64],
