@@ -461,6 +461,32 @@ def test_time_parallel_batch_of_two(hip):
         assert abs(ll[i] - ref) <= RTOL_LL * abs(ref)
 
 
+@pytest.mark.parametrize("J,variant,two_sweep", [(20, "tiled", False), (20, "tiled", True), (6, "column", True),
+                                                 (40, "wide", False), (40, "wide", True)])
+def test_nominal_passes_need_no_cleared_state(hip, J, variant, two_sweep):
+    """GF_SWEEP_ZERO_START: the nominal pass writes its state slots without reading them, so the engine no
+    longer clears them -- slots (and their padding rows) poisoned with NaN between two evaluations must not
+    change a bit of the result, on both fused kernels, the wide kernel, with and without the final pass."""
+    import torch
+    from gadfly_amd.engine import StreamingBatch
+    from oracle import cref
+    prob = util.solar_problem(J, 3000)
+    co = prob["kernel"].get_device_coefficients()
+    eng = StreamingBatch([co, co], prob["t"], prob["y"], diag=prob["diag_user"])
+    if variant != "wide":
+        eng.sweep_variant = hip.GF_SWEEP_TILED if variant == "tiled" else hip.GF_SWEEP_COLUMN
+    eng.two_sweep = two_sweep
+    first = eng.log_likelihood_time_parallel(chunk_len=256).clone()
+    ws = eng._wide_ws_cache if variant == "wide" else eng._tp
+    for name in ("S", "F"):
+        if name in ws:
+            ws[name].fill_(float("nan"))
+    again = eng.log_likelihood_time_parallel(chunk_len=256)
+    assert torch.equal(first, again)
+    ref, _ = cref.loglike(co[:6], prob["t"], prob["diag_user"] + co[6], prob["y"])
+    assert abs(float(again[1]) - ref) <= RTOL_LL * abs(ref)
+
+
 TREE_CASES = [
     ("solar", dict(J=30, N=5000), 512, 1),       # 10 chunks -> P = 16 (identity padding)
     ("solar", dict(J=30, N=4096), 512, 1),       # 8 chunks  -> P = 8 (no padding)
@@ -590,7 +616,14 @@ def test_scaled_factor_sweeps(hip, case):
         ref = cref.solve_upper(t, c, U, W_ref, cref.solve_lower(t, c, U, W_ref, Y) / d_ref[:, None])
         assert _relmax(fac.apply_inverse(Yd)[0].cpu().numpy(), ref) < TOL_VEC
         ref = cref.matmul_lower(t, c, U, W_ref, Y * np.sqrt(d_ref)[:, None])
-        assert _relmax(fac.dot_tril(Yd)[0].cpu().numpy(), ref) < TOL_VEC
+        got = fac.dot_tril(Yd)
+        assert _relmax(got[0].cpu().numpy(), ref) < TOL_VEC
+        # dot_tril's local pass starts from zero by itself: its state slots are not cleared any more, so a
+        # freed block full of NaN (what the allocator hands back for them next) must not change a bit
+        nchm = fac._mm_chunking(R)[1]
+        poison = torch.full((nchm, 64 * R), float("nan"), dtype=torch.float64, device="cuda")
+        del poison
+        assert torch.equal(fac.dot_tril(Yd), got)
     # single-chunk factor (nch = 1) takes the same code path without a combine
     fac1 = eng.stored_factor(chunk_len=4 * N)
     assert fac1.nch == 1
