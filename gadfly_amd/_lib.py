@@ -15,6 +15,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(CSRC, "libgadfly_hip.so")
+if os.environ.get("GADFLY_SO"):                 # another build of the same library (A/B measurements)
+    SO_PATH = os.path.abspath(os.environ["GADFLY_SO"])
 SOURCES = [os.path.join(CSRC, "gadfly_hip.hip"), os.path.join(CSRC, "gadfly_dense.hip")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "gadfly_hip.h")
 

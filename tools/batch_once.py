@@ -10,9 +10,6 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import gadfly_amd  # noqa: E402
-if os.environ.get("GADFLY_SO"):                 # A/B builds of the library (development)
-    from gadfly_amd import _lib
-    _lib.SO_PATH = os.path.abspath(os.environ["GADFLY_SO"])
 from gadfly_amd.synth import cfg4_walkers  # noqa: E402
 
 N, J, B = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
