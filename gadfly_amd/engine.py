@@ -1112,15 +1112,13 @@ class StreamingBatch:
                                     p(diag_add), p(cmax), *tyd, p(w["d"]), p(w["z"]), p(w["r"]),
                                     p(w["Un"]), None, p(w["den"]), p(w["S"]), p(w["F"]), p(w["info"]), st)
             _lib.check(rc, "gf_chunk_sweep")
-            w["S"].view(B, nch, -1)[:, nch - 1].zero_()
-            w["F"].view(B, nch, -1)[:, nch - 1].zero_()
+            self._clear_slots(w["S"], nch, nch - 1)
+            self._clear_slots(w["F"], nch, nch - 1)
             # transitions and Gram sums of the chunks 1 .. nch - 2; from a zero start state the first chunk's
             # map acts through its end state alone (Phi = G = m = 0 for the combine), the last one's not at all
             transition(1, nch - 2, w["Un"], w["den"])
-            for k, n in (("Phi", 4096), ("G", 4096), ("m", 64)):
-                v = w[k].view(B, nch, n)
-                v[:, 0].zero_()
-                v[:, nch - 1].zero_()
+            for k in ("Phi", "G", "m"):
+                self._clear_slots(w[k], nch, 0, nch - 1)
             self._tp_combine(w, nch, st)
             # a nominal pass (zero start state: pivots >= the true ones) can only fail at or after
             # the true failing row; the final pass decides, from exact start states up to there --
@@ -1167,8 +1165,8 @@ class StreamingBatch:
         rc = lib.gf_reduce_tile(B, N, p(w["d"]), p(w["z"]), p(w["work"]), p(w["acc"]), 1, st)
         _lib.check(rc, "gf_reduce_tile")
         transition(1, nch - 1, w["Un"], w["den"])
-        for k, n in (("Phi", 4096), ("G", 4096), ("m", 64)):
-            w[k].view(B, nch, n)[:, 0].zero_()
+        for k in ("Phi", "G", "m"):
+            self._clear_slots(w[k], nch, 0)
         self._tp_combine(w, nch, st)
         if "corr" not in w:
             w["corr"] = torch.empty((int(lib.gf_chunk_corrections_work(B, nch)),), dtype=torch.float64,
@@ -1192,6 +1190,17 @@ class StreamingBatch:
     #: instead of the sequential one (~0.12 ms per chunk)
     tree_min_chunks = 24
 
+    def _clear_slots(self, x, nch, *slots):
+        """Zero the chunk slots `slots` of every problem in x ([B * nch, n]) with ONE kernel (a strided
+        `zero_()` becomes one memset per problem: 64 launches per evaluation on a 32-problem shard)."""
+        key = (nch,) + slots
+        idx = getattr(self, "_slot_idx", {}).get(key)
+        if idx is None:
+            if not hasattr(self, "_slot_idx"):
+                self._slot_idx = {}
+            idx = self._slot_idx[key] = self.torch.tensor(slots, dtype=self.torch.int64, device=self.device)
+        x.view(self.B, nch, -1).index_fill_(1, idx, 0.0)
+
     def _tp_combine(self, w, nch, st):
         """S/F slot c <- true start state of chunk c (sequential or tree LFT combine)."""
         torch = self.torch
@@ -1206,17 +1215,30 @@ class StreamingBatch:
         tr = w.get("tree")
         if tr is None or tr["P"] != P:
             f64 = dict(dtype=torch.float64, device=self.device)
+            big = ("G", "X") if nch == P else ("Phi", "G", "S", "X")
+            small = ("m", "Y") if nch == P else ("m", "F", "Y")
             tr = w["tree"] = dict(
                 P=P, eye=torch.eye(64, **f64).reshape(4096),
-                **{k: torch.empty((B, P, 4096), **f64) for k in ("Phi", "G", "S", "X")},
-                **{k: torch.empty((B, P, 64), **f64) for k in ("m", "F", "Y")})
+                **{k: torch.empty((B, P, 4096), **f64) for k in big},
+                **{k: torch.empty((B, P, 64), **f64) for k in small})
+        if nch == P:
+            # no padding: the scan works on the chunk maps where they are (it overwrites them: G and m, which the
+            # two-sweep corrections read afterwards, go through copies) and its output buffers change places
+            # with the state slots instead of being copied back
+            tr["G"].copy_(w["G"].view(B, P, 4096))
+            tr["m"].copy_(w["m"].view(B, P, 64))
+            rc = lib.gf_chunk_combine_tree(B, P, p(w["Phi"]), p(tr["G"]), p(tr["m"]), p(w["S"]),
+                                           p(w["F"]), p(tr["X"]), p(tr["Y"]), st)
+            _lib.check(rc, "gf_chunk_combine_tree")
+            w["S"], tr["X"] = tr["X"].view(B * P, 4096), w["S"].view(B, P, 4096)
+            w["F"], tr["Y"] = tr["Y"].view(B * P, 64), w["F"].view(B, P, 64)
+            return
         for k, n in (("Phi", 4096), ("G", 4096), ("S", 4096), ("m", 64), ("F", 64)):
             tr[k][:, :nch].copy_(w[k].view(B, nch, n))
-            if nch < P:
-                if k == "Phi":
-                    tr[k][:, nch:] = tr["eye"]
-                else:
-                    tr[k][:, nch:].zero_()
+            if k == "Phi":
+                tr[k][:, nch:] = tr["eye"]
+            else:
+                tr[k][:, nch:].zero_()
         rc = lib.gf_chunk_combine_tree(B, P, p(tr["Phi"]), p(tr["G"]), p(tr["m"]), p(tr["S"]),
                                        p(tr["F"]), p(tr["X"]), p(tr["Y"]), st)
         _lib.check(rc, "gf_chunk_combine_tree")
@@ -1355,7 +1377,7 @@ class StreamingBatch:
             # 1. nominal pass: zero start states; d-bar, z-bar, r-bar, u~ rows, reset spans.  Nothing of the LAST
             #    chunk's map is ever needed (gf_wide_combine): it is left out
             sweep(0, nch - 1, dbar, zbar, p(rbar), (p(Ut), None, p(de)), zero_start=True)
-            S.view(B, nch, -1)[:, nch - 1].zero_()
+            self._clear_slots(S, nch, nch - 1)
             # 2. closed-loop transitions and the rows h (not for the first chunk either: from a zero start
             #    state its map acts through its end state alone)
             rc = lib.gf_chunk_transition_wide(B, N, L, nch, 1, nch - 2, self.Jc, p(c), p(de), p(dbar),
