@@ -2245,17 +2245,22 @@ __device__ __forceinline__ void cb_load(double *dst, const double *__restrict__ 
 __device__ __forceinline__ int cb_row(int ty, int r) { return 16 * (ty >> 2) + (ty & 3) + 4 * r; }
 __device__ __forceinline__ int cb_col(int tx, int q) { return 16 * q + tx; }
 
+// nt (wave-uniform, 1 .. 4): only the leading 16 nt rows / columns of the operands are non-zero (states of
+// width W <= 16 nt, zero-padded to 64): the other tiles of the result are zeros and are not computed.
 template <class FA, class FB>
-__device__ __forceinline__ void cb_mm(double (&acc)[4][4], FA a_of, FB b_of, int tx, int ty) {
+__device__ __forceinline__ void cb_mm(double (&acc)[4][4], FA a_of, FB b_of, int tx, int ty, const int nt = 4) {
     const int i = tx, k = ty & 3, w = ty >> 2;          // lane = (i, k) of wave w
     d4 C[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) C[q] = d4{0.0, 0.0, 0.0, 0.0};
+    if (w < nt) {
 #pragma unroll 4
-    for (int ks = 0; ks < 16; ++ks) {
-        const double av = a_of(16 * w + i, 4 * ks + k);
+        for (int ks = 0; ks < 4 * nt; ++ks) {
+            const double av = a_of(16 * w + i, 4 * ks + k);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) C[q] = GF_MFMA64(av, b_of(4 * ks + k, 16 * q + i), C[q]);
+            for (int q = 0; q < 4; ++q)
+                if (q < nt) C[q] = GF_MFMA64(av, b_of(4 * ks + k, 16 * q + i), C[q]);
+        }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -2266,10 +2271,10 @@ __device__ __forceinline__ void cb_mm(double (&acc)[4][4], FA a_of, FB b_of, int
 // acc = A' B' with A' = A or A^T (TA), B' = B or B^T (TB), row-major LDS matrices
 template <bool TA, bool TB>
 __device__ __forceinline__ void cb_matmul(double (&acc)[4][4], const double *A, int lda,
-                                          const double *B, int ldb, int tx, int ty) {
+                                          const double *B, int ldb, int tx, int ty, const int nt = 4) {
     cb_mm(acc,
           [&](int row, int k) { return TA ? A[k * lda + row] : A[row * lda + k]; },
-          [&](int k, int col) { return TB ? B[col * ldb + k] : B[k * ldb + col]; }, tx, ty);
+          [&](int k, int col) { return TB ? B[col * ldb + k] : B[k * ldb + col]; }, tx, ty, nt);
 }
 
 __device__ __forceinline__ void cb_store_lds(double *dst, int ld, const double (&acc)[4][4], int tx, int ty) {
@@ -2289,7 +2294,9 @@ __device__ __forceinline__ void cb_store_lds(double *dst, int ld, const double (
 // (updating them is harmless and keeps the loops compile-time).  The multiplier buffer alternates
 // between two halves so that the next owner may write while slower waves still read.
 // scratch >= 140 doubles.  On exit Au[:, 64:129] = A^-1 RHS.
-__device__ __forceinline__ void cb_gauss_jordan(double *Au, double *scratch, int tid) {
+// n (uniform, <= 64): the system is the identity beyond its leading n x n block with zero right-hand sides there
+// (zero-padded states): the steps k >= n are skipped and those rows of the solution are zeros.
+__device__ __forceinline__ void cb_gauss_jordan(double *Au, double *scratch, int tid, const int n = 64) {
     constexpr int LA = CB_LA, NC = 33;
     const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *fbuf = scratch;                                     // [2][64] multipliers
@@ -2307,6 +2314,7 @@ __device__ __forceinline__ void cb_gauss_jordan(double *Au, double *scratch, int
     __syncthreads();
     static_for([&](auto kc) {
         constexpr int k = decltype(kc)::value, wo = k & 3, lk = k >> 2, buf = k & 1;
+        if (k >= n) return;
         if (w == wo) {                      // wave-uniform: this wave owns column k
             const double cval = R[lk];
             const double cand = used ? -1.0 : fabs(cval);
@@ -2328,7 +2336,7 @@ __device__ __forceinline__ void cb_gauss_jordan(double *Au, double *scratch, int
 #pragma unroll
     for (int lc = 16; lc < NC; ++lc) {
         const int c = 4 * lc + w;
-        if (c <= 128) Au[myk * LA + c] = R[lc] * mypinv;
+        if (c <= 128) Au[(used ? myk : lane) * LA + c] = used ? R[lc] * mypinv : 0.0;   // (rows >= n: never pivots)
     }
     __syncthreads();
 }
@@ -2340,7 +2348,8 @@ __device__ __forceinline__ void cb_apply(double *Xs, double *Au, double *Bs, dou
                                          const double *__restrict__ Pg, const double *__restrict__ Gg,
                                          const double *__restrict__ mg, const double *__restrict__ Xbar,
                                          const double *__restrict__ Ybar, const double (&xreg)[16],
-                                         const double yreg, int tid) {
+                                         const double yreg, int tid, const int n = 64) {
+    const int nt = (n + 15) >> 4;             // (maps of width n <= 64, zero-padded: cb_mm / cb_gauss_jordan)
     // Xbar/Ybar: global pointers, or nullptr to take them from registers (xreg[q] = element
     // e = tid + 256 q of the [j][i] layout, yreg = element tid)
     constexpr int LD = CB_LD, LA = CB_LA;
@@ -2350,7 +2359,7 @@ __device__ __forceinline__ void cb_apply(double *Xs, double *Au, double *Bs, dou
     __syncthreads();
     {
         double acc[4][4] = {};
-        cb_matmul<false, false>(acc, Xs, LD, Bs, LD, tx, ty);
+        cb_matmul<false, false>(acc, Xs, LD, Bs, LD, tx, ty, nt);
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -2362,11 +2371,11 @@ __device__ __forceinline__ void cb_apply(double *Xs, double *Au, double *Bs, dou
     }
     if (tid < 64) {                         // rhs = Y - X m
         double sacc = Ys[tid];
-        for (int k = 0; k < 64; ++k) sacc = fma(-Xs[tid * LD + k], vs[k], sacc);
+        for (int k = 0; k < n; ++k) sacc = fma(-Xs[tid * LD + k], vs[k], sacc);
         Au[tid * LA + 128] = sacc;
     }
     __syncthreads();
-    cb_gauss_jordan(Au, Bs, tid);
+    cb_gauss_jordan(Au, Bs, tid, n);
     // Bs <- Phi ; Xs <- Z = Phi K  (K symmetrised)
     cb_load(Bs, Pg, tid);
     if (tid < 64) vs[tid] = Au[tid * LA + 128];
@@ -2376,19 +2385,19 @@ __device__ __forceinline__ void cb_apply(double *Xs, double *Au, double *Bs, dou
         cb_mm(acc,
               [&](int row, int k) { return Bs[row * LD + k]; },
               [&](int k, int col) { return 0.5 * (Au[k * LA + 64 + col] + Au[col * LA + 64 + k]); },
-              tx, ty);
+              tx, ty, nt);
         __syncthreads();
         cb_store_lds(Xs, LD, acc, tx, ty);
     }
     double ynew = 0.0;
     if (tid < 64) {                         // Y+ = Ybar + Phi v
         ynew = Ybar ? Ybar[tid] : yreg;
-        for (int k = 0; k < 64; ++k) ynew = fma(Bs[tid * LD + k], vs[k], ynew);
+        for (int k = 0; k < n; ++k) ynew = fma(Bs[tid * LD + k], vs[k], ynew);
     }
     __syncthreads();
     {                                       // X+ = Xbar + Z Phi^T  -> Au left half as staging
         double acc[4][4] = {};
-        cb_matmul<false, true>(acc, Xs, LD, Bs, LD, tx, ty);
+        cb_matmul<false, true>(acc, Xs, LD, Bs, LD, tx, ty, nt);
         __syncthreads();
         cb_store_lds(Au, LA, acc, tx, ty);
     }
@@ -2405,8 +2414,9 @@ __device__ __forceinline__ void cb_apply(double *Xs, double *Au, double *Bs, dou
 // Sequential LFT combine over the chunks of each problem (one workgroup per problem).
 // S_state/F_state slot c holds (Xbar_end, Ybar_end) of chunk c on entry and the TRUE start
 // state of chunk c on exit (slot 0 <- 0).
+template <bool FULL>                    // FULL: widths beyond 48 take the whole 64 x 64 slots (compile-time bounds)
 __global__ void __launch_bounds__(256)
-k_combine(const int nch, const double *__restrict__ Phi_, const double *__restrict__ G_,
+k_combine(const int nch, const int n_, const double *__restrict__ Phi_, const double *__restrict__ G_,
           const double *__restrict__ m_, double *__restrict__ S_state,
           double *__restrict__ F_state) {
     constexpr int LD = CB_LD, LA = CB_LA;
@@ -2418,6 +2428,7 @@ k_combine(const int nch, const double *__restrict__ Phi_, const double *__restri
     double *vs = Ys + 64;                   // [64]
     const int pr = blockIdx.x;
     const int tid = threadIdx.x;
+    const int n = FULL ? 64 : n_;
     for (int e = tid; e < 64 * LD; e += 256) Xs[e] = 0.0;
     if (tid < 64) Ys[tid] = 0.0;
     __syncthreads();
@@ -2436,7 +2447,7 @@ k_combine(const int nch, const double *__restrict__ Phi_, const double *__restri
         if (tid < 64) { ybar = Fg[tid]; Fg[tid] = Ys[tid]; }
         if (c == nch - 1) break;
         cb_apply(Xs, Au, Bs, Ys, vs, Phi_ + slot * 4096, G_ + slot * 4096, m_ + slot * 64,
-                 nullptr, nullptr, xbar, ybar, tid);
+                 nullptr, nullptr, xbar, ybar, tid, n);
     }
 }
 
@@ -2448,11 +2459,12 @@ k_combine(const int nch, const double *__restrict__ Phi_, const double *__restri
 // Down-sweep on states: s[left] <- s[right] ; s[right] <- map[left](s[right]).
 // Slots are (problem, index) with P = power-of-two indices per problem; identity maps pad.
 struct TreeArgs {
-    int P, d;                               // level: pairs (idx - d, idx), idx = (k+1) 2d - 1
+    int P, d, n;                            // level: pairs (idx - d, idx), idx = (k+1) 2d - 1; n = state width
     double *Phi, *G, *S, *F, *m;            // maps [B*P][...]
     double *Xst, *Yst;                      // states [B*P][4096] / [64]
 };
 
+template <bool FULL>
 __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
     constexpr int LD = CB_LD, LA = CB_LA;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -2465,6 +2477,7 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
     const int ir = (k + 1) * 2 * A.d - 1, il = ir - A.d;
     const size_t L = (size_t)pr * A.P + il, Rr = (size_t)pr * A.P + ir;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int n = FULL ? 64 : A.n, nt = FULL ? 4 : ((n + 15) >> 4);
     double *w = v1, *vv = v1 + 64, *g2v = v1 + 128, *tmpv = v1 + 192;
     // a. M0 = Xbar1, M1 = G2 ;  AL = I - Xbar1 G2 ; AR = I ; col 128 = Ybar1 - Xbar1 m2
     cb_load(M0, A.S + L * 4096, tid);
@@ -2473,7 +2486,7 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
     __syncthreads();
     {
         double acc[4][4] = {};
-        cb_matmul<false, false>(acc, M0, LD, M1, LD, tx, ty);
+        cb_matmul<false, false>(acc, M0, LD, M1, LD, tx, ty, nt);
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -2485,23 +2498,23 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
     }
     if (tid < 64) {
         double sacc = A.F[L * 64 + tid];
-        for (int kk = 0; kk < 64; ++kk) sacc = fma(-M0[tid * LD + kk], tmpv[kk], sacc);
+        for (int kk = 0; kk < n; ++kk) sacc = fma(-M0[tid * LD + kk], tmpv[kk], sacc);
         Au[tid * LA + 128] = sacc;
     }
     __syncthreads();
-    cb_gauss_jordan(Au, M1, tid);           // AR = D, col 128 = v   (M1 serves as scratch ...
+    cb_gauss_jordan(Au, M1, tid, n);          // AR = D, col 128 = v   (M1 serves as scratch ...
     cb_load(M1, A.G + Rr * 4096, tid);      // ... so G2 is loaded again)
     if (tid < 64) vv[tid] = Au[tid * LA + 128];
     __syncthreads();
     if (tid < 64) {                         // g2v = G2 v ;  m12 pieces need it
         double sacc = 0.0;
-        for (int kk = 0; kk < 64; ++kk) sacc = fma(M1[tid * LD + kk], vv[kk], sacc);
+        for (int kk = 0; kk < n; ++kk) sacc = fma(M1[tid * LD + kk], vv[kk], sacc);
         g2v[tid] = sacc;
     }
     // c. AL = D Xbar1
     {
         double acc[4][4] = {};
-        cb_matmul<false, false>(acc, Au + 64, LA, M0, LD, tx, ty);
+        cb_matmul<false, false>(acc, Au + 64, LA, M0, LD, tx, ty, nt);
         __syncthreads();
         cb_store_lds(Au, LA, acc, tx, ty);
     }
@@ -2511,19 +2524,19 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
     __syncthreads();
     {
         double acc[4][4] = {};
-        cb_matmul<false, false>(acc, M0, LD, Au, LA, tx, ty);
+        cb_matmul<false, false>(acc, M0, LD, Au, LA, tx, ty, nt);
         __syncthreads();
         cb_store_lds(Au, LA, acc, tx, ty);
     }
     if (tid < 64) {
         double sacc = A.F[Rr * 64 + tid];
-        for (int kk = 0; kk < 64; ++kk) sacc = fma(M0[tid * LD + kk], vv[kk], sacc);
+        for (int kk = 0; kk < n; ++kk) sacc = fma(M0[tid * LD + kk], vv[kk], sacc);
         w[tid] = sacc;                      // Ybar12 (stored at the end)
     }
     __syncthreads();
     {
         double acc[4][4] = {};
-        cb_matmul<false, true>(acc, Au, LA, M0, LD, tx, ty);
+        cb_matmul<false, true>(acc, Au, LA, M0, LD, tx, ty, nt);
         __syncthreads();
         cb_store_lds(Au, LA, acc, tx, ty);
     }
@@ -2542,14 +2555,14 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
     __syncthreads();
     {
         double acc[4][4] = {};
-        cb_matmul<false, false>(acc, Au + 64, LA, Au, LA, tx, ty);
+        cb_matmul<false, false>(acc, Au + 64, LA, Au, LA, tx, ty, nt);
         __syncthreads();
         cb_store_lds(Au + 64, LA, acc, tx, ty);
     }
     __syncthreads();
     {
         double acc[4][4] = {};
-        cb_matmul<false, false>(acc, M0, LD, Au + 64, LA, tx, ty);
+        cb_matmul<false, false>(acc, M0, LD, Au + 64, LA, tx, ty, nt);
         double *Pr = A.Phi + Rr * 4096;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -2560,20 +2573,20 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
     // f. M1 <- G2 (D Phi1) ;  G12 = G1 + Phi1^T M1 ;  m12 = m1 + Phi1^T (m2 - G2 v)
     {
         double acc[4][4] = {};
-        cb_matmul<false, false>(acc, M1, LD, Au + 64, LA, tx, ty);
+        cb_matmul<false, false>(acc, M1, LD, Au + 64, LA, tx, ty, nt);
         __syncthreads();
         cb_store_lds(M1, LD, acc, tx, ty);
     }
     __syncthreads();
     {
         double acc[4][4] = {};
-        cb_matmul<true, false>(acc, Au, LA, M1, LD, tx, ty);
+        cb_matmul<true, false>(acc, Au, LA, M1, LD, tx, ty, nt);
         __syncthreads();
         cb_store_lds(M0, LD, acc, tx, ty);  // Phi2 no longer needed
     }
     if (tid < 64) {
         double sacc = A.m[L * 64 + tid];
-        for (int kk = 0; kk < 64; ++kk) sacc = fma(Au[kk * LA + tid], tmpv[kk] - g2v[kk], sacc);
+        for (int kk = 0; kk < n; ++kk) sacc = fma(Au[kk * LA + tid], tmpv[kk] - g2v[kk], sacc);
         A.m[Rr * 64 + tid] = sacc;
         A.F[Rr * 64 + tid] = w[tid];
     }
@@ -2589,6 +2602,15 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
     }
 }
 
+// the down-sweep starts from a zero state in the last slot of every problem (one launch: a memset per problem
+// and array was 2 B launches per scan)
+__global__ void __launch_bounds__(256) k_tree_root(const int P, double *__restrict__ Xst, double *__restrict__ Yst) {
+    const size_t slot = (size_t)blockIdx.x * P + P - 1;
+    for (int e = threadIdx.x; e < 4096; e += 256) Xst[slot * 4096 + e] = 0.0;
+    if (threadIdx.x < 64) Yst[slot * 64 + threadIdx.x] = 0.0;
+}
+
+template <bool FULL>
 __global__ void __launch_bounds__(256) k_tree_apply(const TreeArgs A) {
     constexpr int LD = CB_LD, LA = CB_LA;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -2615,7 +2637,7 @@ __global__ void __launch_bounds__(256) k_tree_apply(const TreeArgs A) {
     __syncthreads();
     const double noreg[16] = {};
     cb_apply(Xs, Au, Bs, Ys, vs, A.Phi + L * 4096, A.G + L * 4096, A.m + L * 64,
-             A.S + L * 4096, A.F + L * 64, noreg, 0.0, tid);
+             A.S + L * 4096, A.F + L * 64, noreg, 0.0, tid, FULL ? 64 : A.n);
     _Pragma("unroll 16")
     for (int e = tid; e < 4096; e += 256) { const int j = e >> 6, i = e & 63; Xr[e] = Xs[i * LD + j]; }
     if (tid < 64) A.Yst[Rr * 64 + tid] = Ys[tid];
@@ -5127,14 +5149,16 @@ static size_t cb_lds_bytes(bool with_xn) {
     return sizeof(double) * (64 * CB_LD + 64 * CB_LA + 64 * CB_LD + 256);
 }
 
-int gf_chunk_combine(int B, int nch, const double *Phi, const double *G, const double *m,
+int gf_chunk_combine(int B, int nch, int W, const double *Phi, const double *G, const double *m,
                      double *S_state, double *F_state, void *stream) {
     if (B < 1 || nch < 1) return set_err("gf_chunk_combine: empty problem%s", "");
+    if (W < 1 || W > 64) return set_err("gf_chunk_combine: width %s%lld unsupported (1..64)", "", W);
     if (!Phi || !G || !m || !S_state || !F_state) return set_err("gf_chunk_combine: null pointer%s", "");
     const size_t lds = cb_lds_bytes(true);
-    const void *fn[1] = {(const void *)k_combine};
-    if (!lds_opt_in(0, (hipStream_t)stream, fn, 1, lds)) return set_err("gf_chunk_combine: cannot opt in to %s%lld bytes of LDS", "", (long long)lds);
-    hipLaunchKernelGGL(k_combine, dim3(B), dim3(256), lds, (hipStream_t)stream, nch, Phi, G, m, S_state, F_state);
+    const void *fn[2] = {(const void *)k_combine<true>, (const void *)k_combine<false>};
+    if (!lds_opt_in(0, (hipStream_t)stream, fn, 2, lds)) return set_err("gf_chunk_combine: cannot opt in to %s%lld bytes of LDS", "", (long long)lds);
+    if (W > 48) hipLaunchKernelGGL(k_combine<true>, dim3(B), dim3(256), lds, (hipStream_t)stream, nch, W, Phi, G, m, S_state, F_state);
+    else hipLaunchKernelGGL(k_combine<false>, dim3(B), dim3(256), lds, (hipStream_t)stream, nch, W, Phi, G, m, S_state, F_state);
     return check_launch("gf_chunk_combine");
 }
 
@@ -5142,27 +5166,28 @@ int gf_chunk_combine(int B, int nch, const double *Phi, const double *G, const d
 // >= nch; the caller fills slots c < nch with the chunk maps (Phi, G, m and Xbar/Ybar = the
 // nominal end states) and the rest with identity maps (Phi = I, everything else 0).  On exit
 // Xst/Yst slot c hold the TRUE start state of chunk c.  The map arrays are overwritten.
-int gf_chunk_combine_tree(int B, int P, double *Phi, double *G, double *m, double *S, double *F,
+int gf_chunk_combine_tree(int B, int P, int W, double *Phi, double *G, double *m, double *S, double *F,
                           double *Xst, double *Yst, void *stream) {
     if (B < 1 || P < 2 || (P & (P - 1))) return set_err("gf_chunk_combine_tree: P=%s%lld must be a power of two >= 2", "", P);
+    if (W < 1 || W > 64) return set_err("gf_chunk_combine_tree: width %s%lld unsupported (1..64)", "", W);
     if (!Phi || !G || !m || !S || !F || !Xst || !Yst) return set_err("gf_chunk_combine_tree: null pointer%s", "");
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = cb_lds_bytes(false);
-    const void *fn[2] = {(const void *)k_tree_compose, (const void *)k_tree_apply};
-    if (!lds_opt_in(1, st, fn, 2, lds)) return set_err("gf_chunk_combine_tree: cannot opt in to %s%lld bytes of LDS", "", (long long)lds);
+    const void *fn[4] = {(const void *)k_tree_compose<true>, (const void *)k_tree_apply<true>,
+                         (const void *)k_tree_compose<false>, (const void *)k_tree_apply<false>};
+    if (!lds_opt_in(1, st, fn, 4, lds)) return set_err("gf_chunk_combine_tree: cannot opt in to %s%lld bytes of LDS", "", (long long)lds);
     TreeArgs A;
-    A.P = P; A.Phi = Phi; A.G = G; A.S = S; A.F = F; A.m = m; A.Xst = Xst; A.Yst = Yst;
+    A.P = P; A.n = W; A.Phi = Phi; A.G = G; A.S = S; A.F = F; A.m = m; A.Xst = Xst; A.Yst = Yst;
     for (int d = 1; d < P; d *= 2) {        // up-sweep
         A.d = d;
-        hipLaunchKernelGGL(k_tree_compose, dim3(B * (P / (2 * d))), dim3(256), lds, st, A);
+        if (W > 48) hipLaunchKernelGGL(k_tree_compose<true>, dim3(B * (P / (2 * d))), dim3(256), lds, st, A);
+        else hipLaunchKernelGGL(k_tree_compose<false>, dim3(B * (P / (2 * d))), dim3(256), lds, st, A);
     }
-    for (int b = 0; b < B; ++b) {           // root state = zero
-        (void)hipMemsetAsync(Xst + ((size_t)b * P + P - 1) * 4096, 0, sizeof(double) * 4096, st);
-        (void)hipMemsetAsync(Yst + ((size_t)b * P + P - 1) * 64, 0, sizeof(double) * 64, st);
-    }
+    hipLaunchKernelGGL(k_tree_root, dim3(B), dim3(256), 0, st, P, Xst, Yst);   // root state = zero
     for (int d = P / 2; d >= 1; d /= 2) {   // down-sweep
         A.d = d;
-        hipLaunchKernelGGL(k_tree_apply, dim3(B * (P / (2 * d))), dim3(256), lds, st, A);
+        if (W > 48) hipLaunchKernelGGL(k_tree_apply<true>, dim3(B * (P / (2 * d))), dim3(256), lds, st, A);
+        else hipLaunchKernelGGL(k_tree_apply<false>, dim3(B * (P / (2 * d))), dim3(256), lds, st, A);
     }
     return check_launch("gf_chunk_combine_tree");
 }

@@ -1207,7 +1207,7 @@ class StreamingBatch:
         lib, p = self.lib, _lib.ptr
         B = self.B
         if nch < self.tree_min_chunks:
-            rc = lib.gf_chunk_combine(B, nch, p(w["Phi"]), p(w["G"]), p(w["m"]), p(w["S"]),
+            rc = lib.gf_chunk_combine(B, nch, self.W, p(w["Phi"]), p(w["G"]), p(w["m"]), p(w["S"]),
                                       p(w["F"]), st)
             _lib.check(rc, "gf_chunk_combine")
             return
@@ -1227,7 +1227,7 @@ class StreamingBatch:
             # with the state slots instead of being copied back
             tr["G"].copy_(w["G"].view(B, P, 4096))
             tr["m"].copy_(w["m"].view(B, P, 64))
-            rc = lib.gf_chunk_combine_tree(B, P, p(w["Phi"]), p(tr["G"]), p(tr["m"]), p(w["S"]),
+            rc = lib.gf_chunk_combine_tree(B, P, self.W, p(w["Phi"]), p(tr["G"]), p(tr["m"]), p(w["S"]),
                                            p(w["F"]), p(tr["X"]), p(tr["Y"]), st)
             _lib.check(rc, "gf_chunk_combine_tree")
             w["S"], tr["X"] = tr["X"].view(B * P, 4096), w["S"].view(B, P, 4096)
@@ -1239,7 +1239,7 @@ class StreamingBatch:
                 tr[k][:, nch:] = tr["eye"]
             else:
                 tr[k][:, nch:].zero_()
-        rc = lib.gf_chunk_combine_tree(B, P, p(tr["Phi"]), p(tr["G"]), p(tr["m"]), p(tr["S"]),
+        rc = lib.gf_chunk_combine_tree(B, P, self.W, p(tr["Phi"]), p(tr["G"]), p(tr["m"]), p(tr["S"]),
                                        p(tr["F"]), p(tr["X"]), p(tr["Y"]), st)
         _lib.check(rc, "gf_chunk_combine_tree")
         w["S"].view(B, nch, 4096).copy_(tr["X"][:, :nch])

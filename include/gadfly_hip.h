@@ -249,9 +249,11 @@ int gf_scaled_propagator(int B, int64_t N, int W, int ld, const double *c, const
 int gf_chunk_transition_wide(int B, int64_t N, int64_t chunk_len, int nch, int chunk_first, int chunk_count, int Jc,
                              const double *c, const double *de, const double *dbar, const double *rbar,
                              const double *Ut, double *h_out, double *Phi_out, void *stream);
-int gf_chunk_combine(int B, int nch, const double *Phi, const double *G, const double *m,
+/* (W = Jr + 2 Jc <= 63, the width of the states: the 64 x 64 slots are zero beyond it, and the combines'
+ * pivoted solves and matrix products are carried out on the leading W rows and columns only) */
+int gf_chunk_combine(int B, int nch, int W, const double *Phi, const double *G, const double *m,
                      double *S_state, double *F_state, void *stream);
-int gf_chunk_combine_tree(int B, int P, double *Phi, double *G, double *m, double *S, double *F,
+int gf_chunk_combine_tree(int B, int P, int W, double *Phi, double *G, double *m, double *S, double *F,
                           double *Xst, double *Yst, void *stream);
 
 /*
