@@ -15,7 +15,8 @@
 //                 triangle and mirrored -- exactly symmetric results at half the tiles), the scan's
 //                 mat-vecs, and strided copies
 //   k_wide_gram   G_c = sum_n h_n h_n^T / d_n, m_c = sum_n h_n z_n / d_n of a chunk: one workgroup per
-//                 chunk, one wave per 16-row strip of G, the rows h_n read ONCE through LDS
+//                 chunk, the upper-triangular 16 x 16 tiles of G and the strips of m dealt evenly over its
+//                 4 or 8 waves, the rows h_n read ONCE through LDS
 //   k_lft_pack / k_lft_unpack   sweep-state layout ([column][row], k_factorw / k_phiw) <-> dense maps
 // The one solve per tree level is gf_dense_solve (k_dense_solve, gadfly_hip.hip).
 //
@@ -348,20 +349,28 @@ struct JobBuilder {
 // ------------------------------------------------------------------------------------------------
 // Gram sums of a chunk: G = sum_n h_n h_n^T / d_n (upper triangle, mirrored), m = sum_n h_n z_n / d_n
 // ------------------------------------------------------------------------------------------------
-template <int NT>                       // WP = 16 NT
-__global__ void __launch_bounds__(64 * NT)
+// The work of a chunk is NT (NT + 1) / 2 upper-triangular 16 x 16 tiles of G plus one 16 x 1 strip of m per row
+// strip: NT (NT + 3) / 2 units of one MFMA per 4 rows each.  They are dealt out EVENLY, in row-strip order, over
+// the waves of the workgroup(s) of a chunk (NW waves per workgroup, gridDim.y workgroups): with one wave per row
+// strip the first wave carried NT + 1 units and the last 2, and the step time was the first wave's (cfg4's
+// shard: 24 of a workgroup's 80 MFMAs per K-step on one SIMD, 1.8 TB/s).
+template <int NT>
+struct GramPlan {
+    static constexpr int WP = 16 * NT, UNITS = NT * (NT + 3) / 2, NW = (NT <= 5) ? 4 : 8;
+};
+
+template <int NT, int SPLIT>            // WP = 16 NT; SPLIT workgroups share a chunk (few chunks on 256 CUs)
+__global__ void __launch_bounds__(64 * GramPlan<NT>::NW)
 k_wide_gram(const int64_t N, const int64_t L, const int nch, const int ch0, const int nsel, const int P,
             const int CP, const double *__restrict__ h_, const double *__restrict__ dbar_, const double *__restrict__ zbar_,
             double *__restrict__ G_out, double *__restrict__ m_out) {
-    constexpr int WP = 16 * NT;
+    using Plan = GramPlan<NT>;
+    constexpr int WP = Plan::WP, NW = Plan::NW, NTH = 64 * NW;
+    constexpr int UPW = (Plan::UNITS + NW * SPLIT - 1) / (NW * SPLIT);     // units per wave (at most)
     constexpr int HLD = (WP + 31) / 32 * 32 + 16;   // rows k, k + 1 land 32 banks apart
-    constexpr int NV = 4;                           // double2 loads per thread and K-step (at most)
-    // gridDim.y workgroups share a chunk (few chunks: the reference's default kernel has 128 on 256 CUs):
-    // workgroup y takes the 16-row strips r = y, y + gridDim.y, ... (every workgroup stages all rows h)
-    const int split = gridDim.y, NTH = blockDim.x;
+    constexpr int NV = (8 * WP + NTH - 1) / NTH;    // double2 loads per thread and K-step
     const int tid = threadIdx.x, lane = tid & 63;
-    const int r = __builtin_amdgcn_readfirstlane((int)(tid >> 6) * split + (int)blockIdx.y);
-    const bool live = r < NT;
+    const int gw = __builtin_amdgcn_readfirstlane((int)(tid >> 6) + NW * (int)blockIdx.y);   // wave among NW SPLIT
     const int li = lane & 15, lk = lane >> 4;
     const int sel = blockIdx.x, pr = sel / nsel, ch = ch0 + (sel - pr * nsel);      // chunks ch0 .. ch0 + nsel - 1
     const int64_t c0 = (int64_t)ch * L;
@@ -372,9 +381,22 @@ k_wide_gram(const int64_t N, const int64_t L, const int nch, const int ch0, cons
     const double *__restrict__ zg = zbar_ + pb;
     __shared__ __attribute__((aligned(16))) double Hs[2][16 * HLD];
     __shared__ double Ss[2][16], Zs[2][16];
-    d4 acc[NT + 1];
+    // this wave's units: u = gw UPW + s in row-strip order (strip r: its tiles q = r .. NT - 1, then q = NT: m)
+    int ur[UPW], uq[UPW];
+    {
+        int u0 = gw * UPW, r = 0, base = 0;         // base = first unit of strip r
+        while (r < NT && u0 >= base + (NT - r + 1)) { base += NT - r + 1; ++r; }
 #pragma unroll
-    for (int q = 0; q <= NT; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int s = 0; s < UPW; ++s) {
+            const int u = u0 + s;
+            while (r < NT && u >= base + (NT - r + 1)) { base += NT - r + 1; ++r; }
+            ur[s] = (r < NT) ? r : -1;              // (-1: no such unit)
+            uq[s] = (r < NT) ? r + (u - base) : 0;
+        }
+    }
+    d4 acc[UPW];
+#pragma unroll
+    for (int s = 0; s < UPW; ++s) acc[s] = d4{0.0, 0.0, 0.0, 0.0};
     double2 v[NV];
     double sv = 0.0, zv = 0.0;
     auto fetch = [&](const int kb) {
@@ -406,40 +428,44 @@ k_wide_gram(const int64_t N, const int64_t L, const int nch, const int ch0, cons
     for (int kb = 0; kb < rows; kb += 16) {
         const bool more = kb + 16 < rows;
         if (more) fetch(kb + 16);
-        if (live) {
-            const double *hrow = &Hs[cur][0];
+        const double *hrow = &Hs[cur][0];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int k = 4 * ks + lk;
-                const double av = hrow[k * HLD + 16 * r + li] * Ss[cur][k];
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = 4 * ks + lk;
+            const double sc = Ss[cur][k];
 #pragma unroll
-                for (int q = 0; q < NT; ++q)
-                    if (q >= r) acc[q] = GF_MFMA64(av, hrow[k * HLD + 16 * q + li], acc[q]);
-                acc[NT] = GF_MFMA64(av, (li == 0) ? Zs[cur][k] : 0.0, acc[NT]);
+            for (int s = 0; s < UPW; ++s) {
+                if (ur[s] < 0) continue;            // (wave-uniform)
+                const double av = hrow[k * HLD + 16 * ur[s] + li] * sc;
+                const double bv = (uq[s] < NT) ? hrow[k * HLD + 16 * uq[s] + li] : ((li == 0) ? Zs[cur][k] : 0.0);
+                acc[s] = GF_MFMA64(av, bv, acc[s]);
             }
         }
         if (more) stash(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
-    if (!live) return;
     const size_t mp = (size_t)pr * P + ch;          // dense map index (the scan pads nch to P)
     double *__restrict__ Gd = G_out + mp * ((size_t)WP * WP);
 #pragma unroll
-    for (int q = 0; q < NT; ++q) {
-        if (q < r) continue;
+    for (int s = 0; s < UPW; ++s) {
+        const int r = ur[s], q = uq[s];
+        if (r < 0) continue;
+        if (q == NT) {                              // the strip of m
+            if (li == 0) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) m_out[mp * WP + 16 * r + lk + 4 * rr] = acc[s][rr];
+            }
+            continue;
+        }
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int row = 16 * r + lk + 4 * rr, col = 16 * q + li;
             if (q > r || col >= row) {
-                Gd[(size_t)row * WP + col] = acc[q][rr];
-                Gd[(size_t)col * WP + row] = acc[q][rr];
+                Gd[(size_t)row * WP + col] = acc[s][rr];
+                Gd[(size_t)col * WP + row] = acc[s][rr];
             }
         }
-    }
-    if (li == 0) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) m_out[mp * WP + 16 * r + lk + 4 * rr] = acc[NT][rr];
     }
 }
 
@@ -739,12 +765,15 @@ bool pow2(int x) { return x >= 1 && (x & (x - 1)) == 0; }
 template <int NT>
 void launch_gram(int B, int64_t N, int64_t L, int nch, int ch0, int nsel, int P, int CP, const double *h,
                  const double *dbar, const double *zbar, double *G, double *m, hipStream_t st) {
-    // few chunks: two workgroups per chunk, strips dealt alternately (the strips' work falls off linearly)
+    // few chunks: two workgroups per chunk (each stages all rows of h, the units are dealt over both)
     const int slots = B * nsel;
-    const int split = (slots < 200 && NT >= 4) ? 2 : 1;
-    const int waves = (NT + split - 1) / split;
-    hipLaunchKernelGGL((k_wide_gram<NT>), dim3(slots, split), dim3(64 * waves), 0, st, N, L, nch, ch0, nsel, P, CP,
-                       h, dbar, zbar, G, m);
+    constexpr int NW = GramPlan<NT>::NW;
+    if (slots < 200 && NT >= 4)
+        hipLaunchKernelGGL((k_wide_gram<NT, 2>), dim3(slots, 2), dim3(64 * NW), 0, st, N, L, nch, ch0, nsel, P, CP,
+                           h, dbar, zbar, G, m);
+    else
+        hipLaunchKernelGGL((k_wide_gram<NT, 1>), dim3(slots, 1), dim3(64 * NW), 0, st, N, L, nch, ch0, nsel, P, CP,
+                           h, dbar, zbar, G, m);
 }
 
 int dispatch_gram(int WP, int B, int64_t N, int64_t L, int nch, int ch0, int nsel, int P, int CP, const double *h,
