@@ -105,6 +105,12 @@ def test_random_problem(hip, seed):
         eng.tree_min_chunks = int(rng.choice([2, 1 << 30]))              # tree or sequential combine
         ll_tp = float(eng.log_likelihood_time_parallel(chunk_len=L)[0])
         assert abs(ll_tp - ref) <= RTOL_LL * abs(ref), (tag, L, ll_tp, ref)
+        # the same from two sweeps (nominal sums + per-chunk corrections): these matrices are
+        # positive definite (info == 0 above), so the result is finite and the same number
+        eng.two_sweep = True
+        ll_2 = float(eng.log_likelihood_time_parallel(chunk_len=L)[0])
+        eng.two_sweep = False
+        assert abs(ll_2 - ref) <= RTOL_LL * abs(ref), (tag, L, ll_2, ref)
         fac = eng.stored_factor(chunk_len=L)
         assert _relmax(fac.apply_inverse(Yd)[0].cpu().numpy(), ai_ref) < TOL_VEC, (tag, L)
         dt_ref = cref.matmul_lower(t, c, U, W_ref, Y * np.sqrt(d_ref)[:, None])
