@@ -710,7 +710,7 @@ class StreamingBatch:
     """
 
     def __init__(self, coeffs_list, t, y, diag=None, tile_rows=8192, device=None,
-                 force_v1=False, overlap_build=False, allow_fused=True):
+                 force_v1=False, overlap_build=False, allow_fused=True, dt_median=None):
         torch = _lib.require_device()
         self.torch = torch
         self.lib = _lib.load()
@@ -794,7 +794,12 @@ class StreamingBatch:
         self.tile_rows = T
         # typical cadence (median spacing) sets how many rows a scaled block may span
         tt = self.t[0]
-        self._dt_med = float(torch.median(tt[1:] - tt[:-1])) if self.N > 1 else 0.0
+        # (a sort of N spacings and a host synchronisation: a caller that factorises the same time axis again
+        # -- GaussianProcess.recompute() -- passes the value it got the first time)
+        if dt_median is not None:
+            self._dt_med = float(dt_median)
+        else:
+            self._dt_med = float(torch.median(tt[1:] - tt[:-1])) if self.N > 1 else 0.0
         self._pack = self._make_pack(*self._coeff_host)
 
         def rows_buf():
@@ -1062,24 +1067,31 @@ class StreamingBatch:
         opts = (int(self.generator_period), int(self.sweep_variant))
         f64 = dict(dtype=torch.float64, device=self.device)
         key = (chunk_len, nch)
+
+        def rows(*tail):
+            # a row array with its eight spare rows (fetched ahead unconditionally, never used) cleared; the
+            # rows themselves are written by the sweeps before anything reads them -- clearing 0.5 GB per
+            # array and compute() at N = 1e6 was 0.3 ms of memsets
+            x = torch.empty((B * N + 8,) + tail, **f64)
+            x[B * N:].zero_()
+            return x
+
         if getattr(self, "_tp_key", None) != key:
             self._tp = dict(
                 S=torch.empty((B * nch, 4096), **f64), F=torch.empty((B * nch, 64), **f64),
                 Phi=torch.empty((B * nch, 4096), **f64), G=torch.empty((B * nch, 4096), **f64),
                 m=torch.empty((B * nch, 64), **f64),
                 # (eight spare rows: the transition sweep fetches r-bar / d-bar rows ahead, unconditionally)
-                d=torch.zeros((B * N + 8,), **f64), z=torch.zeros((B * N + 8,), **f64),
-                r=torch.zeros((B * N + 8, 64), **f64),
-                Un=torch.zeros((B * N + 8, 64), **f64), den=torch.zeros((B * N + 8,), **f64),
+                d=rows(), z=rows(), r=rows(64), Un=rows(64), den=rows(),
                 info=torch.zeros((B * nch,), dtype=torch.int32, device=self.device),
                 work=torch.empty((B * int(lib.gf_reduce_work(N)),), **f64),
                 acc=torch.empty((B, 3), **f64))
             self._tp_key = key
         w = self._tp
         if store and "Ut" not in w:
-            w["Ut"] = torch.zeros((B * N + 8, 64), **f64)
+            w["Ut"] = rows(64)
             w["Wt"] = torch.empty((B * N, 64), **f64)
-            w["de"] = torch.zeros((B * N + 8,), **f64)
+            w["de"] = rows()
             # the factor's own copy of the chunk transitions: a later non-storing evaluation
             # (log_likelihood of another y) refills "Phi" with the NOMINAL pass' transitions
             w["PhiT"] = torch.empty((B * nch, 4096), **f64)
