@@ -35,6 +35,41 @@
 #define FM_INLINE __device__ __forceinline__
 #include "fastmath.h"
 
+// fm_exp with its coefficients formed where they are used.  Written as literals, hipcc hoists the fourteen FP64
+// coefficients out of any loop that contains a call -- also when the call sits on a reset row, one row in 16 to
+// 64 -- and holds them in 28 VGPRs for the whole sweep (k_phi7<60> then spills).  Each coefficient's two words
+// XOR an opaque zero taken once per call, so it is not loop-invariant; same bits, same result.  For the sweeps
+// whose only transcendental is this one (the transition sweeps); the factor sweeps are faster with the hoisted
+// literals (measured: DESIGN.md 2.1e).
+template <unsigned long long BITS>
+__device__ __forceinline__ double fm_local_constant(const int z) {
+    return __hiloint2double((int)(unsigned)(BITS >> 32) ^ z, (int)(unsigned)(BITS & 0xffffffffull) ^ z);
+}
+#define GF_K(x) fm_local_constant<__builtin_bit_cast(unsigned long long, (double)(x))>(fm_z)
+__device__ __forceinline__ double fm_exp_local(const double x) {
+    int fm_z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(fm_z));
+    if (x < -745.0) return 0.0;
+    const double k = rint(x * GF_K(1.44269504088896338700e+00));
+    const double r = fma(-k, GF_K(1.90821492927058770002e-10), fma(-k, GF_K(6.93147180369123816490e-01), x));
+    double p = GF_K(1.0 / 6227020800.0);
+    p = fma(p, r, GF_K(1.0 / 479001600.0));
+    p = fma(p, r, GF_K(1.0 / 39916800.0));
+    p = fma(p, r, GF_K(1.0 / 3628800.0));
+    p = fma(p, r, GF_K(1.0 / 362880.0));
+    p = fma(p, r, GF_K(1.0 / 40320.0));
+    p = fma(p, r, GF_K(1.0 / 5040.0));
+    p = fma(p, r, GF_K(1.0 / 720.0));
+    p = fma(p, r, GF_K(1.0 / 120.0));
+    p = fma(p, r, GF_K(1.0 / 24.0));
+    p = fma(p, r, GF_K(1.0 / 6.0));
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
+#undef GF_K
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -1530,7 +1565,7 @@ k_phi7(const int64_t N, const int64_t chunk_len, const int nch, const int ch0, c
         const double de = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(dev)),
                                            __builtin_amdgcn_readfirstlane(__double2loint(dev)));
         if (de >= 0.0) {                    // reset row: Phi <- E (Phi + pending): row scaling only
-            s_e[own] = fm_exp(-cj * de);
+            s_e[own] = fm_exp_local(-cj * de);
             wave_lds_fence();
             double d0, d1;
             sweep7_preload<ROWS>(ub, wb, pe, pw);
@@ -2098,7 +2133,7 @@ k_phiw(const int64_t N, const int64_t chunk_len, const int nch, const int ch0, c
         const double2 *pw = (const double2 *)&ring_r[(n == 0) ? D : (int)((n - 1) & (D - 1))][0] + g;
         if (de >= 0.0) {                    // reset row: Phi <- E (Phi + pending): row scaling only
 #pragma unroll
-            for (int k = 0; k < NL; ++k) s_e[lane + 64 * k] = fm_exp(-ci[k] * de);
+            for (int k = 0; k < NL; ++k) s_e[lane + 64 * k] = fm_exp_local(-ci[k] * de);
             wave_lds_fence();
             double d0, d1;
             sweepw_run<TR, true, 8>(T, pe, pw, q0, q1, 1.0, 1.0, d0, d1);
@@ -2197,7 +2232,7 @@ k_phi(const int64_t N, const int64_t chunk_len, const int nch, const int ch0, co
         const double de = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(dev)),
                                            __builtin_amdgcn_readfirstlane(__double2loint(dev)));
         if (de >= 0.0) {                    // Phi <- E (Phi + pending): row scaling only
-            s_e[lane] = fm_exp(-cj * de);
+            s_e[lane] = fm_exp_local(-cj * de);
             wave_lds_fence();
             sweep_preload<ROWS>(ab, wb, s_e, sw);
             (void)sweep_run<ROWS, true>(T, ab, wb, s_e, sw, q, 1.0);
