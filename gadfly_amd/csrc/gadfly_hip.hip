@@ -3576,21 +3576,25 @@ k_dense_solve(const int n, const int nrhs, const double *__restrict__ A_, double
 
 // Combine of GF_MATMUL_LOWER (dot_tril): the chunk transitions are DIAGONAL (D_c), so the start states are
 // a plain scan  F_{c+1} = loc_c + D_c o F_c  of 64 x R independent scalar sequences.  One workgroup of 16
-// waves per (problem, state row), lane = right-hand side (the states are stored [row][R]: coalesced rows
-// of 8 R bytes; with lane = state row every lane touched its own cache line): the chunks are cut into 16 segments that are
-// scanned concurrently (zero start; eight chunks of loads in flight per wave: the loop is otherwise one
-// dependent memory round trip per chunk), the 16 segment summaries are chained in LDS, and every wave
-// rescans its segment from its true start state, writing the start state of every chunk.
-constexpr int LCM_WAVES = 16, LCM_BATCH = 8;
+// waves per (problem, state row, 16 right-hand sides): a wave's four 16-lane groups take one segment of the
+// chunks each (64 segments per workgroup), lane & 15 = right-hand side (the states are stored [row][R]: 128-byte
+// pieces of a row; with lane = state row every lane touched its own cache line).  The segments are scanned
+// concurrently (zero start; eight chunks of loads in flight per lane: the loop is otherwise one dependent memory
+// round trip per chunk), the 64 segment summaries are chained in LDS, and every group rescans its segment from
+// its true start state, writing the start state of every chunk.  (With lane = right-hand side over all 64 and
+// 16 segments there were 64 workgroups per problem: a quarter of the chip, 45 us at cfg5's size.)
+constexpr int LCM_WAVES = 16, LCM_BATCH = 8, LCM_SEGS = 4 * LCM_WAVES;
 __global__ void __launch_bounds__(64 * LCM_WAVES)
 k_lincombine_mm(const int nch, const int R, const int rows, const double *__restrict__ Dch_,
                 double *__restrict__ F_state) {
     const int pr = blockIdx.x, i = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int r = (lane < R) ? lane : (R - 1);      // idle lanes shadow the last right-hand side (no stores)
-    const bool rok = lane < R;
-    const int seg = (nch + LCM_WAVES - 1) / LCM_WAVES;
-    const int s0 = w * seg, s1 = (s0 + seg < nch) ? (s0 + seg) : nch;
-    __shared__ double s_end[LCM_WAVES][64], s_dec[LCM_WAVES][64];
+    const int rr = lane & 15, sg = 4 * w + (lane >> 4);        // right-hand side within the 16, segment
+    const int rq = 16 * blockIdx.z + rr;
+    const int r = (rq < R) ? rq : (R - 1);          // idle lanes shadow the last right-hand side (no stores)
+    const bool rok = rq < R;
+    const int seg = (nch + LCM_SEGS - 1) / LCM_SEGS;
+    const int s0 = (sg * seg < nch) ? sg * seg : nch, s1 = (s0 + seg < nch) ? (s0 + seg) : nch;
+    __shared__ double s_end[LCM_SEGS][16], s_dec[LCM_SEGS][16];
     auto F_at = [&](int s) { return F_state + ((size_t)pr * nch + s) * rows * R + (size_t)i * R + r; };
     auto D_at = [&](int s) { return Dch_[((size_t)pr * nch + s) * rows + i]; };
     // phase 1: segment end state from a zero start, and the segment's total decay
@@ -3606,12 +3610,12 @@ k_lincombine_mm(const int nch, const int R, const int rows, const double *__rest
 #pragma unroll
         for (int j = 0; j < LCM_BATCH; ++j) { cur = fma(dd[j], cur, loc[j]); dec *= dd[j]; }
     }
-    s_end[w][lane] = cur;
-    s_dec[w][lane] = dec;
+    s_end[sg][rr] = cur;
+    s_dec[sg][rr] = dec;
     __syncthreads();
     // phase 2: this segment's true start state (chain of the summaries before it)
     double start = 0.0;
-    for (int w2 = 0; w2 < w; ++w2) start = fma(s_dec[w2][lane], start, s_end[w2][lane]);
+    for (int g2 = 0; g2 < sg; ++g2) start = fma(s_dec[g2][rr], start, s_end[g2][rr]);
     // phase 3: rescan, leaving the true start state of every chunk in its slot
     cur = start;
     for (int s = s0; s < s1; s += LCM_BATCH) {
@@ -5329,7 +5333,7 @@ int gf_chunk_linear_combine(int mode, int B, int64_t N, int64_t chunk_len, int n
     hipStream_t st = (hipStream_t)stream;
     if (mode == GF_MATMUL_LOWER) {
         hipLaunchKernelGGL(k_chunk_decay, dim3(B * nch), dim3(64), 0, st, N, chunk_len, nch, W, c, de, D_work);
-        hipLaunchKernelGGL(k_lincombine_mm, dim3(B, 64), dim3(64 * LCM_WAVES), 0, st, nch, R, 64, D_work, F_state);
+        hipLaunchKernelGGL(k_lincombine_mm, dim3(B, 64, (R + 15) / 16), dim3(64 * LCM_WAVES), 0, st, nch, R, 64, D_work, F_state);
         return check_launch("gf_chunk_linear_combine");
     }
     hipLaunchKernelGGL(k_lincombine<0>, dim3(B, R), dim3(256), 0, st, nch, nch, mode, R, Phi, D_work, F_state,
@@ -5489,7 +5493,7 @@ int gf_chunk_diag_scan(int B, int nch, int rows, int R, const double *D, double 
     if (B < 1 || nch < 1 || rows < 1 || R < 1 || R > 64)
         return set_err("gf_chunk_diag_scan: bad shape (rows=%s%lld, R=%lld)", "", rows, R);
     if (!D || !F_state) return set_err("gf_chunk_diag_scan: null pointer%s", "");
-    hipLaunchKernelGGL(k_lincombine_mm, dim3(B, rows), dim3(64 * LCM_WAVES), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_lincombine_mm, dim3(B, rows, (R + 15) / 16), dim3(64 * LCM_WAVES), 0, (hipStream_t)stream,
                        nch, R, rows, D, F_state);
     return check_launch("gf_chunk_diag_scan");
 }
