@@ -142,11 +142,7 @@ class BatchedLogLikelihood:
     def pack_parameters(self, S0, w0, Q, delta):
         """Coefficient pack straight from (B, J) hyperparameter arrays (:func:`sho_coefficient_pack`):
         the vectorised form of :meth:`pack` for ``StellarOscillatorKernel``-type kernels."""
-        Jr, Jc, real, comp, diag_add, c = sho_coefficient_pack(S0, w0, Q, delta)
-        eng = self.engine
-        if (Jr, Jc) != (eng.Jr, eng.Jc) or real.shape[1] != eng.B:
-            raise ValueError("coefficient pack does not match the batch structure")
-        pk = _Pack(eng._make_pack(real, comp, diag_add, c))
+        pk = _Pack(self.engine.pack_arrays(*sho_coefficient_pack(S0, w0, Q, delta)))
         pk.psd_safe = bool(np.all(np.asarray(S0) > 0.0) and np.all(np.asarray(w0) > 0.0)
                            and np.all(np.asarray(Q) > 0.0))
         return pk

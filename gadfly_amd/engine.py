@@ -56,6 +56,22 @@ def _coeff_pack(coeffs_list):
     return Jr, Jc, real, comp, diag_add, c
 
 
+def _complexify_pack(Jr, Jc, real, comp, diag_add, c):
+    """The same kernels with every real term a e^{-c tau} written as the complex term (a, b = 0, c, d = 0):
+    two state columns instead of one (the sine column is identically zero), in exchange for a term structure
+    the fused wide sweep takes (k_factorw generates complex terms only).  Stacked arrays in, stacked arrays
+    out (see _coeff_pack)."""
+    B = comp.shape[1]
+    J = Jr + Jc
+    comp2 = np.zeros((4, B, max(J, 1)))
+    comp2[0, :, :Jr], comp2[2, :, :Jr] = real[0, :, :Jr], real[1, :, :Jr]
+    comp2[:, :, Jr:J] = comp[:, :, :Jc]
+    c2 = np.zeros((B, 2 * J))
+    c2[:, 0::2] = comp2[2, :, :J]
+    c2[:, 1::2] = comp2[2, :, :J]
+    return 0, J, np.zeros((2, B, 1)), comp2, diag_add, c2
+
+
 class DeviceBatch:
     """B problems on one GPU.  Every method only *enqueues* work on the current stream;
     results stay on the device until the caller reads them."""
@@ -718,6 +734,15 @@ class StreamingBatch:
                                    else f"cuda:{torch.cuda.current_device()}")   # the rank's own GPU
         self.B = len(coeffs_list)
         self.Jr, self.Jc, real, comp, diag_add, c = _coeff_pack(coeffs_list)
+        # A WIDE kernel with real terms (an overdamped SHO term, Q < 1/2, next to 30+ others) rides on the fused
+        # wide sweep with its real terms written as degenerate complex ones (two columns each, the second all
+        # zeros) rather than on the materialised-row kernels of round 1.
+        self._struct0 = (self.Jr, self.Jc)
+        self._complexified = bool(
+            allow_fused and not force_v1 and self.Jr > 0 and self.Jr + 2 * self.Jc > 63
+            and self.lib.gf_fused_supported(0, self.Jr + self.Jc))
+        if self._complexified:
+            self.Jr, self.Jc, real, comp, diag_add, c = _complexify_pack(self.Jr, self.Jc, real, comp, diag_add, c)
         self.W = self.Jr + 2 * self.Jc
         if self.W < 1 or self.W > _lib.GF_MAX_WIDTH:
             raise ValueError(
@@ -904,9 +929,17 @@ class StreamingBatch:
         return dev(real), dev(comp), dev(diag_add), dev(c), dev(cmax), block, dmax
 
     def pack_coefficients(self, coeffs_list):
-        Jr, Jc, real, comp, diag_add, c = _coeff_pack(coeffs_list)
-        if (Jr, Jc) != (self.Jr, self.Jc) or len(coeffs_list) != self.B:
+        if len(coeffs_list) != self.B:
             raise ValueError("coefficient pack does not match the batch structure")
+        return self.pack_arrays(*_coeff_pack(coeffs_list))
+
+    def pack_arrays(self, Jr, Jc, real, comp, diag_add, c):
+        """Device pack from stacked coefficient arrays of the batch's ORIGINAL term structure (_coeff_pack /
+        batch.sho_coefficient_pack)."""
+        if (Jr, Jc) != self._struct0 or comp.shape[1] != self.B:
+            raise ValueError("coefficient pack does not match the batch structure")
+        if self._complexified:
+            Jr, Jc, real, comp, diag_add, c = _complexify_pack(Jr, Jc, real, comp, diag_add, c)
         return self._make_pack(real, comp, diag_add, c)
 
     def use_coefficients(self, pack):

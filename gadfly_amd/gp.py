@@ -416,7 +416,8 @@ class GaussianProcess:
         W = len(co[0]) + 2 * len(co[2])
         fast = None
         wide = None
-        if W <= 63 or (len(co[0]) == 0 and W <= 176):
+        # (a wide kernel with real terms rides on the fused wide sweep too: engine._complexify_pack)
+        if W <= 63 or 2 * (len(co[0]) + len(co[2])) <= 176:
             torch = _lib.require_device()       # (fails loudly without a HIP device: no CPU path)
             f64 = dict(dtype=torch.float64, device=self._device_of())
             const = getattr(self, "_diag_const", None)

@@ -367,6 +367,60 @@ def test_gaussian_process_wide_kernel(hip, J, N, kw):
     assert gp.log_likelihood(y) == -np.inf
 
 
+def test_wide_kernel_with_real_terms(hip):
+    """A WIDE kernel with overdamped terms (Q < 1/2: two real exponentials each; W = 6 + 66 = 72): the engine
+    writes its real terms as degenerate complex ones (engine._complexify_pack) so that it rides on the fused wide
+    sweep and its stored factor -- through the drop-in class and the batched evaluator (streamed and
+    time-parallel), against the oracle on the ORIGINAL term structure."""
+    import gadfly_amd
+    from gadfly_amd.engine import WideFactor, StreamingBatch
+    from gadfly_amd.terms import SHOTerm, TermSum, TermConvolution
+    from gadfly_amd.synth import solar_like_hyperparameters
+    from oracle import cref, seq
+    prob = util.solar_problem(33, 2400, gaps=True)
+    hp = solar_like_hyperparameters(33)
+    # w0 in rad / (1e6 s): slow, overdamped components next to the solar-like terms
+    terms = [SHOTerm(S0=4.0e3, w0=60.0, Q=0.3), SHOTerm(S0=9.0e2, w0=400.0, Q=0.45), SHOTerm(S0=2.0e2, w0=2500.0, Q=0.2)]
+    terms += [SHOTerm(S0=float(h["hyperparameters"]["S0"]), w0=float(h["hyperparameters"]["w0"]),
+                      Q=float(h["hyperparameters"]["Q"])) for h in hp]
+    k = TermConvolution(TermSum(*terms), 60.0e-6)
+    co = k.get_device_coefficients()
+    assert len(co[0]) == 6 and len(co[0]) + 2 * len(co[2]) == 72
+    t, y, du = prob["t"], prob["y"], prob["diag_user"]
+    n = len(t)
+    ref, info = cref.loglike(co[:6], t, du + co[6], y)
+    assert info == 0
+    eng = StreamingBatch([co, co], t, y, diag=du)
+    assert eng._complexified and eng.Jr == 0 and eng.W == 78 and eng._wide_ok()
+    eng.generator_period = 1
+    ll = eng.log_likelihood().cpu().numpy()
+    assert np.all(np.abs(ll - ref) <= RTOL_LL * abs(ref)), (ll, ref)
+    for two in (False, True):
+        eng.two_sweep = two
+        ll_tp = eng.log_likelihood_time_parallel(chunk_len=256).cpu().numpy()
+        assert np.all(np.abs(ll_tp - ref) <= RTOL_LL * abs(ref)), (two, ll_tp, ref)
+    pack = eng.pack_coefficients([co, co])              # packs of the original structure are accepted
+    eng.use_coefficients(pack)
+    assert abs(float(eng.log_likelihood()[1]) - ref) <= RTOL_LL * abs(ref)
+    # the drop-in class: stored factor, solves, conditional mean at new times
+    gp = gadfly_amd.GaussianProcess(k, t=t, diag=du)
+    assert isinstance(gp._factor, WideFactor)
+    prob2 = dict(kernel=k, t=t, diag_user=du)
+    c, a, U, V = util.oracle_matrices(prob2, seq)
+    d_ref, W_ref, _ = cref.factor(t, c, a, U, V)
+    assert abs(gp.log_likelihood(y) - ref) <= RTOL_LL * abs(ref)
+    rng = np.random.default_rng(5)
+    Y = rng.normal(size=(n, 3))
+    ref_ai = cref.solve_upper(t, c, U, W_ref, cref.solve_lower(t, c, U, W_ref, Y) / d_ref[:, None])
+    assert _relmax(gp.apply_inverse(Y), ref_ai) < TOL_VEC
+    ref_dt = cref.matmul_lower(t, c, U, W_ref, Y * np.sqrt(d_ref)[:, None])
+    assert _relmax(gp.dot_tril(Y), ref_dt) < TOL_VEC
+    alpha = cref.solve_upper(t, c, U, W_ref, cref.solve_lower(t, c, U, W_ref, y) / d_ref)
+    ts = np.sort(rng.uniform(t[0], t[-1], 40))
+    _, _, Us, Vs = seq.celerite_matrices(co[:6], ts, 0.0)
+    assert _relmax(gp.predict(y, t=ts), cref.general_matmul(ts, t, c, Us, Vs, U, V, alpha)) < TOL_VEC
+
+
 @pytest.mark.parametrize("J,N,L,kw", [(40, 3000, 256, dict()), (86, 2600, 192, dict(gaps=True)),
                                       (33, 2100, 128, dict(jitter_t=True)), (64, 1500, 512, dict(yerr=0.0)),
                                       (86, 20000, None, dict())],
