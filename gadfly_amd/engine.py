@@ -1236,15 +1236,10 @@ class StreamingBatch:
     tree_min_chunks = 24
 
     def _clear_slots(self, x, nch, *slots):
-        """Zero the chunk slots `slots` of every problem in x ([B * nch, n]) with ONE kernel (a strided
-        `zero_()` becomes one memset per problem: 64 launches per evaluation on a 32-problem shard)."""
-        key = (nch,) + slots
-        idx = getattr(self, "_slot_idx", {}).get(key)
-        if idx is None:
-            if not hasattr(self, "_slot_idx"):
-                self._slot_idx = {}
-            idx = self._slot_idx[key] = self.torch.tensor(slots, dtype=self.torch.int64, device=self.device)
-        x.view(self.B, nch, -1).index_fill_(1, idx, 0.0)
+        """Zero the chunk slots `slots` of every problem in x ([B * nch, n]): one strided fill kernel each."""
+        v = x.view(self.B, nch, -1)
+        for s in slots:
+            v[:, s].zero_()
 
     def _tp_combine(self, w, nch, st):
         """S/F slot c <- true start state of chunk c (sequential or tree LFT combine)."""
