@@ -726,7 +726,7 @@ class StreamingBatch:
     """
 
     def __init__(self, coeffs_list, t, y, diag=None, tile_rows=8192, device=None,
-                 force_v1=False, overlap_build=False, allow_fused=True, dt_median=None):
+                 force_v1=False, overlap_build=False, allow_fused=True, axis_stats=None):
         torch = _lib.require_device()
         self.torch = torch
         self.lib = _lib.load()
@@ -774,7 +774,9 @@ class StreamingBatch:
 
         t = rows(t, "t")
         self.N = int(t.shape[1])
-        self._tmax = float(t.abs().max())
+        # (largest |t| and the median spacing: two reductions with a host synchronisation each -- a caller that
+        # factorises the same time axis again, GaussianProcess.recompute(), passes what `axis_stats` held the first time)
+        self._tmax = float(t.abs().max()) if axis_stats is None else float(axis_stats[0])
         self.t, self._tpad = padded(t)
         y = rows(y, "y")
         if y.shape[1] != self.N:
@@ -819,12 +821,11 @@ class StreamingBatch:
         self.tile_rows = T
         # typical cadence (median spacing) sets how many rows a scaled block may span
         tt = self.t[0]
-        # (a sort of N spacings and a host synchronisation: a caller that factorises the same time axis again
-        # -- GaussianProcess.recompute() -- passes the value it got the first time)
-        if dt_median is not None:
-            self._dt_med = float(dt_median)
+        if axis_stats is not None:
+            self._dt_med = float(axis_stats[1])
         else:
             self._dt_med = float(torch.median(tt[1:] - tt[:-1])) if self.N > 1 else 0.0
+        self.axis_stats = (self._tmax, self._dt_med)
         self._pack = self._make_pack(*self._coeff_host)
 
         def rows_buf():

@@ -422,14 +422,14 @@ class GaussianProcess:
             f64 = dict(dtype=torch.float64, device=self._device_of())
             const = getattr(self, "_diag_const", None)
             if self._t_dev is None:         # (recompute() with another kernel: t, diag are on the device already)
-                self._dt_median = None
+                self._axis_stats = None
                 self._t_dev = torch.as_tensor(self._t).to(**f64)
                 self._diag_dev = (torch.as_tensor(self._diag).to(**f64) if const is None
                                   else torch.full((self._size,), const, **f64))
             fast = StreamingBatch([co], self._t_dev, torch.zeros((self._size,), **f64),
                                   diag=self._diag_dev, device=self._device,
-                                  dt_median=getattr(self, "_dt_median", None))
-            self._dt_median = fast._dt_med      # (the same time axis until compute() is called again)
+                                  axis_stats=getattr(self, "_axis_stats", None))
+            self._axis_stats = fast.axis_stats  # (the same time axis until compute() is called again)
             if fast._wide_ok() and not fast._fused_ok():
                 # wide kernel (e.g. the 86-term solar kernel, W = 172): ONE pass of the fused wide sweep
                 # factorises and stores the factor in scaled form; solves run on it (engine.WideFactor)
