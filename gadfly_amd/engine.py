@@ -361,7 +361,7 @@ class ScaledFactor:
             return torch.cat([self._sweep(mode, Y[:, :, r0:r0 + self.RMAX].contiguous(), scale)
                               for r0 in range(0, R, self.RMAX)], dim=2)
         Y = Y.contiguous()
-        Z = torch.empty_like(Y)
+        Z = None                        # (allocated behind the local pass' launch: the device starts earlier)
         f64 = dict(dtype=torch.float64, device=self.device)
         chunk_len, nch = self.chunk_len, self.nch
         if mode == _lib.GF_MATMUL_LOWER and nch > 1:
@@ -377,8 +377,9 @@ class ScaledFactor:
         args = (mode, B, N, chunk_len, nch, self.W, R)
         rows = (p(self.c), p(self.Ut), p(self.Wt), p(self.d), p(self.de))
         if nch > 1:
-            rc = lib.gf_chunk_linear(*args, int(scale), 0, *rows, p(Y), p(Z), p(F), st)
+            rc = lib.gf_chunk_linear(*args, int(scale), 0, *rows, p(Y), p(Y), p(F), st)    # (writes no rows)
             _lib.check(rc, "gf_chunk_linear")
+            Z = torch.empty_like(Y)
             fresh_D = False
             if mode == _lib.GF_MATMUL_LOWER and (self._D is None or self._D_key != (chunk_len, nch)):
                 # the chunks' diagonal transitions belong to the factor and this chunking: formed once
@@ -398,6 +399,8 @@ class ScaledFactor:
                     None if mode == _lib.GF_MATMUL_LOWER else p(self.Phi),
                     p(self._D) if mode == _lib.GF_MATMUL_LOWER else None, p(F), st)
                 _lib.check(rc, "gf_chunk_linear_combine")
+        if Z is None:
+            Z = torch.empty_like(Y)
         rc = lib.gf_chunk_linear(*args, int(scale), 1, *rows, p(Y), p(Z), p(F), st)
         _lib.check(rc, "gf_chunk_linear")
         return Z
