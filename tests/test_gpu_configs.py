@@ -367,6 +367,42 @@ def test_gaussian_process_wide_kernel(hip, J, N, kw):
     assert gp.log_likelihood(y) == -np.inf
 
 
+@pytest.mark.parametrize("J,N,tile,kw", [(40, 2600, 512, dict()), (33, 1900, 8192, dict(jitter_t=True)),
+                                          (64, 2100, 640, dict(gaps=True)), (86, 1500, 256, dict(yerr=0.0)),
+                                          (50, 3000, 1024, dict(gaps=True)), (72, 1200, 8192, dict())],
+                         ids=["W80", "W66-jitter", "W128-gaps", "W172-yerr0", "W100-gaps", "W144"])
+def test_wide_streamed_log_likelihood(hip, J, N, tile, kw):
+    """The streamed log-likelihood of wide kernels (k_factorw without row stores) against the oracle at six widths,
+    over several tiles (state hand-off through the slots), with gaps and jittered stamps, every pivot / z row of
+    a one-tile run, and a failing pivot.  (Round 3's archived blocked sweep, csrc/experimental, was developed
+    against this test.)"""
+    from gadfly_amd.engine import StreamingBatch
+    from oracle import cref, seq
+    prob = util.solar_problem(J, N, **kw)
+    k, t, y = prob["kernel"], prob["t"], prob["y"]
+    co = k.get_device_coefficients()
+    eng = StreamingBatch([co, co], t, y, diag=prob["diag_user"], tile_rows=tile)
+    assert eng._wide_ok() and not eng._fused_ok()
+    eng.force_streaming = True
+    ll = eng.log_likelihood().cpu().numpy()
+    ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y)
+    assert info == 0 and np.all(np.abs(ll - ref) <= RTOL_LL * abs(ref)), (ll, ref)
+    if tile >= len(t):                                  # one tile: the rows d, z of the whole series are there
+        c, a, U, V = util.oracle_matrices(prob, seq)
+        d_ref, W_ref, _ = cref.factor(t, c, a, U, V)
+        z_ref = cref.solve_lower(t, c, U, W_ref, y)
+        n = len(t)
+        assert _relmax(eng.d[0, :n].cpu().numpy(), d_ref) < 1e-9
+        assert _relmax(eng.z[1, :n].cpu().numpy(), z_ref) < 1e-8
+    # a matrix that is not positive definite stops at the oracle's row
+    bad = prob["diag_user"].copy()
+    bad[len(t) // 2:] = -2.0 * k.get_value(np.zeros(1))[0]
+    engb = StreamingBatch([co], t, y, diag=bad, tile_rows=tile)
+    engb.force_streaming = True
+    llb = engb.log_likelihood()
+    assert float(llb[0]) == float("-inf") and int(engb.info[0]) == len(t) // 2 + 1
+
+
 def test_wide_kernel_with_real_terms(hip):
     """A WIDE kernel with overdamped terms (Q < 1/2: two real exponentials each; W = 6 + 66 = 72): the engine
     writes its real terms as degenerate complex ones (engine._complexify_pack) so that it rides on the fused wide
