@@ -340,6 +340,7 @@ class ScaledFactor:
         self.device = owner.device
         self.B, self.N, self.W = owner.B, owner.N, owner.W
         self.chunk_len, self.nch = chunk_len, nch
+        self.block = int(owner._pack[5])        # scaling block of the stored rows: reset rows at its multiples
         w = owner._tp
         self.Ut, self.Wt, self.de, self.Phi = w["Ut"], w["Wt"], w["de"], w["PhiT"]
         # own copy of the pivots: the shared buffer holds the nominal pass' values while a later
@@ -426,12 +427,14 @@ class ScaledFactor:
 
     def _mm_chunking(self, R):
         """Chunks for the dot_tril sweeps: ~2048 waves (two per SIMD) over B problems and the RHS
-        tiles, at least 128 rows each, on multiples of 64 rows (every chunk starts on a reset row)."""
-        # (R >= 16 runs on the matrix pipe, one wave per SIMD: k_mmR_mfma)
+        tiles, at least 128 rows each, on multiples of the scaling block (every chunk starts on a reset row;
+        rounding to 64 left 5 % of the workgroup slots empty at cfg5's size)."""
+        # (R >= 16 runs on the matrix pipe, two-wave workgroups: k_mmR_mfma)
         tiles = -(-R // 64) if R > 1 else 1
         want = max(1, (1024 if R >= 16 else 2048) // (self.B * tiles))
+        q = max(self.block, 16)
         chunk_len = max(128, -(-self.N // want))
-        chunk_len = (chunk_len + 63) // 64 * 64
+        chunk_len = (chunk_len + q - 1) // q * q
         return chunk_len, -(-self.N // chunk_len)
 
     def solve_lower(self, Y):
