@@ -113,25 +113,48 @@ def hipcc_command(out=SO_PATH):
     return ["hipcc"] + HIPCC_FLAGS + ["-shared", "-o", out] + SOURCES
 
 
+def _source_hash(src):
+    """SHA-256 over a translation unit, the headers it includes and the compiler flags: what its object is
+    a function of (file times say nothing after a checkout or a copy to another machine)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for path in [src] + _DEPS:
+        with open(path, "rb") as fh:
+            h.update(b"\0" + os.path.basename(path).encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
     """Compile the HIP library for gfx950 in-tree (cross-compiles without a GPU): one object per
-    translation unit (rebuilt only when its source or a shared header changed), then the link."""
-    deps = max(os.path.getmtime(p) for p in _DEPS)
-    objs, relink = [], force or not os.path.exists(SO_PATH)
+    translation unit, rebuilt when the hash of its source + shared headers + flags differs from the one
+    recorded beside the object (``<unit>.o.srchash``), then the link (recorded the same way beside the library)."""
+    objs, hashes = [], []
     for src in SOURCES:
         obj = os.path.splitext(src)[0] + ".o"
+        tag = obj + ".srchash"
+        want = _source_hash(src)
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), deps):
+        hashes.append(want)
+        have = open(tag).read().strip() if os.path.exists(tag) else None
+        if force or not os.path.exists(obj) or have != want:
             cmd = ["hipcc"] + HIPCC_FLAGS + ["-c", "-o", obj, src]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
-            relink = True
-    if relink or os.path.getmtime(SO_PATH) < max(os.path.getmtime(o) for o in objs):
+            with open(tag, "w") as fh:
+                fh.write(want + "\n")
+    tag = SO_PATH + ".srchash"
+    want = " ".join(hashes)
+    have = open(tag).read().strip() if os.path.exists(tag) else None
+    if force or not os.path.exists(SO_PATH) or have != want:
         cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", SO_PATH] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        with open(tag, "w") as fh:
+            fh.write(want + "\n")
+    elif verbose:
+        print(f"{SO_PATH}: up to date with its sources (hash {hashes[0][:12]} ...)")
     return SO_PATH
 
 

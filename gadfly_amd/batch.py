@@ -79,15 +79,35 @@ class _Pack(tuple):
     psd_safe = False
 
 
-def _sho_only(kernel):
-    """True for the kernels gadfly builds: [TermConvolution of] a sum of SHO terms with S0, w0, Q > 0 -- a
-    covariance function, so K + diag(>= 0) is positive semi-definite whatever the hyperparameters."""
+def _sho_only(kernel, dt_min=None, t_abs_max=0.0):
+    """True when K + diag(>= 0) is positive semi-definite BY CONSTRUCTION: a sum of SHO terms with S0, w0, Q > 0
+    is a covariance function whatever the hyperparameters; its exposure-integrated form (``TermConvolution``,
+    every kernel gadfly builds) is one only where the celerite coefficients represent it exactly, i.e. for lags
+    >= delta -- closer time stamps get the un-integrated form's continuation, which need not be a covariance
+    (``TermConvolution(SHOTerm(S0=1, w0=2, Q=0.7), 1)`` on ``arange(200) * 0.2`` has 33 negative eigenvalues).
+    ``dt_min``: the smallest spacing of the time axis the kernel is evaluated on (None: unknown -> False for an
+    integrated kernel); spacings within the rounding of the time stamps of delta count as delta."""
     from .terms import SHOTerm, TermConvolution
-    base = kernel.term if isinstance(kernel, TermConvolution) else kernel
+    base = kernel
+    if isinstance(kernel, TermConvolution):
+        base = kernel.term
+        if not _exposure_resolved(float(kernel.delta), dt_min, t_abs_max):
+            return False
     terms = getattr(base, "terms", None)
     if terms is None:
         terms = (base,)
     return len(terms) > 0 and all(type(t) is SHOTerm and t.S0 > 0.0 and t.w0 > 0.0 and t.Q > 0.0 for t in terms)
+
+
+def _exposure_resolved(delta, dt_min, t_abs_max=0.0):
+    """No two time stamps closer than the exposure time ``delta`` (up to the rounding of the stamps themselves:
+    a one-minute cadence on a JD-based axis jitters by 5e-7 of the spacing)."""
+    if delta <= 0.0:
+        return True
+    if dt_min is None:
+        return False
+    tol = max(1e-9 * delta, 4.0 * float(np.spacing(abs(t_abs_max))))
+    return dt_min >= delta - tol
 
 
 class BatchedLogLikelihood:
@@ -115,10 +135,17 @@ class BatchedLogLikelihood:
                                      y - mean, diag=d, tile_rows=tile_rows, device=device,
                                      overlap_build=overlap_build)
         #: the time-parallel route may drop its final pass (engine.two_sweep) when the matrix is positive
-        #: semi-definite by construction: SHO kernels and a non-negative diagonal.  A non-finite result of such
-        #: an evaluation (rounding can still break a pivot) is repeated with the final pass by :meth:`resolve`
+        #: semi-definite by construction: SHO kernels, a non-negative diagonal, no two time stamps closer than
+        #: the exposure time.  Rounding can still break a pivot: the corrections check the sign of EVERY pivot
+        #: of a chunk (a Cholesky attempt on (I - X G) X, gadfly_dense.hip: k_spd_check), not only the parity
+        #: det(I - X G) gives, and a chunk that fails it leaves a non-finite value, which :meth:`resolve` repeats
+        #: with the final pass
         self._diag_nonneg = d is None or bool(np.all(np.asarray(d) >= 0.0))
-        self._init_safe = self._diag_nonneg and all(_sho_only(k) for k in kernels)
+        #: smallest spacing of the time axes and their largest |t|: an exposure-integrated kernel is a covariance
+        #: only while no two stamps are closer than its exposure time (see _sho_only)
+        self._dt_min = float(np.min(np.diff(t, axis=-1))) if t.shape[-1] > 1 else None
+        self._t_abs_max = float(np.max(np.abs(t))) if t.size else 0.0
+        self._init_safe = self._diag_nonneg and all(_sho_only(k, self._dt_min, self._t_abs_max) for k in kernels)
         self.two_sweep = True
         #: keep the row generator's share of the relative log-likelihood error below this by
         #: choosing its re-anchoring period from the measured conditioning
@@ -136,7 +163,7 @@ class BatchedLogLikelihood:
 
     def pack(self, kernels):
         pk = _Pack(self.engine.pack_coefficients([k.get_device_coefficients() for k in kernels]))
-        pk.psd_safe = all(_sho_only(k) for k in kernels)
+        pk.psd_safe = all(_sho_only(k, self._dt_min, self._t_abs_max) for k in kernels)
         return pk
 
     def pack_parameters(self, S0, w0, Q, delta):
@@ -144,7 +171,9 @@ class BatchedLogLikelihood:
         the vectorised form of :meth:`pack` for ``StellarOscillatorKernel``-type kernels."""
         pk = _Pack(self.engine.pack_arrays(*sho_coefficient_pack(S0, w0, Q, delta)))
         pk.psd_safe = bool(np.all(np.asarray(S0) > 0.0) and np.all(np.asarray(w0) > 0.0)
-                           and np.all(np.asarray(Q) > 0.0))
+                           and np.all(np.asarray(Q) > 0.0)
+                           and all(_exposure_resolved(float(dl), self._dt_min, self._t_abs_max)
+                                   for dl in np.atleast_1d(np.asarray(delta, dtype=np.float64))))
         return pk
 
     def evaluate_device(self, pack=None):
@@ -184,7 +213,8 @@ class BatchedLogLikelihood:
             flag = None
             if period > 1:
                 # a non-positive pivot (failed factorisation: -inf either way) is not an accuracy case
-                flag = (eng.GEN_ERR * period * amax > self.generator_target * dmin) & (dmin > 0)
+                # (GEN_ERR * period + the phase-quantum term of a time axis far from zero: engine.PHASE_ERR)
+                flag = (eng.generator_error_coefficient(period) * amax > self.generator_target * dmin) & (dmin > 0)
             if getattr(eng, "_two_sweep_used", False):
                 # no final pass ran: a pivot that rounding pushed below zero inside a chunk shows up as a
                 # non-finite value (det(I - X G) <= 0) -- repeated with the final pass by resolve()

@@ -5,24 +5,30 @@
 // Argument reduction by pi/2 with FMA: fn = rint(x 2/pi); x - fn P1 is formed EXACTLY inside one fma
 // (P1 = pi/2 rounded to 53 bits), the remaining fn (P2 + P3) -- pi/2 to 159 bits -- is taken off in
 // double-double arithmetic (fn P2 split exactly by a second fma), so the remainder y0 + y1 carries no
-// cancellation error for any |x| < 2^31 pi/2 ~ 3.37e9 (beyond, the quadrant no longer fits an int).
-// Then the classic minimax kernels on [-pi/4, pi/4].  <= 1 ulp against long-double libm over +-3e9,
-// including the doubles closest to multiples of pi/2 (oracle/fastmath_check.c).  (The previous
+// cancellation error: fn (P1 + P2 + P3) misses fn pi/2 by |fn| 2^-160, i.e. 4e-37 at |x| = 1e12, against a
+// remainder that no double below 1e12 brings under ~1e-20.  The quadrant fn mod 4 is read from the low
+// mantissa bits of fn + 1.5 2^52 (two's complement there: exact for |fn| < 2^51, no float -> int conversion
+// whose range would cap the argument -- round 3 took (int)fn and stopped at 2^31 pi/2 = 3.37e9, below the
+// 4-5e9 rad a JD-based time axis reaches with the solar p-modes, /root/reference/gadfly/gp.py:79-80).
+// Then the classic minimax kernels on [-pi/4, pi/4] (|r| may exceed pi/4 by ulp(x 2/pi) / 2 <= 6e-5 when the
+// rounded product picks the neighbouring fn: inside the kernels' margin).  <= 1 ulp against long-double libm
+// over +-1e12, including the doubles closest to multiples of pi/2 (oracle/fastmath_check.c).  (The previous
 // three-round Cody-Waite scheme with 33-bit pieces was exact without FMA but stopped at 2^20 pi/2 =
 // 1.6e6 -- a 1e6-point series at one-minute cadence already exceeds it with the solar p-modes -- and
 // cost five more operations.)
-#define FM_SINCOS_RANGE 3.0e9
+#define FM_SINCOS_RANGE 1.0e12
 FM_INLINE void fm_sincos(double x, double *sn, double *cs) {
     const double invpio2 = 6.36619772367581382433e-01;
     const double P1 = 1.5707963267948966e+00;       // 0x3FF921FB54442D18
     const double P2 = 6.123233995736766e-17;        // 0x3C91A62633145C07
     const double P3 = -1.4973849048591698e-33;      // 0xB91F1976B7ED8FBC
-    double y0, y1, fn;
+    double y0, y1, fn, qm;
     {
 #ifdef __clang__
 #pragma clang fp contract(off)                      // the error terms below rely on every rounding as written
 #endif
         fn = rint(x * invpio2);
+        qm = fn + 6755399441055744.0;               // 1.5 * 2^52: fn's integer bits land in the low mantissa
         const double r0 = fma(-fn, P1, x);          // exact difference, one rounding
         const double h = fn * P2;
         const double l = fma(fn, P2, -h);           // fn P2 = h + l exactly
@@ -47,7 +53,9 @@ FM_INLINE void fm_sincos(double x, double *sn, double *cs) {
     const double hz = 0.5 * z;
     const double wc = 1.0 - hz;
     const double kc = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
-    const int q = ((int)fn) & 3;
+    unsigned long long qb;
+    __builtin_memcpy(&qb, &qm, sizeof(qb));
+    const int q = (int)(qb & 3ull);
     const double s_ = (q & 1) ? kc : ks;
     const double c_ = (q & 1) ? ks : kc;
     *sn = (q & 2) ? -s_ : s_;

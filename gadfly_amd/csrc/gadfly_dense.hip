@@ -694,6 +694,156 @@ int tree_scan(const TreePlan &T, const Maps &M0, double *Xs0, double *Ys0, doubl
 }
 
 // ------------------------------------------------------------------------------------------------
+// Is every pivot of a chunk positive?  det(I - X G) > 0 only says that the NUMBER of non-positive pivots of the
+// chunk is even.  With X (the true start state) and G (the nominal pass' Gram sums) symmetric positive
+// semi-definite and X = R R^T, the non-zero eigenvalues of X G are those of the symmetric R^T G R, and the number
+// of them >= 1 IS the number of non-positive pivots of the chunk (each row is a rank-one step of G and
+// d_n / dbar_n the ratio of successive determinants).  So:  all pivots positive  <=>  M = I - R^T G R positive
+// definite, which an unpivoted Cholesky attempt decides (k_spd_check; M's eigenvalues 1 - mu_i lie in (0, 1] for a
+// healthy chunk: a well-scaled test, pivots compared with their own diagonal entry).
+//   k_pchol      R by Cholesky with diagonal pivoting, stopped where the largest remaining diagonal entry has
+//                fallen to PCHOL_TOL of its original value: X is a covariance of state ESTIMATES and numerically
+//                rank-deficient whenever fewer combinations of the data are informative than there are states (an
+//                un-pivoted attempt on the congruent form (I - X G) X fails on healthy chunks for that reason);
+//                the factor is written transposed (Rt[k][i] = R[i][k], zero rows past the rank) for the GEMM tiles
+//   two GEMM jobs    T = G Rt^T,  M = I - Rt T
+// A failed attempt marks the chunk's log det correction NaN: the caller repeats the evaluation with a final pass,
+// which names the failing row the way celerite2 does (/root/reference/gadfly/gp.py:188-192).  A rounding-level
+// false alarm costs that repeat, never a wrong value.  One workgroup per map, the lower triangle packed by rows in
+// (dynamic) LDS: n (n + 1) / 2 + 2 n doubles.
+// ------------------------------------------------------------------------------------------------
+constexpr int SPD_THREADS = 512;
+constexpr double SPD_TOL = 1e-12;       // ~ 30 n eps at n = 176: pivots this far inside rounding count as zero
+constexpr double PCHOL_TOL = 1e-13;     // relative size of a remaining diagonal entry of X that still gets a column
+
+__global__ void __launch_bounds__(SPD_THREADS)
+k_pchol(const int P, const int first, const int count, const int n, const double *__restrict__ X_,
+        double *__restrict__ Rt_) {
+    const int pr = blockIdx.x / count, c = first + (blockIdx.x - pr * count);
+    const size_t mp = (size_t)pr * P + c;
+    const double *__restrict__ X = X_ + mp * (size_t)n * n;
+    double *__restrict__ Rt = Rt_ + mp * (size_t)n * n;
+    extern __shared__ __attribute__((aligned(16))) double spd_lds[];
+    double *T = spd_lds;                            // T[i (i + 1) / 2 + j], j <= i
+    double *d0 = spd_lds + (size_t)n * (n + 1) / 2; // 1 / original diagonal (0: row not in play)
+    double *col = d0 + n;                           // the current column of R
+    __shared__ double s_val[SPD_THREADS / 64];
+    __shared__ int s_idx[SPD_THREADS / 64];
+    __shared__ int s_done[192];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NWV = blockDim.x >> 6;
+    for (int i = wave; i < n; i += NWV)
+        for (int j = lane; j <= i; j += 64) T[i * (i + 1) / 2 + j] = X[(size_t)i * n + j];
+    __syncthreads();
+    for (int i = tid; i < n; i += blockDim.x) {
+        const double v = T[i * (i + 1) / 2 + i];
+        const bool live = v > 0.0;                  // (zero: padding / a zero state; negative: rounding of a null direction)
+        d0[i] = live ? 1.0 / v : 0.0;
+        s_done[i] = live ? 0 : 1;
+    }
+    __syncthreads();
+    int k = 0;
+    for (; k < n; ++k) {
+        // largest remaining diagonal entry relative to its original value
+        if (tid < 192) {
+            double v = -1.0;
+            int ix = tid;
+            if (tid < n && !s_done[tid]) v = T[tid * (tid + 1) / 2 + tid] * d0[tid];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const double ov = __shfl_xor(v, m);
+                const int oi = __shfl_xor(ix, m);
+                if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+            }
+            if (lane == 0) { s_val[wave] = v; s_idx[wave] = ix; }
+        }
+        __syncthreads();
+        double best = s_val[0];
+        int p = s_idx[0];
+#pragma unroll
+        for (int w = 1; w < 3; ++w)
+            if (s_val[w] > best || (s_val[w] == best && s_idx[w] < p)) { best = s_val[w]; p = s_idx[w]; }
+        if (!(best > PCHOL_TOL)) break;             // (uniform) numerical rank reached
+        const double piv = T[p * (p + 1) / 2 + p];
+        const double r = 1.0 / sqrt(piv);
+        for (int i = tid; i < n; i += blockDim.x) {
+            double v = 0.0;
+            if (!s_done[i]) v = (i >= p ? T[i * (i + 1) / 2 + p] : T[p * (p + 1) / 2 + i]) * r;
+            col[i] = v;
+            Rt[(size_t)k * n + i] = v;
+        }
+        __syncthreads();
+        if (tid == 0) s_done[p] = 1;
+        // trailing update of the rows still in play (row p itself is finished: its column stays in `col` this step)
+        for (int i = wave; i < n; i += NWV) {
+            if (s_done[i] || i == p) continue;      // (wave-uniform)
+            const double ci = col[i];
+            double *row = T + i * (i + 1) / 2;
+            for (int j = lane; j <= i; j += 64) row[j] = fma(-ci, col[j], row[j]);
+        }
+        __syncthreads();
+    }
+    for (int e = k * n + tid; e < n * n; e += blockDim.x) Rt[e] = 0.0;     // rows past the numerical rank
+}
+
+__global__ void __launch_bounds__(SPD_THREADS)
+k_spd_check(const int P, const int first, const int count, const int n, const double *__restrict__ M_,
+            double *__restrict__ ld) {
+    const int pr = blockIdx.x / count, c = first + (blockIdx.x - pr * count);
+    const size_t mp = (size_t)pr * P + c;
+    const double *__restrict__ S = M_ + mp * (size_t)n * n;
+    extern __shared__ __attribute__((aligned(16))) double spd_lds[];
+    double *T = spd_lds;                            // T[i (i + 1) / 2 + j], j <= i
+    double *d0 = spd_lds + (size_t)n * (n + 1) / 2; // original diagonal
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NWV = blockDim.x >> 6;
+    if (tid == 0) s_fail = 0;
+    for (int i = wave; i < n; i += NWV)             // rows: coalesced pieces of the lower triangle
+        for (int j = lane; j <= i; j += 64) T[i * (i + 1) / 2 + j] = S[(size_t)i * n + j];
+    __syncthreads();
+    for (int i = tid; i < n; i += blockDim.x) {
+        const double v = T[i * (i + 1) / 2 + i];
+        d0[i] = v;
+        if (!(v > 0.0)) s_fail = 1;                 // non-positive (or NaN) diagonal: not positive definite
+    }
+    __syncthreads();
+    for (int k = 0; k < n && !s_fail; ++k) {
+        const double piv = T[k * (k + 1) / 2 + k];
+        if (!(piv > SPD_TOL * d0[k])) {             // (uniform: every thread reads the same two values)
+            __syncthreads();
+            if (tid == 0) s_fail = 1;
+            __syncthreads();
+            break;
+        }
+        const double r = 1.0 / sqrt(piv);
+        __syncthreads();                            // everyone has read the pivot
+        for (int i = k + 1 + tid; i < n; i += blockDim.x) T[i * (i + 1) / 2 + k] *= r;      // column k of L
+        __syncthreads();
+        // trailing update: rows dealt over the waves, a row's columns over the lanes; the lane's entries of
+        // column k are kept in registers (j = k + 1 + lane + 64 q)
+        double lk[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int j = k + 1 + lane + 64 * q;
+            lk[q] = (j < n) ? T[j * (j + 1) / 2 + k] : 0.0;
+        }
+        for (int i = k + 1 + wave; i < n; i += NWV) {
+            const double lik = T[i * (i + 1) / 2 + k];
+            double *row = T + i * (i + 1) / 2;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int j = k + 1 + lane + 64 * q;
+                if (j <= i) row[j] = fma(-lik, lk[q], row[j]);
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid == 0 && s_fail) ld[mp] = __longlong_as_double(0x7ff8000000000000LL);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Log-likelihood of a chunked series WITHOUT a final pass.  With (X, Y) the true start state of a chunk and
 // (G, m) its Gram sums from the nominal pass (zero start), the chunk's sums over its rows satisfy
 //     sum log d_n     = sum log dbar_n        + log det(I - X G)
@@ -733,14 +883,14 @@ k_corr_finish(const int P, const int first, const int count, const int WP, const
 
 // corrections of the chunks first .. first + count - 1 of every problem, added to acc [B][3] (sum log d,
 // sum z^2 / d, min d: the accumulators of gf_reduce_tile); maps [B * P][WP x WP] / [B * P][WP]; work:
-// n (WP^2 + 18 WP + 1) doubles for n = B P
-size_t corrections_work(size_t n, int WP) { return n * ((size_t)WP * WP + 18 * (size_t)WP + 1); }
+// n (3 WP^2 + 18 WP + 1) doubles for n = B P
+size_t corrections_work(size_t n, int WP) { return n * (3 * (size_t)WP * WP + 18 * (size_t)WP + 1); }
 
 int chunk_corrections(int B, int P, int WP, int first, int count, const double *X, const double *Y,
                       const double *G, const double *m, double *acc, double *work, hipStream_t st) {
     if (count < 1) return 0;
     const long long n = (long long)B * P, msz = (long long)WP * WP;
-    double *A = work, *R = A + n * msz, *ev = R + n * WP * 16, *u1 = ev + n * WP, *ld = u1 + n * WP;
+    double *A = work, *R = A + n * msz, *ev = R + n * WP * 16, *u1 = ev + n * WP, *ld = u1 + n * WP, *Rt = ld + n, *Mx = Rt + n * msz;
     const long long sR = (long long)WP * 16;
     {   // A = I - X G ; e = Y - X m (X symmetric: the coalesced mat-vec form), once as the right-hand side
         JobBuilder jb;
@@ -755,6 +905,27 @@ int chunk_corrections(int B, int P, int WP, int first, int count, const double *
         JobBuilder jb;
         jb.matvec(1, WP, WP, 1.0, G, WP, msz, R, 16, sR, nullptr, 0, u1, 1, WP);
         jb.launch(n, st);
+    }
+    {   // every pivot of the chunk positive?  X = R R^T (rank-revealing), M = I - R^T G R, Cholesky attempt on M;
+        // a failed attempt turns the chunk's log det correction into NaN  (T reuses A: the solve is done with it)
+        double *Tm = A;
+        const size_t lds = sizeof(double) * ((size_t)WP * (WP + 1) / 2 + 2 * (size_t)WP);
+        const void *fn[2] = {(const void *)k_pchol, (const void *)k_spd_check};
+        if (lds > 64 * 1024 && !gf_internal_lds_opt_in(2, st, fn, 2, sizeof(double) * (192 * 193 / 2 + 2 * 192)))     // (the widest map: 151 KB)
+            return gf_internal_error(-1, "chunk corrections: cannot opt in to %lld bytes of LDS", (long long)lds);
+        const int threads = WP <= 64 ? 256 : SPD_THREADS;
+        hipLaunchKernelGGL(k_pchol, dim3((unsigned)(B * count)), dim3(threads), lds, st, P, first, count, WP, X, Rt);
+        {
+            JobBuilder jb;
+            jb.gemm(0, 1, EPI_PLAIN, WP, WP, WP, G, WP, msz, Rt, WP, msz, nullptr, 0, 0, Tm, WP, msz);
+            jb.launch(n, st);
+        }
+        {
+            JobBuilder jb;
+            jb.gemm(0, 0, EPI_IMINUS, WP, WP, WP, Rt, WP, msz, Tm, WP, msz, nullptr, 0, 0, Mx, WP, msz);
+            jb.launch(n, st);
+        }
+        hipLaunchKernelGGL(k_spd_check, dim3((unsigned)(B * count)), dim3(threads), lds, st, P, first, count, WP, Mx, ld);
     }
     hipLaunchKernelGGL(k_corr_finish, dim3(B), dim3(256), 0, st, P, first, count, WP, Y, m, ev, u1, ld, acc);
     return 0;

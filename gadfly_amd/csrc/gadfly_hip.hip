@@ -811,7 +811,7 @@ k_factor2(const int64_t N, const int64_t n_first, const int ld, const int W,
 //   real column: d = 0 (cos = 1), uA = a_r, uB = 0.
 // Between reset rows (anchors: exact fm_sincos, rho = 1) the rho-scaled phasor advances by a cached
 // one-cadence rotation with a second-order correction for cadence jitter (RowGen::next).
-// Valid while |d t| < 3e9 (fm_sincos's range, FM_SINCOS_RANGE): the caller checks and otherwise
+// Valid while |d t| < 1e12 (fm_sincos's range, FM_SINCOS_RANGE): the caller checks and otherwise
 // uses the k_build2 + k_factor2 pair.
 //
 // Chunk mode (time-parallel evaluation of one series, see k_phi / k_combine): the grid is
@@ -2161,15 +2161,11 @@ k_phiw(const int64_t N, const int64_t chunk_len, const int nch, const int ch0, c
     }
 }
 
-// helpers shared with the archived variants
+// (the archived sweep variants k_factor4/5/6 of rounds 1-3 live outside the package: tools/archive/sweeps_456.inc)
 template <class F, int... K>
 __device__ __forceinline__ void static_for(F &&f, std::integer_sequence<int, K...>) {
     (f(std::integral_constant<int, K>{}), ...);
 }
-
-#ifdef GF_EXPERIMENTAL_SWEEPS
-#include "experimental/sweeps_456.inc"     // archived variants (k_factor4/5/6), never in the product build
-#endif
 
 // ------------------------------------------------------------------------------------
 // Exact time-parallel evaluation of ONE series (Lainiotis-type partitioning; the numpy
@@ -4870,6 +4866,28 @@ int dispatch_factorw(const FactorWArgs &A, const FactorWPtrs &P, int W, int grid
 // ======================================================================================
 // C-ABI
 // ======================================================================================
+// (shared with gadfly_dense.hip: `which` = 0, 1 here, 2 there)
+bool gf_internal_lds_opt_in(int which, hipStream_t st, const void *const *funcs, int nfuncs, size_t bytes) {
+    static std::atomic<bool> done[4][64];
+    if (which < 0 || which >= 4) return false;
+    int dev = -1;
+    if (st == nullptr || hipStreamGetDevice(st, &dev) != hipSuccess) {
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+    }
+    if (dev < 0 || dev >= 64) return false;
+    if (done[which][dev].load(std::memory_order_acquire)) return true;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return false;
+    if (cur != dev && hipSetDevice(dev) != hipSuccess) return false;
+    bool ok = true;
+    for (int i = 0; i < nfuncs; ++i)
+        ok = ok && hipFuncSetAttribute(funcs[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+    if (cur != dev) (void)hipSetDevice(cur);
+    if (ok) done[which][dev].store(true, std::memory_order_release);
+    return ok;
+}
+
+
 extern "C" {
 
 int gf_version(void) { return 100; }
@@ -5165,22 +5183,7 @@ int gf_chunk_transition(int B, int64_t N, int64_t chunk_len, int nch, int chunk_
 // device the STREAM belongs to (not the calling thread's current device) -- and apply it with that
 // device current.  Returns false if the attribute could not be set.
 static bool lds_opt_in(int which, hipStream_t st, const void *const *funcs, int nfuncs, size_t bytes) {
-    static std::atomic<bool> done[2][64];
-    int dev = -1;
-    if (st == nullptr || hipStreamGetDevice(st, &dev) != hipSuccess) {
-        if (hipGetDevice(&dev) != hipSuccess) return false;
-    }
-    if (dev < 0 || dev >= 64) return false;
-    if (done[which][dev].load(std::memory_order_acquire)) return true;
-    int cur = -1;
-    if (hipGetDevice(&cur) != hipSuccess) return false;
-    if (cur != dev && hipSetDevice(dev) != hipSuccess) return false;
-    bool ok = true;
-    for (int i = 0; i < nfuncs; ++i)
-        ok = ok && hipFuncSetAttribute(funcs[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
-    if (cur != dev) (void)hipSetDevice(cur);
-    if (ok) done[which][dev].store(true, std::memory_order_release);
-    return ok;
+    return gf_internal_lds_opt_in(which, st, funcs, nfuncs, bytes);
 }
 
 static size_t cb_lds_bytes(bool with_xn) {

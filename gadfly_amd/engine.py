@@ -317,7 +317,7 @@ class DeviceBatch:
 
 LOG_2PI = math.log(2.0 * math.pi)
 #: largest phase |d t| the in-kernel sincos takes (FM_SINCOS_RANGE in csrc/fastmath.h)
-SINCOS_RANGE = 3.0e9
+SINCOS_RANGE = 1.0e12
 
 
 
@@ -815,7 +815,7 @@ class StreamingBatch:
         # 4 = throughput setting (log-likelihood within ~2e-9 at a condition of 4e5; 3 % slower than
         # 16, which reaches 1e-8 there), 1 = exact generation every row (float64-class accuracy,
         # 15 % slower)
-        self.generator_period = 4
+        self.generator_period = 4           # (1 on time axes whose phase quantum rules rotation out: below)
         # time-parallel log-likelihood WITHOUT a final pass (nominal sums + per-chunk corrections from the
         # start states: gf_chunk_corrections / gf_wide_combine(acc)); off by default -- the rows d, z then hold
         # the NOMINAL values and a non-positive pivot shows up as NaN, which the caller must resolve with a
@@ -833,6 +833,11 @@ class StreamingBatch:
             self._dt_med = float(torch.median(tt[1:] - tt[:-1])) if self.N > 1 else 0.0
         self.axis_stats = (self._tmax, self._dt_med)
         self._pack = self._make_pack(*self._coeff_host)
+        # a time axis far from zero (JD: phases of 5e9 rad): rotation rows would differ from celerite2's
+        # rounded-phase rows by more than the accuracy target allows at an ordinary conditioning -- exact rows
+        # until a caller calibrates (period_for_condition applies the same term to a measured condition)
+        self.generator_period = self.period_for_condition(self.NOMINAL_COND) if self.generator_period > 1 else 1
+        self.generator_period = min(self.generator_period, 4)
 
         def rows_buf():
             # one spare row: the sweep prefetches row n+1 unconditionally
@@ -873,7 +878,7 @@ class StreamingBatch:
                      for _ in range(self._nbuf)]
 
     def _fused_ok(self):
-        """Phases d*t must stay inside fm_sincos's range (|x| < 3e9: FM_SINCOS_RANGE of fastmath.h)."""
+        """Phases d*t must stay inside fm_sincos's range (|x| < 1e12: FM_SINCOS_RANGE of fastmath.h)."""
         return self.allow_fused and self._pack[6] * self._tmax < SINCOS_RANGE
 
     def _wide_ok(self):
@@ -883,6 +888,30 @@ class StreamingBatch:
     # error of the log-likelihood ~ GEN_ERR * period * condition (measured: 1e-8 at period 16 and a
     # condition of 4e5)
     GEN_ERR = 1.6e-15
+    # ... + PHASE_ERR * quantum * condition / sqrt(N) for any period > 1, quantum = max|d t| 2^-53: celerite2's rows
+    # (and the oracle's, and this library's exact rows) take cos / sin of theta = fl(d t), which carries up to half
+    # an ulp of the PHASE as rounding -- 5e-7 rad at the 5e9 rad a JD-based axis reaches with the solar p-modes
+    # (/root/reference/gadfly/gp.py:79-80) -- while rotation steps between anchors follow the true phase.  The two
+    # sets of rows differ incoherently (zero mean, row by row), hence the 1 / sqrt(N); measured on time axes moved
+    # by 0 ... 2e6 (units of 1e6 s), N = 16 384 and 131 072, conditions of 34 and 135, periods 4 and 64
+    # (tools/phase_quantum.py, profiles/r04_phase_quantum.txt): observed error <= 0.03 quantum cond / sqrt(N).
+    PHASE_ERR = 0.1
+    #: condition assumed for the phase-quantum term before any evaluation has measured one
+    NOMINAL_COND = 1.0e3
+
+    def phase_quantum(self):
+        """Half an ulp of the largest phase |d t| of the current coefficients."""
+        return float(self._pack[6]) * self._tmax * 2.0 ** -53
+
+    def phase_error_coefficient(self):
+        """Relative log-likelihood error per unit of condition number that a generator period > 1 adds through
+        the phase quantum (see PHASE_ERR)."""
+        return self.PHASE_ERR * self.phase_quantum() / math.sqrt(max(self.N, 1))
+
+    def generator_error_coefficient(self, period):
+        """err / condition of an evaluation at this generator period (0 for exact rows' own float64 class)."""
+        period = int(period)
+        return 0.0 if period <= 1 else self.GEN_ERR * period + self.phase_error_coefficient()
 
     def last_acc(self):
         """(B, 3) device tensor [sum log d, sum z^2/d, min d] of the LAST evaluation, whichever route ran."""
@@ -910,7 +939,7 @@ class StreamingBatch:
         """Longest generator period (a power of two in 1..64) whose share GEN_ERR * period * cond of the
         relative log-likelihood error stays below ``target``."""
         period = 1
-        while period < 64 and self.GEN_ERR * (2 * period) * cond <= target:
+        while period < 64 and self.generator_error_coefficient(2 * period) * cond <= target:
             period *= 2
         return period
 
@@ -1098,7 +1127,7 @@ class StreamingBatch:
         """Chunk-parallel factor + forward solve.  store=True also keeps the factor in scaled
         form (u~, w~ rows, reset spans, per-chunk true transitions) for :class:`ScaledFactor`."""
         if not self._fused_ok():
-            raise ValueError("time-parallel evaluation needs W <= 63 and |d t| < 3e9")
+            raise ValueError("time-parallel evaluation needs W <= 63 and |d t| < 1e12")
         torch = self.torch
         lib, p = self.lib, _lib.ptr
         N, B = self.N, self.B
@@ -1477,7 +1506,7 @@ class StreamingBatch:
         if self._wide_ok() and not self._fused_ok():
             return self._tp_run_wide(chunk_len)[0]
         if not self._fused_ok():
-            raise ValueError("time-parallel evaluation needs W <= 63 and |d t| < 3e9")
+            raise ValueError("time-parallel evaluation needs W <= 63 and |d t| < 1e12")
         if self._tp_chunking(chunk_len)[1] == 1:
             return self.log_likelihood()
         return self._tp_run(chunk_len, store=False)[0]

@@ -142,7 +142,7 @@ int gf_factor_scaled(int B, int64_t N, int64_t n_first, int W, int ld, const dou
  * Fully fused log-likelihood sweep (W <= 63): matrix build + factor + forward solve of N
  * consecutive rows in one kernel, generator rows produced in registers (nothing but t, y, diag
  * is read: 24 B/row).  Replaces gf_build_scaled + gf_factor_scaled on the log-likelihood path
- * (gp.py:202 + gp.py:350) whenever max|d_c| * max|t| < 3e9 (the range of the kernel's
+ * (gp.py:202 + gp.py:350) whenever max|d_c| * max|t| < 1e12 (the range of the kernel's
  * FMA-reduced sincos; the caller checks).  Arguments as in gf_build_scaled / gf_factor_scaled;
  * t, diag (NULL = 0), y are the WHOLE series (global row index, batch strides t_bs, diag_bs,
  * y_bs) and must be readable three elements past row n_first + N - 1.
@@ -205,7 +205,7 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
  * Same argument conventions (gen_period and variant included: pass the SAME values to all
  * calls of one evaluation) and padding rules as gf_loglike_fused; the row arrays gf_chunk_transition
  * reads (Ut, rbar, dbar, zbar, de) must be readable EIGHT rows past the end (they are fetched ahead by
- * LDS-DMA).  Width 1..63, phases |d t| < 3e9.  gf_chunk_sweep works on the chunks chunk_first ..
+ * LDS-DMA).  Width 1..63, phases |d t| < 1e12.  gf_chunk_sweep works on the chunks chunk_first ..
  * chunk_first + chunk_count - 1 of every problem (state slots and rows of the others are left alone): the
  * nominal pass leaves out the last chunk, a final pass that stores no factor the first one (whose nominal
  * pass was exact).  A slot whose info entry is non-zero on entry is skipped as well.

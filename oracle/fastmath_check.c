@@ -11,7 +11,7 @@ static double ulp_err(double a, double ref) {
 int main() {
     srand48(1); double ms = 0, mc = 0, me = 0; long double worst = 0;
     for (long i = 0; i < 20000000; ++i) {
-        double x = (drand48() * 2 - 1) * ((i % 3 == 0) ? 3.0e9 : (i % 3 == 1) ? 2.0e7 : 1.6e6);
+        double x = (drand48() * 2 - 1) * ((i % 5 == 0) ? 1.0e12 : (i % 5 == 1) ? 6.0e9 : (i % 5 == 2) ? 3.0e9 : (i % 5 == 3) ? 2.0e7 : 1.6e6);
         if (i % 7 == 0) x = rint(x / M_PI_2) * M_PI_2 + (drand48() - 0.5) * 1e-9;   // near multiples of pi/2
         if (i % 13 == 0) x = rint(x / M_PI_2) * M_PI_2;                             // the closest doubles to them
         double s, c; fm_sincos(x, &s, &c);

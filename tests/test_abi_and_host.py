@@ -32,9 +32,10 @@ def test_library_exports_every_declared_symbol():
     assert lib.gf_reduce_work(1_000_000) > 0
 
 
-def test_library_has_gfx950_code_object():
+def test_library_has_gfx950_code_object(tmp_path):
+    # (llvm-objdump --offloading drops the unbundled code objects into its working directory: a scratch one)
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", _lib.SO_PATH],
-                         capture_output=True, text=True)
+                         capture_output=True, text=True, cwd=tmp_path)
     assert "gfx950" in out.stdout + out.stderr
 
 

@@ -374,7 +374,7 @@ def test_gaussian_process_wide_kernel(hip, J, N, kw):
 def test_wide_streamed_log_likelihood(hip, J, N, tile, kw):
     """The streamed log-likelihood of wide kernels (k_factorw without row stores) against the oracle at six widths,
     over several tiles (state hand-off through the slots), with gaps and jittered stamps, every pivot / z row of
-    a one-tile run, and a failing pivot.  (Round 3's archived blocked sweep, csrc/experimental, was developed
+    a one-tile run, and a failing pivot.  (Round 3's archived blocked sweep, tools/archive, was developed
     against this test.)"""
     from gadfly_amd.engine import StreamingBatch
     from oracle import cref, seq

@@ -298,12 +298,13 @@ def test_streaming_not_positive_definite(hip):
 
 
 def test_streaming_large_phases_fall_back(hip):
-    """JD-like time axes push d*t beyond the fused kernel's sincos range: the engine must
-    fall back to the materialised path (OCML sincos) and still match."""
+    """Phases d*t beyond the fused kernel's sincos range (1e12 rad -- a JD-based axis reaches 5e9 and stays on
+    the fused kernels, test_gpu_jd_axis.py): the engine must fall back to the materialised path (OCML sincos)
+    and still match."""
     from gadfly_amd.engine import StreamingBatch
     from oracle import cref
     prob = util.solar_problem(20, 1200)
-    t = prob["t"] + 2.1e5                      # ~ JD 2,450,000 d in units of 1e6 s
+    t = prob["t"] + 1.0e8                      # phases of 2e12 rad
     co = prob["kernel"].get_device_coefficients()
     eng = StreamingBatch([co], t, prob["y"], diag=prob["diag_user"], tile_rows=256)
     assert not eng._fused_ok()
@@ -314,7 +315,7 @@ def test_streaming_large_phases_fall_back(hip):
 
 def test_fused_kernels_take_large_phases(hip):
     """Time axes far from zero (phases d t up to ~1e9 rad, e.g. mission days or a 1e6-point series at one
-    minute cadence): the in-kernel sincos reduces its argument with FMA over |x| < 3e9, so the fused
+    minute cadence): the in-kernel sincos reduces its argument with FMA over |x| < 1e12, so the fused
     sweeps -- streamed, time-parallel, and the wide kernel -- keep running and still match the oracle
     (both form theta = d t as ONE rounded product)."""
     from gadfly_amd.engine import StreamingBatch
@@ -325,7 +326,7 @@ def test_fused_kernels_take_large_phases(hip):
         co = prob["kernel"].get_device_coefficients()
         eng = StreamingBatch([co], t, prob["y"], diag=prob["diag_user"], tile_rows=512)
         eng.generator_period = 1
-        assert 1.6e6 < eng._pack[6] * eng._tmax < 3e9
+        assert 1.6e6 < eng._pack[6] * eng._tmax < 1e12
         assert eng._fused_ok() or eng._wide_ok()
         ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], prob["y"])
         ll = float(eng.log_likelihood()[0])
