@@ -147,12 +147,17 @@ class StellarOscillatorKernel(_terms.TermConvolution):
         return cls(terms=terms, delta=delta, name=name)
 
     def __add__(self, other):
-        """Assumes ``other`` is an SHO term (or a list of them)."""
+        """Assumes ``other`` is an SHO term (``ShotNoiseKernel`` in the reference's use).
+
+        A *list* is not accepted, as in the reference: its list branch reads ``other.terms``
+        (/root/reference/gadfly/core.py:412), which a list does not have, so ``kernel + [term, ...]`` raises
+        ``AttributeError`` there and here (add the terms one by one; SURVEY.md App. B.7 read the branch as
+        working)."""
         if not isinstance(other, list):
             other_names = [other.name]
             other = [other]
         else:
-            other_names = [t.name for t in other]
+            other_names = [t.name for t in other.terms]
 
         name = ""
         if self.name is not None:

@@ -157,7 +157,9 @@ class ConditionalDistribution:
         with torch.cuda.device(Kall.device):
             # the long dimension N is cut into S slabs (one batch entry each: a tile's K-loop is sequential),
             # the slabs' partial products are added afterwards
-            S = int(min(64, max(1, N // 4096)))
+            # (at most N M / 4 doubles of partial products: a quarter of one of the two N x M blocks held anyway;
+            # 64 slabs of M x M were 8.6 GB at M = 4096)
+            S = int(min(64, max(1, N // 4096), max(1, N // (4 * M))))
             Ks = N // S
             part = torch.empty((S, M, M), dtype=torch.float64, device=Kall.device)
             st = torch.cuda.current_stream(Kall.device).cuda_stream
