@@ -200,25 +200,76 @@ def check_sample(sample):
             "ok": bool(info == 0 and e_ll <= 1e-8 and e_mu <= 1e-6 and e_ms <= 1e-6)}
 
 
+def runtime_speed_cpu(r):
+    """CPU side of the runtime-speed leg: the same `gp.sample()` on ONE host core through the oracle's C restatement
+    (randn + sqrt(d) scaling + matmul_lower + the mean subtraction, on a factor made beforehand -- the notebook
+    times the call, not the construction), and the GPU's draw checked against it (1e-6)."""
+    from oracle import cref
+    cpu = {}
+    for smp in r.pop("_samples"):
+        n, t, co = smp["N"], smp["t"], smp["coeffs"]
+        c, a, U, V = cref.get_matrices(co[:6], t, np.zeros(n) + co[6])
+        d, Wm, info = cref.factor(t, c, a, U, V)
+        best, want = None, None
+        for _ in range(2):
+            np.random.seed(42)
+            t0 = time.perf_counter()
+            nn = np.random.randn(n)
+            want = cref.matmul_lower(t, c, U, Wm, (nn * np.sqrt(d))[:, None])[:, 0]
+            want = want - want.mean()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        err = float(np.max(np.abs(smp["draw"] - want)) / np.max(np.abs(want)))
+        cpu[n] = (best, err, info)
+    worst = 0.0
+    for row in r["durations"]:
+        if row["N"] in cpu:
+            row["cpu_sample_ms"] = 1e3 * cpu[row["N"]][0]
+            row["draw_rel_err_vs_oracle"] = cpu[row["N"]][1]
+            worst = max(worst, cpu[row["N"]][1])
+        else:
+            row["cpu_sample_ms"] = None
+    nmax = max(cpu)
+    r["cpu_port_us_per_row"] = 1e6 * cpu[nmax][0] / nmax
+    r["cpu_port_years_per_second"] = (nmax / cpu[nmax][0]) / 1440.0 / 365.25
+    r["cpu_note"] = ("oracle/celerite_ref.c on one core, sizes up to 1.1e5 rows (the port is linear in N beyond a few "
+                     "thousand rows: years per second from its time per row at the largest size run)")
+    r["parity"] = {"what": "gp.sample() (np.random.seed(42)) vs oracle matmul_lower at every size checked",
+                   "rel_err": worst, "gate": 1e-6, "ok": bool(worst <= 1e-6 and not any(v[2] for v in cpu.values()))}
+    return r
+
+
 def other_configs(check):
     """BASELINE.json configs 2 (API legs), 3, 4, 5 on this GPU: measured by tools/configs.py, one
     sampled entry of each checked against the oracle here (a failed check fails the run)."""
     from tools import configs
     import torch
     out = {}
-    for name, fn in (("cfg2_api", configs.measure_cfg2_api), ("cfg3", configs.measure_cfg3),
+    for name, fn in (("cfg2_api", configs.measure_cfg2_api),
+                     ("cfg2_api_jd", lambda: configs.measure_cfg2_api(jd=True)),
+                     ("runtime_speed", configs.measure_runtime_speed),
+                     ("cfg3", configs.measure_cfg3),
                      ("cfg3_shard", lambda: configs.measure_cfg3_shard(out["cfg3"]["ms"])),
                      ("cfg4", configs.measure_cfg4),
                      ("cfg4_shard", lambda: configs.measure_cfg4_shard(out["cfg4"]["ms"])),
                      ("cfg5", configs.measure_cfg5)):
         r = fn()
-        sample = r.pop("_sample")
-        if check:
-            r["parity"] = check_sample(sample)
-            if not r["parity"]["ok"]:
-                raise SystemExit(f"parity gate failed in {name}: {r['parity']}")
+        if name == "runtime_speed":
+            if check:
+                r = runtime_speed_cpu(r)
+            r.pop("_samples", None)
+        else:
+            sample = r.pop("_sample")
+            if check:
+                r["parity"] = check_sample(sample)
+        if check and not r["parity"]["ok"]:
+            raise SystemExit(f"parity gate failed in {name}: {r['parity']}")
         out[name] = r
         torch.cuda.empty_cache()
+    if "cfg2_api_jd" in out:
+        a, b = out["cfg2_api"], out["cfg2_api_jd"]
+        b["vs_cfg2_api"] = {k: b[k] / a[k] for k in ("compute_ms", "log_likelihood_ms", "predict_mean_ms",
+                                                    "predict_1000_new_times_ms")}
     return out
 
 

@@ -220,13 +220,22 @@ def measure_cfg5():
                             got=Z[0, :, col].cpu().numpy())}
 
 
-def measure_cfg2_api():
+#: Time(0, format='bkjd') as the reference's GaussianProcess sees it: jd * day in units of 1e6 s
+#: (/root/reference/gadfly/gp.py:79-80) -- the time axis of a lightkurve light curve or of the runtime-speed notebook
+BKJD0 = 2454833.0 * 0.0864
+
+
+def measure_cfg2_api(jd=False):
     import torch
     import gadfly_amd
     from gadfly_amd.synth import solar_like_hyperparameters, uniform_times
     N, J = 1_000_000, 30
     k = gadfly_amd.StellarOscillatorKernel(solar_like_hyperparameters(J), texp=60.0)
     t = uniform_times(N, 60.0)
+    if jd:
+        # the same series on a JD-based axis (what `GaussianProcess(kernel, light_curve=lc)` hands over,
+        # docs/gadfly/synth.rst:73-91): phases d t of 5e9 rad, still on the fused / time-parallel kernels
+        t = BKJD0 + t
     rng = np.random.Generator(np.random.PCG64(12345))
     y = np.cumsum(rng.normal(size=N)) * 5.0 + 30.0 * rng.normal(size=N)
     gp = gadfly_amd.GaussianProcess(k)
@@ -243,7 +252,9 @@ def measure_cfg2_api():
     idx = np.linspace(0, N - 1, 64).astype(int)
     return {"workload": f"cfg2 through the drop-in GaussianProcess: N={N}, J={J} (W={W}), ONE series "
                         "(latency path: exact time-parallel factorisation / sweeps); host arrays in, "
-                        "host arrays out (PCIe included)",
+                        "host arrays out (PCIe included)"
+                        + ("; time axis = BKJD 0 + n minutes as jd * day (t ~ 2.12e5, phases to 5e9 rad)" if jd else ""),
+            "route": type(gp._factor).__name__,
             "compute_ms": 1e3 * c_ms, "log_likelihood_ms": 1e3 * l_ms,
             "recompute_plus_log_likelihood_ms": 1e3 * r_ms,
             "predict_mean_ms": 1e3 * p_ms, "predict_1000_new_times_ms": 1e3 * q_ms,
@@ -254,6 +265,62 @@ def measure_cfg2_api():
                             y=y, ts=ts, idx=idx, got_ll=float(ll), got_mu=mu[idx].copy(), got_mus=mus.copy())}
 
 
+def measure_runtime_speed():
+    """The reference's own performance harness (/root/reference/notebooks/paper/runtime-speed.ipynb:40-42, :77):
+    ``SolarOscillatorKernel()`` (86 terms, W = 172), eight durations 0.1 ... 1000 d at one-minute cadence on
+    ``linspace(0, D, n) d + Time(0, format='bkjd')``, ``gp = GaussianProcess(kernel, t=new_times)``, then
+    ``%timeit gp.sample()`` -- the construction is outside the timing there and here -- and "years of observations
+    per second" = interp(1 s, runtimes, durations).  astropy / tynt are not installed: the kernel takes the bolometric
+    SOHO VIRGO bandpass (alpha = 1) instead of the default Kepler one, the axis is formed as jd * 0.0864 directly.
+    ``_samples``: inputs and the GPU's draw (seed 42) of the sizes an oracle run finishes in seconds; bench.py times
+    the same call on a host core and checks the draw there (this module never touches oracle/)."""
+    import warnings
+    import torch
+    import gadfly_amd
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        k = gadfly_amd.SolarOscillatorKernel(texp=60.0, bandpass="SOHO VIRGO")
+    co = k.get_device_coefficients()
+    durations = np.logspace(-1, 3, 8)               # days
+    rows, samples = [], []
+    for D in durations:
+        n = int(D * 1440.0)
+        t = (2454833.0 + np.linspace(0.0, D, n)) * 0.0864
+        c0 = time.perf_counter()
+        gp = gadfly_amd.GaussianProcess(k, t=t)
+        _ = gp._engine
+        torch.cuda.synchronize()
+        construct = time.perf_counter() - c0
+
+        def once():
+            np.random.seed(42)                      # (so that the draw handed to the check is randn(n) after seed 42)
+            return gp.sample()
+
+        dt, draw = _clock(torch, once, reps=3, warm=1)
+        rows.append({"duration_d": float(D), "N": n, "sample_ms": 1e3 * dt, "construct_ms": 1e3 * construct,
+                     "route": type(gp._factor).__name__
+                              + (f" ({gp._factor.nch} chunks)" if getattr(gp._factor, "nch", 1) > 1 else "")})
+        if n <= 110_000:
+            samples.append(dict(N=n, t=t, coeffs=co, draw=draw))
+        del gp
+        torch.cuda.empty_cache()
+    secs = np.array([r["sample_ms"] for r in rows]) * 1e-3
+    days = np.array([r["duration_d"] for r in rows])
+    per_s = float(np.interp(1.0, secs, days)) / 365.25         # the notebook's statement (clamps at 1000 d)
+    slope = (days[-1] - days[-2]) / (secs[-1] - secs[-2])       # days of observations per second of runtime
+    return {"workload": "runtime-speed.ipynb: gp.sample() of SolarOscillatorKernel (86 terms, W = 172) on a BKJD "
+                        "axis, eight durations at one-minute cadence; construction outside the timing as in the "
+                        "notebook; host randn (the reference's RNG contract) and PCIe both ways inside it",
+            "durations": rows,
+            "years_of_observations_per_second": per_s,
+            "years_per_second_note": "np.interp(1 s, runtimes, durations) as the notebook prints it; the longest run "
+                                     f"(1000 d = 2.74 yr) takes {secs[-1] * 1e3:.1f} ms, so the statement clamps "
+                                     "there; extrapolated with the last two sizes' slope: "
+                                     f"{(days[-1] + slope * (1.0 - secs[-1])) / 365.25:.0f} yr",
+            "largest_ms": float(secs[-1] * 1e3),
+            "_samples": samples}
+
+
 def main():
     import json
     which = [a for a in sys.argv[1:] if not a.startswith("--so=")]
@@ -261,11 +328,12 @@ def main():
         if a.startswith("--so="):               # A/B builds of the library (development)
             from gadfly_amd import _lib
             _lib.SO_PATH = os.path.abspath(a[5:])
-    fns = dict(cfg2=measure_cfg2_api, cfg3=measure_cfg3, cfg4=measure_cfg4, cfg5=measure_cfg5,
-               cfg3s=measure_cfg3_shard, cfg4s=measure_cfg4_shard)
+    fns = dict(cfg2=measure_cfg2_api, cfg2jd=lambda: measure_cfg2_api(jd=True), cfg3=measure_cfg3, cfg4=measure_cfg4,
+               cfg5=measure_cfg5, cfg3s=measure_cfg3_shard, cfg4s=measure_cfg4_shard, runtime=measure_runtime_speed)
     for fn in ([fns[w] for w in which] if which else fns.values()):
         r = fn()
         r.pop("_sample", None)
+        r.pop("_samples", None)
         print(json.dumps(r))
 
 
