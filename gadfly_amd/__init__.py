@@ -14,6 +14,6 @@ from .gp import GaussianProcess, ConditionalDistribution, LinAlgError  # noqa: F
 from .batch import BatchedLogLikelihood, log_likelihood_batch  # noqa: F401
 from . import terms  # noqa: F401
 from .psd import PowerSpectrum, bin_power_spectrum  # noqa: F401
-from .interp import interpolate_missing_data  # noqa: F401
+from .interp import interpolate_missing_data, stitch_quarters  # noqa: F401
 
 __version__ = "0.1.0"

@@ -6,9 +6,15 @@ hyperparameters, ``compute`` (matrix build + factor, /root/reference/gadfly/gp.p
 by ``log_likelihood`` (forward solve + reductions, gp.py:350).  Here the factor and the
 forward solve share one sweep and nothing returns to the host until the B scalars are read.
 
-Two batch shapes:
+Batch shapes:
   * walkers      : shared t, y; one kernel (hyperparameter set) per walker;
-  * light curves : own t, y (and kernel) per problem, common N.
+  * light curves : own t, y (and kernel) per problem -- a (B, N) array when the series share N, or a LIST of B
+                   series of different lengths (real Kepler quarters, /root/reference/gadfly/core.py:509-512,
+                   psd.py:483-531): every series is then extended to the longest one with MISSING-DATA rows -- its
+                   own cadence continued, y = 0 and the diagonal PAD_DIAG = 2^1000.  Such a row has the pivot 2^1000
+                   exactly, the gain 2^-1000 (no trace in the state at double precision) and z^2 / d = 0: the sums
+                   over the real rows are untouched, and what a pad row does add -- log 2^1000 to sum log d, one more
+                   row to N log 2 pi -- is a known constant taken off again per problem.  No kernel knows about it.
 """
 import numpy as np
 
@@ -110,14 +116,104 @@ def _exposure_resolved(delta, dt_min, t_abs_max=0.0):
     return dt_min >= delta - tol
 
 
+#: diagonal of a missing-data row (ragged batches): a power of two, so that a + 2^1000 and the pivot are 2^1000 exactly
+PAD_DIAG = 2.0 ** 1000
+
+
+def _is_ragged(t):
+    """A list / tuple / object array of 1-D series (not one rectangular array)."""
+    if isinstance(t, np.ndarray):
+        return t.dtype == object
+    if isinstance(t, (list, tuple)) and len(t) and all(np.ndim(x) == 1 for x in t):
+        return len({len(x) for x in t}) > 1         # (equal lengths: an ordinary (B, N) array)
+    return False
+
+
+def _pad_ragged(t, y, d, mean):
+    """B series of different lengths -> rectangular (B, Nmax) arrays with missing-data rows at the end.
+    Returns (t, y - mean, diag, rows per problem, largest real diagonal per problem, smallest real spacing,
+    largest real |t|)."""
+    B = len(t)
+    ts = [np.ascontiguousarray(x, dtype=np.float64) for x in t]
+    if not isinstance(y, (list, tuple)) and not (isinstance(y, np.ndarray) and y.dtype == object):
+        raise ValueError("dimension mismatch")
+    ys = [np.ascontiguousarray(x, dtype=np.float64) for x in y]
+    if len(ys) != B or any(a.ndim != 1 or a.shape != b.shape for a, b in zip(ts, ys)):
+        raise ValueError("dimension mismatch")
+    rows = np.array([len(x) for x in ts], dtype=np.int64)
+    if np.any(rows < 1):
+        raise ValueError("dimension mismatch")
+    if any(np.any(np.diff(x) < 0.0) for x in ts):
+        raise ValueError("The input coordinates must be sorted")
+    if d is None:
+        ds = [np.zeros(n) for n in rows]
+    elif isinstance(d, (list, tuple)) or (isinstance(d, np.ndarray) and d.dtype == object):
+        ds = [np.broadcast_to(np.asarray(x, dtype=np.float64), (n,)) for x, n in zip(d, rows)]
+        if len(ds) != B:
+            raise ValueError("dimension mismatch")
+    else:
+        d = np.asarray(d, dtype=np.float64)
+        if d.ndim > 1 or (d.ndim == 1 and d.shape[0] != B):
+            raise ValueError("dimension mismatch")          # a scalar, or one value per problem
+        ds = [np.full(n, float(d if d.ndim == 0 else d[i])) for i, n in enumerate(rows)]
+    means = np.broadcast_to(np.asarray(mean, dtype=np.float64), (B,)) if np.ndim(mean) <= 1 else None
+    if means is None:
+        raise ValueError("dimension mismatch")
+    Nmax = int(rows.max())
+    T = np.empty((B, Nmax))
+    Y = np.zeros((B, Nmax))
+    D = np.full((B, Nmax), PAD_DIAG)
+    for i, n in enumerate(rows):
+        T[i, :n], Y[i, :n], D[i, :n] = ts[i], ys[i] - means[i], ds[i]
+        if n < Nmax:
+            # the series' own cadence continued: the row generator keeps stepping, no gap, no new phase range
+            dt = float(np.median(np.diff(ts[i]))) if n > 1 else 1.0
+            if not dt > 0.0:
+                dt = 1.0
+            T[i, n:] = ts[i][-1] + dt * np.arange(1, Nmax - n + 1)
+    dmax = np.array([float(np.max(x)) if len(x) else 0.0 for x in ds])
+    dmin_real = min(float(np.min(x)) for x in ds)
+    dt_min = min((float(np.min(np.diff(x))) for x in ts if len(x) > 1), default=None)
+    tabs = max(float(np.max(np.abs(x))) for x in ts)
+    return T, Y, D, rows, dmax, dmin_real, dt_min, tabs
+
+
 class BatchedLogLikelihood:
     """Reusable evaluator: device buffers are allocated once; each :meth:`evaluate` with new
-    kernels costs an O(B J) coefficient upload plus the device work."""
+    kernels costs an O(B J) coefficient upload plus the device work.
+
+    ``t`` / ``y``: shared ((N,)), per problem ((B, N)), or -- ragged -- lists of B series of different lengths
+    (``yerr`` / ``diag`` then a scalar, one value per problem, or a list of per-series arrays; ``mean`` a scalar or
+    one value per problem)."""
 
     def __init__(self, kernels, t, y, yerr=None, diag=None, mean=0.0, device=None,
                  tile_rows=8192, overlap_build=False):
         if yerr is not None and diag is not None:
             raise ValueError("only one of 'diag' and 'yerr' can be provided")
+        self.rows = None                    # ragged batches: real rows per problem
+        self._pad_corr = None
+        if _is_ragged(t):
+            if len(t) != len(kernels):
+                raise ValueError("dimension mismatch")
+            dd = diag
+            if yerr is not None:
+                dd = ([np.asarray(e, dtype=np.float64) ** 2 for e in yerr]
+                      if isinstance(yerr, (list, tuple)) or (isinstance(yerr, np.ndarray) and yerr.dtype == object)
+                      else np.asarray(yerr, dtype=np.float64) ** 2)
+            t, ym, d, self.rows, dmax, dmin_real, dt_min, tabs = _pad_ragged(t, y, dd, mean)
+            self.engine = StreamingBatch([k.get_device_coefficients() for k in kernels], t, ym, diag=d,
+                                         tile_rows=tile_rows, device=device, overlap_build=overlap_build)
+            eng = self.engine
+            torch = eng.torch
+            # the condition estimates look at the REAL rows' diagonal, and the results lose the pad rows' constants
+            eng._diag_amax = torch.as_tensor(dmax, dtype=torch.float64, device=eng.device)
+            pad = (t.shape[1] - self.rows).astype(np.float64)
+            self._pad_corr = torch.as_tensor(0.5 * pad * (np.log(PAD_DIAG) + np.log(2.0 * np.pi)),
+                                             dtype=torch.float64, device=eng.device)
+            self._diag_nonneg = dmin_real >= 0.0
+            self._dt_min, self._t_abs_max = dt_min, tabs
+            self._finish_init(kernels)
+            return
         t = np.ascontiguousarray(t, dtype=np.float64)
         y = np.ascontiguousarray(y, dtype=np.float64)
         if np.any(np.diff(t, axis=-1) < 0.0):
@@ -134,17 +230,20 @@ class BatchedLogLikelihood:
         self.engine = StreamingBatch([k.get_device_coefficients() for k in kernels], t,
                                      y - mean, diag=d, tile_rows=tile_rows, device=device,
                                      overlap_build=overlap_build)
+        self._diag_nonneg = d is None or bool(np.all(np.asarray(d) >= 0.0))
+        #: smallest spacing of the time axes and their largest |t|: an exposure-integrated kernel is a covariance
+        #: only while no two stamps are closer than its exposure time (see _sho_only)
+        self._dt_min = float(np.min(np.diff(t, axis=-1))) if t.shape[-1] > 1 else None
+        self._t_abs_max = float(np.max(np.abs(t))) if t.size else 0.0
+        self._finish_init(kernels)
+
+    def _finish_init(self, kernels):
         #: the time-parallel route may drop its final pass (engine.two_sweep) when the matrix is positive
         #: semi-definite by construction: SHO kernels, a non-negative diagonal, no two time stamps closer than
         #: the exposure time.  Rounding can still break a pivot: the corrections check the sign of EVERY pivot
         #: of a chunk (a Cholesky attempt on (I - X G) X, gadfly_dense.hip: k_spd_check), not only the parity
         #: det(I - X G) gives, and a chunk that fails it leaves a non-finite value, which :meth:`resolve` repeats
         #: with the final pass
-        self._diag_nonneg = d is None or bool(np.all(np.asarray(d) >= 0.0))
-        #: smallest spacing of the time axes and their largest |t|: an exposure-integrated kernel is a covariance
-        #: only while no two stamps are closer than its exposure time (see _sho_only)
-        self._dt_min = float(np.min(np.diff(t, axis=-1))) if t.shape[-1] > 1 else None
-        self._t_abs_max = float(np.max(np.abs(t))) if t.size else 0.0
         self._init_safe = self._diag_nonneg and all(_sho_only(k, self._dt_min, self._t_abs_max) for k in kernels)
         self.two_sweep = True
         #: keep the row generator's share of the relative log-likelihood error below this by
@@ -198,6 +297,8 @@ class BatchedLogLikelihood:
         eng.two_sweep = bool(self.two_sweep and self._safe)
         # small batches of long series are chunked in time as well (exact, see engine.evaluate)
         out = eng.evaluate()[0]
+        if self._pad_corr is not None:
+            out = out + self._pad_corr      # ragged batch: the missing-data rows' constants (-inf / NaN stay)
         period = int(eng.generator_period)
         if eng._fused_ok() or eng._wide_ok():
             torch = eng.torch
@@ -247,6 +348,8 @@ class BatchedLogLikelihood:
             eng.generator_period = 1
             eng.two_sweep = False           # the repeat is the reference formulation: exact rows, final pass
             exact = eng.evaluate()[0]
+            if self._pad_corr is not None:
+                exact = exact + self._pad_corr
             out.copy_(torch.where(flag, exact, out))
             redone += int(hit.sum())
         eng._pack, eng.generator_period, eng.two_sweep = keep_pack, keep_period, keep_two

@@ -52,7 +52,8 @@ def sharded_log_likelihood(kernels, t, y, yerr=None, diag=None, mean=0.0, evalua
     log-likelihoods of B problems evaluated across the ranks of ``torch.distributed``.
 
     ``kernels`` is the full list of B kernels on every rank; ``t`` / ``y`` are either shared
-    ((N,)) or per problem ((B, N)).  ``evaluate(kernels, t, y, yerr=..., diag=..., mean=...)
+    ((N,)), per problem ((B, N)), or ragged (lists of B series of different lengths; ``yerr`` / ``diag`` then a
+    scalar or a list of per-series arrays).  ``evaluate(kernels, t, y, yerr=..., diag=..., mean=...)
     -> (b,) array`` defaults to :func:`gadfly_amd.log_likelihood_batch` on this rank's GPU
     (the tests inject a checker so the partition/gather logic runs under gloo without a GPU).
     Returns the full (B,) numpy array on every rank.
@@ -73,7 +74,12 @@ def sharded_log_likelihood(kernels, t, y, yerr=None, diag=None, mean=0.0, evalua
     def part(x):
         if x is None:
             return None
+        if isinstance(x, (list, tuple)) and len(x) == B and all(np.ndim(v) >= 1 for v in x) \
+                and len({np.shape(v) for v in x}) > 1:
+            return list(x[lo:hi])           # ragged: one series per problem, different lengths
         x = np.asarray(x)
+        if x.ndim == 1 and x.dtype == object and x.shape[0] == B:
+            return list(x[lo:hi])
         return x[lo:hi] if (x.ndim == 2 and x.shape[0] == B) else x
 
     local = np.zeros(0)

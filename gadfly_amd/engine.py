@@ -931,8 +931,8 @@ class StreamingBatch:
         if getattr(self, "_two_sweep_used", False):
             dmin /= self.TWO_SWEEP_MARGIN
         amax = float(self._pack[2].max().item())
-        if self.diag is not None:
-            amax += float(self.diag.max().item())
+        if self._diag_amax is not None:
+            amax += float(self._diag_amax.max().item())      # (a ragged batch sets it from its real rows)
         return amax / dmin if dmin > 0.0 else float("inf")
 
     def period_for_condition(self, cond, target=1e-9):

@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["interpolate_missing_data"]
+__all__ = ["interpolate_missing_data", "stitch_quarters"]
 
 
 def interpolate_missing_data(times, fluxes, cadences=None, device=None, return_device=False):
@@ -56,3 +56,33 @@ def interpolate_missing_data(times, fluxes, cadences=None, device=None, return_d
         if return_device:
             return t_out, f_out
         return t_out.cpu().numpy(), f_out.cpu().numpy()
+
+
+def stitch_quarters(quarters, detrend_poly_order=3, in_ppm=False, device=None):
+    """
+    Several observing quarters of one star -> ONE gap-filled series in ppm, the way the reference prepares a
+    ``LightCurveCollection`` (/root/reference/gadfly/psd.py:483-531): per quarter fill the missing cadences
+    (:func:`interpolate_missing_data`), divide by a polynomial of order ``detrend_poly_order`` in ``t - mean(t)`` and
+    by the median of the result, ``1e6 (f / median - 1)`` (skipped when the fluxes are in ppm already,
+    ``in_ppm=True``); concatenate the quarters in the order given, which must be chronological (lightkurve's
+    ``stitch(lambda x: x)``); fill the gaps
+    BETWEEN the quarters the same way.  ``quarters``: list of (times [d], fluxes) pairs, NaNs and outliers already
+    removed (``remove_nans().remove_outliers()`` is lightkurve's, outside this path).  Returns
+    ``(times, flux_ppm, cadence)`` with cadence = median spacing (psd.py:534).  The gap filling runs on the device;
+    the O(N) polynomial fit on the host, as numpy does it in the reference.
+    """
+    ts, fs = [], []
+    for t, f in quarters:
+        t, f = interpolate_missing_data(t, f, device=device)
+        if not in_ppm:
+            x = t - t.mean()
+            fit = np.polyval(np.polyfit(x, f, detrend_poly_order), x)
+            normed = f / fit
+            f = 1e6 * np.array(normed / np.median(normed) - 1)
+        ts.append(t)
+        fs.append(f)
+    t = np.concatenate(ts)                          # (lightkurve's stitch keeps the collection's order)
+    f = np.concatenate(fs)
+    if len(ts) > 1:
+        t, f = interpolate_missing_data(t, f, device=device)
+    return t, f, float(np.median(np.diff(t)))

@@ -32,3 +32,26 @@ def interpolate_missing_data(times, fluxes, cadences=None):
     f_all = np.concatenate([fluxes, f_new])
     order = np.argsort(t_all, kind="stable")                        # interp.py:56-59
     return t_all[order], f_all[order]
+
+
+def stitch_quarters(quarters, detrend_poly_order=3, in_ppm=False):
+    """Restatement of the multi-quarter preparation of /root/reference/gadfly/psd.py:483-531 (the FFT branch with
+    ``detrend=True``): per quarter `interpolate_missing_data`, polynomial normalisation to ppm, stitch in the
+    order given, `interpolate_missing_data` again over the stitched series.  lightkurve's ``remove_nans`` /
+    ``remove_outliers`` / ``stitch`` are not restated (inputs are clean arrays; stitch(lambda x: x) is a
+    concatenation).  Returns (t, flux_ppm, median spacing)."""
+    ts, fs = [], []
+    for t, f in quarters:
+        t, f = interpolate_missing_data(np.asarray(t, float), np.asarray(f, float))
+        if not in_ppm:
+            fit = np.polyval(np.polyfit(t - t.mean(), f, detrend_poly_order), t - t.mean())
+            normed_flux = f / fit
+            median_flux = np.median(normed_flux)
+            f = 1e6 * np.array(normed_flux / median_flux - 1)
+        ts.append(t)
+        fs.append(f)
+    t = np.concatenate(ts)                          # (lightkurve's stitch keeps the collection's order)
+    f = np.concatenate(fs)
+    if len(ts) > 1:
+        t, f = interpolate_missing_data(t, f)
+    return t, f, float(np.median(np.diff(t)))

@@ -152,6 +152,23 @@ def checker2(ks, tt, yy, yerr=None, diag=None, mean=0.0):
                      for i, k in enumerate(ks)])
 res2 = sharded_log_likelihood(kernels, ts, ys, yerr=30.0, evaluate=checker2)
 assert np.all(np.isfinite(res2)) and res2.shape == (B,)
+# ragged batches: lists of series of different lengths are sliced like the kernels (never stacked)
+lens = [300, 420, 350, 600, 512]
+tr = [np.arange(n) * 60e-6 * (1 + 0.02 * i) for i, n in enumerate(lens)]
+yr = [rng.normal(size=n) * 40.0 for n in lens]
+er = [np.full(n, 20.0 + i) for i, n in enumerate(lens)]
+seen = []
+def checker3(ks, tt, yy, yerr=None, diag=None, mean=0.0):
+    assert isinstance(tt, list) and isinstance(yy, list) and isinstance(yerr, list)
+    assert len(tt) == len(yy) == len(yerr) == len(ks)
+    seen.append([len(x) for x in tt])
+    return np.array([cref.loglike(k.get_device_coefficients()[:6], tt[i],
+                     yerr[i] ** 2 + k.get_device_coefficients()[6], yy[i] - mean)[0] for i, k in enumerate(ks)])
+res3 = sharded_log_likelihood(kernels, tr, yr, yerr=er, evaluate=checker3)
+lo, hi = (0, 3) if dist.get_rank() == 0 else (3, 5)
+assert seen[0] == lens[lo:hi]
+ref3 = checker3(kernels, tr, yr, yerr=er)
+assert res3.shape == (B,) and np.array_equal(res3, ref3)
 dist.destroy_process_group()
 print("rank", os.environ["RANK"], "ok")
 """
