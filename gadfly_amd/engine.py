@@ -346,6 +346,10 @@ class ScaledFactor:
         # own copy of the pivots: the shared buffer holds the nominal pass' values while a later
         # evaluation is in flight
         self.d = w["d"][:self.B * self.N].view(self.B, self.N).clone()
+        # the true chunk transitions Phi_c are computed at the first solve (_ensure_transitions): from the rows r
+        # of the final pass, still in the owner's buffer unless it has run another evaluation since
+        self._phi_ready = nch <= 1
+        self._r_rows, self._r_generation = w["r"], getattr(owner, "_tp_generation", 0)
         self.c = owner._pack[3]
         self.t = owner.t
         self.info = owner.info
@@ -354,10 +358,40 @@ class ScaledFactor:
         self._Psi = None
 
     @_on_device
+    def _ensure_transitions(self):
+        """Phi_c of the TRUE factor's chunks: the transition sweep on the stored rows (u~, r = w~ d, d, reset
+        spans), once, at the first solve that chains chunk states."""
+        if self._phi_ready:
+            return
+        torch, lib, p, o = self.torch, self.lib, _lib.ptr, self.owner
+        B, N = self.B, self.N
+        w = o._tp
+        r = self._r_rows
+        if getattr(o, "_tp_generation", 0) != self._r_generation:
+            # the owner has swept again since: its row buffer holds another pass' rows -- r = w~ d from the factor
+            r = torch.empty((B * N + 8, 64), dtype=torch.float64, device=self.device)
+            r[B * N:].zero_()
+            torch.mul(self.Wt.view(B * N, 64), self.d.reshape(B * N, 1), out=r[:B * N])
+        f64 = dict(dtype=torch.float64, device=self.device)
+        G, m = torch.empty((B * self.nch, 4096), **f64), torch.empty((B * self.nch, 64), **f64)   # (by-products)
+        dd = torch.empty((B * N + 8,), **f64)
+        dd[:B * N] = self.d.reshape(-1)
+        dd[B * N:] = 1.0
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        rc = lib.gf_chunk_transition(B, N, self.chunk_len, self.nch, 0, self.nch, o.Jr, o.Jc,
+                                     int(o.sweep_variant), p(self.c), p(self.de), p(dd), p(dd),
+                                     p(r), p(self.Ut), p(self.Phi), p(G), p(m), st)
+        _lib.check(rc, "gf_chunk_transition")
+        self._phi_ready = True
+        self._r_rows = None
+
+    @_on_device
     def _sweep(self, mode, Y, scale):
         torch = self.torch
         lib, p = self.lib, _lib.ptr
         B, N, R = Y.shape
+        if mode != _lib.GF_MATMUL_LOWER:
+            self._ensure_transitions()
         if R > self.RMAX:               # tile the right-hand sides
             return torch.cat([self._sweep(mode, Y[:, :, r0:r0 + self.RMAX].contiguous(), scale)
                               for r0 in range(0, R, self.RMAX)], dim=2)
@@ -414,6 +448,7 @@ class ScaledFactor:
         Sequential depth 2 seg_len + nch / seg_len chunks -> seg_len = sqrt(nch / 2)."""
         if self.nch < self.SEG_MIN_CHUNKS:
             return None
+        self._ensure_transitions()
         if self._Psi is None:
             seg_len = max(2, int(round(math.sqrt(self.nch / 2.0))))
             nseg = -(-self.nch // seg_len)
@@ -1216,8 +1251,10 @@ class StreamingBatch:
         _lib.check(rc, "gf_chunk_sweep")
         if skip_first:
             ci[:, 0] = ci0
-        if store and nch > 1:
-            transition(0, nch, w["Ut"], w["de"], "PhiT")    # on the TRUE rows: the true chunk transitions
+        # (the TRUE chunk transitions -- the transition sweep once more, on the true rows -- are part of the stored
+        # factor but needed by the solves only: ScaledFactor computes them at its first solve, compute() does not
+        # wait for them: 0.67 of its 6 ms of kernels at N = 1e6)
+        self._tp_generation = getattr(self, "_tp_generation", 0) + 1
         rc = lib.gf_reduce_tile(B, N, p(w["d"]), p(w["z"]), p(w["work"]), p(w["acc"]), 1, st)
         _lib.check(rc, "gf_reduce_tile")
         # a chunk that failed marks its problem with the FIRST non-positive pivot (celerite2 and the
@@ -1239,6 +1276,7 @@ class StreamingBatch:
         lib, p = self.lib, _lib.ptr
         N, B = self.N, self.B
         real, comp, diag_add, _, cmax, block, _ = self._pack
+        self._tp_generation = getattr(self, "_tp_generation", 0) + 1
         rc = lib.gf_chunk_sweep(B, N, chunk_len, nch, 0, nch, self.Jr, self.Jc, block, *opts, *coeffs,
                                 p(diag_add), p(cmax), *tyd, p(w["d"]), p(w["z"]), p(w["r"]),
                                 p(w["Un"]), None, p(w["den"]), p(w["S"]), p(w["F"]), p(w["info"]), st)

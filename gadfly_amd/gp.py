@@ -51,11 +51,13 @@ class ConditionalDistribution:
         self.include_mean = include_mean
         self.kernel = kernel
         self._alpha = None
+        self._resid_dev = None
 
     def _get_alpha(self):
         if self._alpha is None:
             gp = self.gp
             resid = gp._resid_to_device(self.y)
+            self._resid_dev = resid
             self._alpha = gp._engine.apply_inverse(resid.reshape(1, -1, 1))
         return self._alpha
 
@@ -64,6 +66,19 @@ class ConditionalDistribution:
         gp = self.gp
         alpha = self._get_alpha()
         if self.t is None and self.kernel is None:
+            if gp._diag_dev is not None and self._resid_dev is not None:
+                # y - diag alpha = (y - mean) - diag alpha + mean, formed where alpha is: one fused pass on the
+                # device and one download instead of a download and three passes over host arrays
+                torch = gp._engine.torch
+                mu_d = torch.addcmul(self._resid_dev.reshape(-1), gp._diag_dev.reshape(-1), alpha.reshape(-1),
+                                     value=-1.0)
+                const = isinstance(gp._mean, _ConstantMean)
+                if self.include_mean and const:
+                    mu_d += float(gp._mean.value)
+                mu = gp._to_host(mu_d)
+                if self.include_mean and not const:
+                    mu += gp._mean_value
+                return mu
             mu = self.y - gp._diag * gp._to_host(alpha.reshape(-1))
             if not self.include_mean:
                 mu = mu - gp._mean_value
@@ -359,23 +374,45 @@ class GaussianProcess:
         t = np.ascontiguousarray(t, dtype=np.float64)
         if t.ndim != 1:
             raise ValueError("dimension mismatch")
-        if check_sorted and np.any(np.diff(t) < 0.0):
-            raise ValueError("The input coordinates must be sorted")
         N = t.shape[0]
+        if check_sorted and N > 1 and not bool(np.all(t[1:] >= t[:-1])):
+            raise ValueError("The input coordinates must be sorted")
         self._t = t
         self._size = N
         self._mean_value = self._mean(t)
-        self._diag = np.zeros(N, dtype=np.float64)
         self._t_dev = self._diag_dev = None
         self._diag_const = 0.0              # a scalar diagonal is made on the device, not uploaded
-        if yerr is not None:
-            if diag is not None:
-                raise ValueError("only one of 'diag' and 'yerr' can be provided")
-            self._diag += np.broadcast_to(np.asarray(yerr, dtype=np.float64), (N,)) ** 2
-            self._diag_const = float(np.asarray(yerr, dtype=np.float64)) ** 2 if np.ndim(yerr) == 0 else None
+        if yerr is not None and diag is not None:
+            raise ValueError("only one of 'diag' and 'yerr' can be provided")
+        if yerr is not None and np.ndim(yerr) == 0:
+            self._diag_const = float(np.asarray(yerr, dtype=np.float64)) ** 2
+        elif yerr is not None:
+            self._diag_const = None
+            self._diag = np.array(np.broadcast_to(np.asarray(yerr, dtype=np.float64), (N,))) ** 2
+        elif diag is not None and np.ndim(diag) == 0:
+            self._diag_const = float(np.asarray(diag, dtype=np.float64))
         elif diag is not None:
-            self._diag += np.broadcast_to(np.asarray(diag, dtype=np.float64), (N,))
-            self._diag_const = float(np.asarray(diag, dtype=np.float64)) if np.ndim(diag) == 0 else None
+            self._diag_const = None
+            self._diag = np.array(np.broadcast_to(np.asarray(diag, dtype=np.float64), (N,)))
+        if self._diag_const is not None:
+            self._diag = np.full(N, self._diag_const, dtype=np.float64)        # (one pass: celerite2 keeps it too)
+        # statistics of the time axis the engine needs (largest |t|, typical spacing), taken here on the host: as
+        # device reductions they cost a 1e6-element sort and two host synchronisations per compute()
+        if N > 1:
+            if check_sorted:
+                tmax = max(abs(float(t[0])), abs(float(t[-1])))
+            else:
+                tmax = max(abs(float(t.min())), abs(float(t.max())))
+            if N <= 65536:
+                dt_med = float(np.median(np.diff(t)))
+            else:
+                # the median spacing of 4097 cadences spread evenly over the series (it only sets how many rows a
+                # block of the scaled recurrence may span)
+                i = np.linspace(0, N - 2, 4097).astype(np.int64)
+                dt_med = float(np.median(t[i + 1] - t[i]))
+            self._axis_stats = (tmax, dt_med)
+        else:
+            self._axis_stats = (abs(float(t[0])) if N else 0.0, 0.0)
 
         self._do_compute(quiet)
 
@@ -424,9 +461,8 @@ class GaussianProcess:
             f64 = dict(dtype=torch.float64, device=self._device_of())
             const = getattr(self, "_diag_const", None)
             if self._t_dev is None:         # (recompute() with another kernel: t, diag are on the device already)
-                self._axis_stats = None
-                self._t_dev = torch.as_tensor(self._t).to(**f64)
-                self._diag_dev = (torch.as_tensor(self._diag).to(**f64) if const is None
+                self._t_dev = self._to_device(self._t)          # (through the page-locked staging buffer)
+                self._diag_dev = (self._to_device(self._diag) if const is None
                                   else torch.full((self._size,), const, **f64))
             fast = StreamingBatch([co], self._t_dev, torch.zeros((self._size,), **f64),
                                   diag=self._diag_dev, device=self._device,

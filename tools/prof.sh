@@ -1,16 +1,10 @@
-# kernel-time profile of one command on the GPU box:  bash tools/prof.sh NAME tools/configs.py cfg4s
-# (rocprofv3 --kernel-trace --stats; the per-kernel summary lands in gpurun_out/prof_NAME/NAME_kernel_stats.csv)
+# kernel-trace summary of one command (run on the GPU box through gpurun, from the repo root):
+#   bash tools/prof.sh NAME script.py [args...]   ->  gpurun_out/r04/r04_NAME_kernel_stats.csv (+ NAME.log)
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04; mkdir -p $O
+name=$1; shift; script=$R/$1; shift
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-NAME=$1; shift
-OUT=$R/gpurun_out/prof_$NAME
-rm -rf $OUT; mkdir -p $OUT
-SCRIPT=$R/$1; shift
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -- python3 $SCRIPT "$@" > $OUT/log.txt 2>&1
-echo "rc=$?"
-f=$(find $OUT/raw -name "*kernel_stats.csv" | head -1)
-cp $f $OUT/${NAME}_kernel_stats.csv
-[ -n "$PROF_TRACE" ] && cp $(find $OUT/raw -name "*kernel_trace.csv" | head -1) $OUT/${NAME}_kernel_trace.csv
-rm -rf $OUT/raw
-head -${PROF_LINES:-16} $OUT/${NAME}_kernel_stats.csv | cut -c1-150
-tail -4 $OUT/log.txt | cut -c1-400
+rm -rf $O/prof_$name
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -- python3 $script "$@" > $O/$name.log 2>&1
+cp $(find $O/prof_$name -name "*kernel_stats.csv" | head -1) $O/r04_${name}_kernel_stats.csv
+rm -rf $O/prof_$name
+grep -v "^[EWI]2026\|amdgpu.ids" $O/$name.log | tail -5
