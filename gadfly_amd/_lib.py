@@ -67,7 +67,7 @@ SIGNATURES = {
     "gf_wide_combine_work": (_i64, [_int, _int, _int]),
     "gf_wide_combine": (_int, [_int, _i64, _i64, _int, _int] + [_vp] * 7 + [_vp]),
     "gf_chunk_corrections_work": (_i64, [_int, _int]),
-    "gf_chunk_corrections": (_int, [_int, _int, _int, _int] + [_vp] * 6 + [_vp]),
+    "gf_chunk_corrections": (_int, [_int, _int, _int, _int, _int] + [_vp] * 6 + [_vp]),
     "gf_wide_gram": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int] + [_vp] * 5 + [_vp]),
     "gf_lft_tree_work": (_i64, [_int, _int, _int]),
     "gf_lft_tree_scan": (_int, [_int, _int, _int] + [_vp] * 8 + [_vp]),

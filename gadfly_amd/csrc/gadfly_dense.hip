@@ -881,10 +881,276 @@ k_corr_finish(const int P, const int first, const int count, const int WP, const
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The corrections of a chunk whose maps live in 64 x 64 slots (celerite width W <= 63), in ONE kernel and entirely
+// through the symmetric form (no LU of I - X G):
+//     X = R R^T  (diagonal pivoting, numerical rank r)        M = I_r - R^T G R = L L^T  (attempt: fails <=> some
+//     log det(I - X G) = log det M = 2 sum log L_kk            pivot of the chunk is not positive -> NaN)
+//     v = (I - X G)^-1 e = e + R M^-1 R^T G e                  (Woodbury; e = Y - X m)
+//     e^T G v - 2 m^T e - m^T X m = (G e)^T v - 2 m^T e - m^T (Y - e)
+// One workgroup of 256 threads per map, two n x (n + 1) LDS buffers for the active width n = W rounded up to 4
+// (X -> its Cholesky workspace -> G -> T = G R -> M -> L; and R), products as 4 x 4 register tiles.  Replaces, for
+// these widths, seven launches (two job launches, the batched LU, k_pchol, two GEMM launches, k_spd_check) that cost
+// 0.9 ms for the 2048 maps of cfg3 -- a fifth of its shard's evaluation.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_corr_small(const int P, const int first, const int count, const int n, const double *__restrict__ X_,
+             const double *__restrict__ Y_, const double *__restrict__ G_, const double *__restrict__ m_,
+             double *__restrict__ ld_out, double *__restrict__ quad_out) {
+    const int pr = blockIdx.x / count, c = first + (blockIdx.x - pr * count);
+    const size_t mp = (size_t)pr * P + c;
+    const double *__restrict__ X = X_ + mp * 4096, *__restrict__ G = G_ + mp * 4096;
+    const double *__restrict__ Y = Y_ + mp * 64, *__restrict__ mv = m_ + mp * 64;
+    const int LD = n + 1;
+    extern __shared__ __attribute__((aligned(16))) double spd_lds[];
+    double *A = spd_lds, *Rm = A + n * LD;
+    double *ve = Rm + n * LD, *vw1 = ve + 64, *vw2 = vw1 + 64, *vy = vw2 + 64, *vm = vy + 64, *d0 = vm + 64,
+           *col = d0 + 64;
+    __shared__ int s_done[64];
+    __shared__ int s_p, s_fail, s_rank;
+    __shared__ double s_best, s_red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- X -> A (lower triangle is what is used), Y, m; R := 0
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, j = e - i * n;
+        A[i * LD + j] = X[i * 64 + j];
+        Rm[i * LD + j] = 0.0;
+    }
+    if (tid < 64) { vy[tid] = (tid < n) ? Y[tid] : 0.0; vm[tid] = (tid < n) ? mv[tid] : 0.0; }
+    if (tid == 0) { s_fail = 0; s_rank = 0; }
+    __syncthreads();
+    // ---- e = Y - X m (X symmetric, full rows are there); original diagonal of X
+    if (tid < n) {
+        double acc = vy[tid];
+        for (int j = 0; j < n; ++j) acc = fma(-A[tid * LD + j], vm[j], acc);
+        ve[tid] = acc;
+        const double v = A[tid * LD + tid];
+        const bool live = v > 0.0;
+        d0[tid] = live ? 1.0 / v : 0.0;
+        s_done[tid] = live ? 0 : 1;
+    } else if (tid < 64) {
+        ve[tid] = 0.0; d0[tid] = 0.0; s_done[tid] = 1;
+    }
+    __syncthreads();
+    // ---- X = R R^T with diagonal pivoting
+    int rank = 0;
+    for (int k = 0; k < n; ++k) {
+        if (wave == 0) {
+            double v = -1.0;
+            int ix = lane;
+            if (lane < n && !s_done[lane]) v = A[lane * LD + lane] * d0[lane];
+#pragma unroll
+            for (int mk = 32; mk >= 1; mk >>= 1) {
+                const double ov = __shfl_xor(v, mk);
+                const int oi = __shfl_xor(ix, mk);
+                if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+            }
+            if (lane == 0) { s_best = v; s_p = ix; }
+        }
+        __syncthreads();
+        const double best = s_best;
+        const int p = s_p;
+        if (!(best > PCHOL_TOL)) break;             // (uniform) numerical rank reached
+        const double r = 1.0 / sqrt(A[p * LD + p]);
+        if (tid < n) {
+            double v = 0.0;
+            if (!s_done[tid]) v = (tid >= p ? A[tid * LD + p] : A[p * LD + tid]) * r;
+            col[tid] = v;
+            Rm[tid * LD + k] = v;
+        }
+        __syncthreads();
+        if (tid == 0) s_done[p] = 1;
+        for (int i = wave; i < n; i += 4) {
+            if (s_done[i] || i == p) continue;
+            const double ci = col[i];
+            if (lane <= i) A[i * LD + lane] = fma(-ci, col[lane], A[i * LD + lane]);
+        }
+        rank = k + 1;
+        __syncthreads();
+    }
+    __syncthreads();
+    // ---- G -> A (whole rows), w1 = G e
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, j = e - i * n;
+        A[i * LD + j] = G[i * 64 + j];
+    }
+    __syncthreads();
+    if (tid < n) {
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc = fma(A[tid * LD + j], ve[j], acc);
+        vw1[tid] = acc;
+    }
+    // ---- T = G R as 4 x 4 register tiles (tile (ti, tj): rows 4 ti.., columns 4 tj.. < rank), then T -> A
+    const int nt = n >> 2, ti = tid >> 4, tj = tid & 15;
+    const bool tile = ti < nt && tj < nt;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    if (tile && 4 * tj < rank) {
+        for (int l = 0; l < n; ++l) {
+            double ga[4], rb[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) ga[a] = A[(4 * ti + a) * LD + l];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) rb[b] = Rm[l * LD + 4 * tj + b];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = fma(ga[a], rb[b], acc[a][b]);
+        }
+    }
+    __syncthreads();
+    if (tile) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) A[(4 * ti + a) * LD + 4 * tj + b] = acc[a][b];
+    }
+    __syncthreads();
+    // ---- M = I - R^T T (rank x rank; identity beyond), then M -> A
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    if (tile && 4 * ti < rank && 4 * tj < rank) {
+        for (int l = 0; l < n; ++l) {
+            double ra[4], tb[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) ra[a] = Rm[l * LD + 4 * ti + a];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) tb[b] = A[l * LD + 4 * tj + b];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = fma(ra[a], tb[b], acc[a][b]);
+        }
+    }
+    __syncthreads();
+    if (tile) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                A[(4 * ti + a) * LD + 4 * tj + b] = ((4 * ti + a == 4 * tj + b) ? 1.0 : 0.0) - acc[a][b];
+    }
+    // w2 = R^T w1
+    if (tid < n) {
+        double a2 = 0.0;
+        if (tid < rank) for (int i = 0; i < n; ++i) a2 = fma(Rm[i * LD + tid], vw1[i], a2);
+        vw2[tid] = a2;
+    }
+    __syncthreads();
+    // ---- M = L L^T (attempt, lower triangle, `rank` steps; pivots against their own diagonal entry)
+    if (tid < 64) d0[tid] = (tid < rank) ? A[tid * LD + tid] : 1.0;
+    __syncthreads();
+    if (tid < rank && !(d0[tid] > 0.0)) s_fail = 1;
+    __syncthreads();
+    for (int k = 0; k < rank && !s_fail; ++k) {
+        const double piv = A[k * LD + k];
+        if (!(piv > SPD_TOL * d0[k])) {
+            __syncthreads();
+            if (tid == 0) s_fail = 1;
+            __syncthreads();
+            break;
+        }
+        const double r = 1.0 / sqrt(piv);
+        __syncthreads();
+        if (tid == 0) A[k * LD + k] = sqrt(piv);
+        if (tid > k && tid < rank) A[tid * LD + k] *= r;
+        __syncthreads();
+        const int j = k + 1 + lane;
+        const double lk = (j < rank) ? A[j * LD + k] : 0.0;
+        for (int i = k + 1 + wave; i < rank; i += 4) {
+            const double lik = A[i * LD + k];
+            if (j <= i) A[i * LD + j] = fma(-lik, lk, A[i * LD + j]);
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (s_fail) {                                   // (uniform) some pivot of the chunk is not positive
+        if (tid == 0) {
+            ld_out[mp] = __longlong_as_double(0x7ff8000000000000LL);
+            quad_out[mp] = __longlong_as_double(0x7ff8000000000000LL);
+        }
+        return;
+    }
+    // ---- log det, w3 = M^-1 w2 (one wave: forward and backward substitution), v = e + R w3, the quadratic form
+    if (wave == 0) {
+        double lg = (lane < rank) ? log(A[lane * LD + lane]) : 0.0;
+        lg = wave_sum_x(lg);
+        double x = (lane < rank) ? vw2[lane] : 0.0;             // L z = w2
+        for (int k = 0; k < rank; ++k) {
+            const double zk = __shfl(x, k) / A[k * LD + k];
+            if (lane == k) x = zk;
+            else if (lane > k && lane < rank) x = fma(-A[lane * LD + k], zk, x);
+        }
+        for (int k = rank - 1; k >= 0; --k) {                   // L^T w3 = z
+            const double wk = __shfl(x, k) / A[k * LD + k];
+            if (lane == k) x = wk;
+            else if (lane < k) x = fma(-A[k * LD + lane], wk, x);
+        }
+        if (lane < 64) vw2[lane] = (lane < rank) ? x : 0.0;     // w3
+        if (lane == 0) s_red[0] = 2.0 * lg;
+    }
+    __syncthreads();
+    double q = 0.0;
+    if (tid < n) {
+        double v = ve[tid];
+        for (int k = 0; k < rank; ++k) v = fma(Rm[tid * LD + k], vw2[k], v);
+        q = vw1[tid] * v - 2.0 * vm[tid] * ve[tid] - vm[tid] * (vy[tid] - ve[tid]);
+    }
+    if (wave == 0) {
+        q = wave_sum_x(q);
+        if (lane == 0) { ld_out[mp] = s_red[0]; quad_out[mp] = q; }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_corr_finish_small(const int P, const int first, const int count, const double *__restrict__ ld,
+                    const double *__restrict__ quad, double *__restrict__ acc) {
+    const int pr = blockIdx.x, tid = threadIdx.x;
+    __shared__ double red[2][256];
+    double sl = 0.0, sq = 0.0;
+    for (int c = first + tid; c < first + count; c += 256) {
+        sl += ld[(size_t)pr * P + c];
+        sq += quad[(size_t)pr * P + c];
+    }
+    red[0][tid] = sl;
+    red[1][tid] = sq;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {         // fixed-shape tree: deterministic
+        if (tid < st) { red[0][tid] += red[0][tid + st]; red[1][tid] += red[1][tid + st]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        acc[3 * pr + 0] += red[0][0];
+        acc[3 * pr + 1] += red[1][0];
+    }
+}
+
 // corrections of the chunks first .. first + count - 1 of every problem, added to acc [B][3] (sum log d,
 // sum z^2 / d, min d: the accumulators of gf_reduce_tile); maps [B * P][WP x WP] / [B * P][WP]; work:
 // n (3 WP^2 + 18 WP + 1) doubles for n = B P
 size_t corrections_work(size_t n, int WP) { return n * (3 * (size_t)WP * WP + 18 * (size_t)WP + 1); }
+
+// W <= 63 (64 x 64 slots): everything in k_corr_small
+int chunk_corrections_small(int B, int P, int W, int first, int count, const double *X, const double *Y,
+                            const double *G, const double *m, double *acc, double *work, hipStream_t st) {
+    if (count < 1) return 0;
+    const long long n = (long long)B * P;
+    double *ld = work, *quad = work + n;
+    const int na = (W + 3) / 4 * 4;
+    const size_t lds = sizeof(double) * (2 * (size_t)na * (na + 1) + 7 * 64);
+    const void *fn[1] = {(const void *)k_corr_small};
+    if (lds > 64 * 1024 && !gf_internal_lds_opt_in(3, st, fn, 1, sizeof(double) * (2 * 64 * 65 + 7 * 64)))
+        return gf_internal_error(-1, "chunk corrections: cannot opt in to %lld bytes of LDS", (long long)lds);
+    hipLaunchKernelGGL(k_corr_small, dim3((unsigned)(B * count)), dim3(256), lds, st, P, first, count, na, X, Y, G, m,
+                       ld, quad);
+    hipLaunchKernelGGL(k_corr_finish_small, dim3(B), dim3(256), 0, st, P, first, count, ld, quad, acc);
+    return 0;
+}
 
 int chunk_corrections(int B, int P, int WP, int first, int count, const double *X, const double *Y,
                       const double *G, const double *m, double *acc, double *work, hipStream_t st) {
@@ -1032,16 +1298,17 @@ int64_t gf_wide_combine_work(int B, int nch, int Jc) {
 
 int64_t gf_chunk_corrections_work(int B, int nch) { return (B < 1 || nch < 1) ? -1 : (int64_t)corrections_work((size_t)B * nch, 64); }
 
-int gf_chunk_corrections(int B, int nch, int chunk_first, int chunk_count, const double *S_state,
+int gf_chunk_corrections(int B, int nch, int W, int chunk_first, int chunk_count, const double *S_state,
                          const double *F_state, const double *G, const double *m, double *acc, double *work,
                          void *stream) {
     if (B < 1 || nch < 1) return gf_internal_error(-1, "gf_chunk_corrections: empty problem (B=%d, nch=%d)", B, nch);
+    if (W < 1 || W > 63) return gf_internal_error(-1, "gf_chunk_corrections: width %d unsupported (1..63)", W);
     if (chunk_first < 0 || chunk_count < 0 || chunk_first + chunk_count > nch)
         return gf_internal_error(-1, "gf_chunk_corrections: bad chunk range (first=%d, count=%d)", chunk_first, chunk_count);
     if ((long long)B * nch > 65535) return gf_internal_error(-1, "gf_chunk_corrections: too many chunks (B*nch=%lld)", (long long)B * nch);
     if (!S_state || !F_state || !G || !m || !acc || !work) return gf_internal_error(-1, "gf_chunk_corrections: null pointer");
     // the 64 x 64 state slots are stored [column][row]: X and G are symmetric, so they ARE dense row-major maps
-    if (chunk_corrections(B, nch, 64, chunk_first, chunk_count, S_state, F_state, G, m, acc, work, (hipStream_t)stream))
+    if (chunk_corrections_small(B, nch, W, chunk_first, chunk_count, S_state, F_state, G, m, acc, work, (hipStream_t)stream))
         return -1;
     return gf_internal_check_launch("gf_chunk_corrections");
 }

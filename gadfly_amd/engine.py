@@ -1290,7 +1290,7 @@ class StreamingBatch:
         if "corr" not in w:
             w["corr"] = torch.empty((int(lib.gf_chunk_corrections_work(B, nch)),), dtype=torch.float64,
                                     device=self.device)
-        rc = lib.gf_chunk_corrections(B, nch, 1, nch - 1, p(w["S"]), p(w["F"]), p(w["G"]), p(w["m"]),
+        rc = lib.gf_chunk_corrections(B, nch, self.W, 1, nch - 1, p(w["S"]), p(w["F"]), p(w["G"]), p(w["m"]),
                                       p(w["acc"]), p(w["corr"]), st)
         _lib.check(rc, "gf_chunk_corrections")
         # a chunk of the nominal pass that failed: the first such row (exact for chunk 0; later chunks start

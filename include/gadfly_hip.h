@@ -345,13 +345,17 @@ int gf_wide_combine(int B, int64_t N, int64_t chunk_len, int nch, int Jc,
  * corrections: acc [B][3] (gf_reduce_tile's accumulators) += the sums over the chunks chunk_first ..
  * chunk_first + chunk_count - 1.  The nominal pass and the Gram sums must then cover the LAST chunk too
  * (gf_wide_combine with acc != NULL takes the Gram sums of chunks 1 .. nch - 1; pass NULL for the start
- * states alone).  det(I - X G) <= 0 -- a non-positive pivot inside the chunk -- makes the correction NaN:
- * the caller repeats such an evaluation with a final pass (which also names the failing row).
- * gf_chunk_corrections: the W <= 63 route (state slots [B*nch][64*64] / [B*nch][64] after gf_chunk_combine[_tree]);
+ * states alone).  A non-positive pivot ANYWHERE in the chunk makes the correction NaN -- the sign of EVERY pivot is
+ * checked, not the parity det(I - X G) gives: with X = R R^T (Cholesky with diagonal pivoting to the numerical
+ * rank) the chunk's pivots are all positive exactly when M = I - R^T G R is positive definite, decided by a
+ * Cholesky attempt on M -- and the caller repeats such an evaluation with a final pass, which also names the failing
+ * row (celerite2's LinAlgError semantics, reference gp.py:188-192).
+ * gf_chunk_corrections: the W <= 63 route (state slots [B*nch][64*64] / [B*nch][64] after gf_chunk_combine[_tree];
+ * W = the celerite width); one kernel per map, everything through the symmetric form (log det M, Woodbury for v);
  * work: gf_chunk_corrections_work(B, nch) doubles; B * nch <= 65535.
  */
 int64_t gf_chunk_corrections_work(int B, int nch);
-int gf_chunk_corrections(int B, int nch, int chunk_first, int chunk_count, const double *S_state,
+int gf_chunk_corrections(int B, int nch, int W, int chunk_first, int chunk_count, const double *S_state,
                          const double *F_state, const double *G, const double *m, double *acc, double *work,
                          void *stream);
 int gf_wide_gram(int B, int64_t N, int64_t chunk_len, int nch, int chunk_first, int chunk_count, int P, int Jc,
