@@ -830,6 +830,8 @@ struct RowGen {
     // dt > gthr (= gap / cmax), its spacing counts as the cached one when |ddt| < jthr (= 2e-6 / wmax)
     double gthr, jthr, jthr1;       // jthr1 = 1.4e-9 / wmax: below it the step's correction is first order
     int block, sub_mask;            // scaling block length; sub-anchor period - 1
+    // far from t = 0 the rotation steps follow celerite2's ROUNDED phases theta_n = fl(d t_n) (see step())
+    bool qmode;
     // running state: rho-scaled phasor, 1 / rho^2, cached one-cadence multipliers
     double cu, su, irho2, Er, Ei, G2, dt_ref, dt_last, tref, t_m1;
 
@@ -860,7 +862,10 @@ struct RowGen {
         const double wmax = read_lane(wave_max(fmax(cj, fabs(dj))), 0);
         gthr = read_lane(gap_ / cmax, 0);                       // uniform: live in SGPRs
         jthr = read_lane(2e-6 / wmax, 0);
-        jthr1 = read_lane(1.4e-9 / wmax, 0);
+        // phases beyond 4e6 rad at the first row (a time axis that does not start near zero: 5e9 rad on a JD-based
+        // one): their rounding, half an ulp of theta, is no longer negligible against the accuracy target
+        qmode = __builtin_amdgcn_readfirstlane((int)(wmax * fabs(tg[0]) > 4.0e6)) != 0;
+        jthr1 = qmode ? 0.0 : read_lane(1.4e-9 / wmax, 0);      // (the first-order step assumes |x| < 1.4e-9)
         block = block_sub & 0xff;           // (block <= 64) | (sub-anchor period << 8)
         sub_mask = ((block_sub >> 8) & 0xff) - 1;  // (bit 30: zero start, see the sweeps)
         cu = 1.0; su = 0.0; irho2 = 1.0; Er = 1.0; Ei = 0.0; G2 = 1.0; dt_ref = -1.0; dt_last = -2.0;
@@ -924,8 +929,22 @@ struct RowGen {
         dt_ref = read_lane(dt, 0);                  // uniform: keep it in SGPRs
     }
     __device__ __forceinline__ void step(const double tn, const double ddt) {
+        const double tp = t_m1;
         t_m1 = tn;
-        const double xr = -cj * ddt, xi = dj * ddt;
+        const double xr = -cj * ddt;
+        double xi;
+        if (qmode) {
+            // celerite2 takes cos / sin of theta_n = fl(d t_n): at 5e9 rad that is the true phase +- 5e-7 rad,
+            // row by row.  The step must land on THAT phase: the phasor stands at theta_{n-1}, the cached
+            // multiplier turns it by fl(d dt_ref) (what refresh() took the sincos of), so the correction is the
+            // difference of the two ROUNDED products -- exact (neighbouring values) -- minus that angle.  (The
+            // decay needs nothing of the kind: celerite2's exp(-c (t_n - t_{n-1})) sees the time difference too.)
+#pragma clang fp contract(off)
+            const double th_n = dj * tn, th_p = dj * tp;        // two rounded products, as celerite2 forms them
+            xi = (th_n - th_p) - dj * dt_ref;
+        } else {
+            xi = dj * ddt;
+        }
         double Mr, Mi, g2;
         if (fabs(ddt) < jthr1) {
             // |x| < 1.4e-9 (the rounding jitter of a regular cadence): exp(x) = 1 + x to 1e-18

@@ -926,17 +926,25 @@ class StreamingBatch:
     # ... + PHASE_ERR * quantum * condition / sqrt(N) for any period > 1, quantum = max|d t| 2^-53: celerite2's rows
     # (and the oracle's, and this library's exact rows) take cos / sin of theta = fl(d t), which carries up to half
     # an ulp of the PHASE as rounding -- 5e-7 rad at the 5e9 rad a JD-based axis reaches with the solar p-modes
-    # (/root/reference/gadfly/gp.py:79-80) -- while rotation steps between anchors follow the true phase.  The two
-    # sets of rows differ incoherently (zero mean, row by row), hence the 1 / sqrt(N); measured on time axes moved
-    # by 0 ... 2e6 (units of 1e6 s), N = 16 384 and 131 072, conditions of 34 and 135, periods 4 and 64
-    # (tools/phase_quantum.py, profiles/r04_phase_quantum.txt): observed error <= 0.03 quantum cond / sqrt(N).
+    # (/root/reference/gadfly/gp.py:79-80) -- while a rotation step by d (t_n - t_{n-1}) follows the true phase.  The
+    # two sets of rows differ incoherently (zero mean, row by row), hence the 1 / sqrt(N); measured on time axes
+    # moved by 0 ... 2e6 (units of 1e6 s), N = 16 384 and 131 072, conditions of 34 and 135, periods 4 and 64
+    # (tools/phase_quantum.py, profiles/r04_phase_quantum.txt): observed error <= 0.03 quantum cond / sqrt(N), up
+    # to 1e-7 on a JD axis.  The kernels therefore take the step's angle from the difference of the ROUNDED
+    # products wherever phases exceed QMODE_PHASE (RowGen::qmode): the same measurement then shows 1e-13 at every
+    # offset and period, and the term below only covers the phases under that threshold.
     PHASE_ERR = 0.1
     #: condition assumed for the phase-quantum term before any evaluation has measured one
     NOMINAL_COND = 1.0e3
 
+    #: phases beyond this at the first row of a tile / chunk switch the generator's rotation steps to the ROUNDED
+    #: phase differences celerite2's rows carry (RowGen::qmode in gadfly_hip.hip): the phase quantum then drops out
+    QMODE_PHASE = 4.0e6
+
     def phase_quantum(self):
-        """Half an ulp of the largest phase |d t| of the current coefficients."""
-        return float(self._pack[6]) * self._tmax * 2.0 ** -53
+        """Half an ulp of the largest phase |d t| a rotation step may still see un-corrected: tiles and chunks that
+        start beyond QMODE_PHASE follow the rounded phases exactly."""
+        return min(float(self._pack[6]) * self._tmax, self.QMODE_PHASE) * 2.0 ** -53
 
     def phase_error_coefficient(self):
         """Relative log-likelihood error per unit of condition number that a generator period > 1 adds through

@@ -4,7 +4,9 @@ JD-based time axes: the reference turns an astropy ``Time`` into ``jd * day`` an
 :150-155) and the runtime-speed notebook's ``Time(0, format='bkjd')`` axis (notebooks/paper/runtime-speed.ipynb:40)
 hand the GP times around 2.12e5 (units of 1e6 s), where the solar p-modes reach phases d t of 4-5e9 rad.
 Round 3's in-kernel sincos stopped at 3e9 and every fast path switched off there; it now holds to 1e12 (64-bit
-quadrant, oracle/fastmath_check.c), and the generator-period rule knows the phase quantum (engine.PHASE_ERR).
+quadrant, oracle/fastmath_check.c).  And celerite2 takes cos / sin of the ROUNDED product theta = fl(d t) -- half an
+ulp of the phase, 5e-7 rad at 5e9 -- so the generator's rotation steps between anchors take their angle from the
+difference of those rounded products (RowGen::qmode): every generator period reproduces celerite2's rows there.
 
 Every route -- streamed fused sweep, three-sweep and two-sweep time-parallel evaluation, the stored scaled factor,
 the wide kernels (W = 80 and the 86-term solar kernel's W = 172: streamed, time-parallel, `WideFactor`), the
@@ -57,14 +59,22 @@ def test_fused_routes_on_a_jd_axis(hip, J, N, kw):
     ref = _ref(prob)
     eng = StreamingBatch([co], t, y, diag=prob["diag_user"], tile_rows=1024)
     assert eng._pack[6] * eng._tmax > 3.5e9 and eng._fused_ok()        # beyond round 3's range, still fused
-    assert eng.generator_period == 1                                    # the phase quantum rules rotation out
-    ll = float(eng.log_likelihood()[0])
-    assert eng.kernel_used == "fused" and abs(ll - ref) <= RTOL_LL * abs(ref), (ll, ref)
-    for two in (False, True):
-        eng.two_sweep = two
-        ll_tp = float(eng.log_likelihood_time_parallel(chunk_len=512)[0])
-        assert eng._two_sweep_used == two and abs(ll_tp - ref) <= RTOL_LL * abs(ref), (two, ll_tp, ref)
-    eng.two_sweep = False
+    assert eng.generator_period == 4                                    # the default: rotation steps are allowed
+    cond = None
+    for period in (4, 1, 64):
+        # (period 64 where the conditioning allows it by the product's own rule -- yerr = 0 does not)
+        if period == 64 and eng.period_for_condition(cond) < 64:
+            continue
+        eng.generator_period = period
+        ll = float(eng.log_likelihood()[0])
+        cond = eng.condition_estimate() if cond is None else cond
+        assert eng.kernel_used == "fused" and abs(ll - ref) <= RTOL_LL * abs(ref), (period, ll, ref)
+        for two in (False, True):
+            eng.two_sweep = two
+            ll_tp = float(eng.log_likelihood_time_parallel(chunk_len=512)[0])
+            assert eng._two_sweep_used == two and abs(ll_tp - ref) <= RTOL_LL * abs(ref), (period, two, ll_tp, ref)
+        eng.two_sweep = False
+    eng.generator_period = 1
     # the stored scaled factor: solves and draws
     fac = eng.stored_factor(chunk_len=512)
     c, a, U, V = util.oracle_matrices(prob, seq)
@@ -87,39 +97,42 @@ def test_wide_routes_on_a_jd_axis(hip, J, N):
     ref = _ref(prob)
     eng = StreamingBatch([co, co], t, y, diag=prob["diag_user"], tile_rows=1024)
     assert eng._pack[6] * eng._tmax > 3.5e9 and eng._wide_ok() and not eng._fused_ok()
-    assert eng.generator_period == 1
-    ll = eng.log_likelihood().cpu().numpy()
-    assert eng.kernel_used == "fused-wide"
-    assert np.max(np.abs(ll - ref)) <= RTOL_LL * abs(ref), (ll, ref)
-    for two in (False, True):
-        eng.two_sweep = two
-        ll_tp = eng.log_likelihood_time_parallel(chunk_len=640).cpu().numpy()
-        assert eng._last_wide_tp and eng._two_sweep_used == two
-        assert np.max(np.abs(ll_tp - ref)) <= RTOL_LL * abs(ref), (two, ll_tp, ref)
+    for period in (1, 64):
+        eng.generator_period = period
+        ll = eng.log_likelihood().cpu().numpy()
+        assert eng.kernel_used == "fused-wide"
+        assert np.max(np.abs(ll - ref)) <= RTOL_LL * abs(ref), (period, ll, ref)
+        for two in (False, True):
+            eng.two_sweep = two
+            ll_tp = eng.log_likelihood_time_parallel(chunk_len=640).cpu().numpy()
+            assert eng._last_wide_tp and eng._two_sweep_used == two
+            assert np.max(np.abs(ll_tp - ref)) <= RTOL_LL * abs(ref), (period, two, ll_tp, ref)
+        eng.two_sweep = False
 
 
-def test_batched_evaluator_keeps_exact_rows_on_a_jd_axis(hip):
-    """BatchedLogLikelihood calibrates the generator period from the measured conditioning; on a JD axis the
-    phase-quantum term must keep it at 1 (rotation rows would differ from celerite2's rounded-phase rows by
-    up to 5e-7 rad), on the same series moved to t = 0 it may lengthen."""
+def test_batched_evaluator_lengthens_the_generator_period_on_a_jd_axis(hip):
+    """BatchedLogLikelihood calibrates the generator period from the measured conditioning.  On a JD axis the
+    rotation steps follow celerite2's rounded phases (RowGen::qmode), so the calibrated period may lengthen there as
+    it does on the same series moved to t = 0 -- and the values stay within 1e-8 of the oracle (before qmode a
+    period of 64 was 5e-9 ... 1e-7 off at this phase range: profiles/r04_phase_quantum.txt)."""
     import gadfly_amd
     from gadfly_amd.synth import jitter_hyperparameters, solar_like_hyperparameters
     N, B = 20_000, 5
     prob = _jd_problem(30, N)
     hps = [jitter_hyperparameters(solar_like_hyperparameters(30), seed=1000 + i) for i in range(B)]
     kernels = [gadfly_amd.StellarOscillatorKernel(hp, texp=60.0) for hp in hps]
-    ev = gadfly_amd.BatchedLogLikelihood(kernels, prob["t"], prob["y"], yerr=30.0)
-    for _ in range(2):                                  # the second evaluation runs at the calibrated period
-        ll = ev.evaluate()
-        assert ev.engine.generator_period == 1
-        assert ev.engine._fused_ok() and ev.engine._tp_used          # time-parallel, fused
-    for i in (0, B - 1):
-        p = dict(prob, kernel=kernels[i])
-        ref = _ref(p)
-        assert abs(ll[i] - ref) <= RTOL_LL * abs(ref), (i, ll[i], ref)
-    ev0 = gadfly_amd.BatchedLogLikelihood(kernels, prob["t"] - BKJD0, prob["y"], yerr=30.0)
-    ev0.evaluate()
-    assert ev0.engine.generator_period > 1
+    refs = [_ref(dict(prob, kernel=k)) for k in kernels]
+    for t in (prob["t"], prob["t"] - BKJD0):
+        ev = gadfly_amd.BatchedLogLikelihood(kernels, t, prob["y"], yerr=30.0)
+        periods = []
+        for _ in range(3):                              # the later evaluations run at the calibrated period
+            periods.append(int(ev.engine.generator_period))
+            ll = ev.evaluate()
+            assert ev.engine._fused_ok() and ev.engine._tp_used          # time-parallel, fused
+            if t is prob["t"]:
+                for i in range(B):
+                    assert abs(ll[i] - refs[i]) <= RTOL_LL * abs(refs[i]), (periods, i, ll[i], refs[i])
+        assert periods[0] == 4 and periods[-1] == 64, periods
 
 
 @pytest.mark.parametrize("J,N", [(30, 12_000), (86, 18_000)], ids=["J30", "solar-W172"])
