@@ -247,6 +247,7 @@ def other_configs(check):
     out = {}
     for name, fn in (("cfg2_api", configs.measure_cfg2_api),
                      ("cfg2_api_jd", lambda: configs.measure_cfg2_api(jd=True)),
+                     ("jd_batch", configs.measure_jd_batch),
                      ("runtime_speed", configs.measure_runtime_speed),
                      ("cfg3", configs.measure_cfg3),
                      ("cfg3_shard", lambda: configs.measure_cfg3_shard(out["cfg3"]["ms"])),

@@ -1135,9 +1135,11 @@ k_factor3(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
         const double inv = fast_rcp(dn);
         q = fma(zn, is63, r) * inv;                 // lane 63: z / d (r is 0 there)
         const size_t ro = opaque_uniform((size_t)n * 64);
-        if (rg) rg[ro] = r;                         // r~ rows for k_phi (chunk mode)
-        if (ug) ug[ro] = ut_c;
-        if (wg) wg[ro] = fl ? 0.0 : q;
+        if (lane < ROWS || wg) {                    // (nominal passes store the first ROWS columns only: k_factor7)
+            if (rg) rg[ro] = r;                     // r~ rows for k_phi (chunk mode)
+            if (ug) ug[ro] = ut_c;
+            if (wg) wg[ro] = fl ? 0.0 : q;
+        }
         if (lane == 0) { dg[n] = dn; zg[n] = zn; }
     }
     if (fail) {
@@ -1293,6 +1295,10 @@ k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
     double *__restrict__ rg = (ROWSTORE && r_out) ? r_out + pb * 64 + own : nullptr;
     double *__restrict__ ug = (ROWSTORE && Ut_out) ? Ut_out + pb * 64 + own : nullptr;
     double *__restrict__ wg = (ROWSTORE && Wt_out) ? Wt_out + pb * 64 + own : nullptr;
+    // a nominal pass (no w~ rows: nothing but the transition sweep reads what it stores) writes the first ROWS
+    // columns of its 64-double rows only -- cfg3 (W = 40) moved 34 GB per evaluation, a third of it padding; the
+    // stored factor's rows keep their zero padding (the solves read whole rows)
+    const bool st_ok = own < ROWS || Wt_out != nullptr;
     double *__restrict__ eg = (ROWSTORE && de_out) ? de_out + pb : nullptr;
     double *__restrict__ Sg = S_state + (size_t)b * (64 * 64);     // [column][row]
     double *__restrict__ Fg = F_state + (size_t)b * 64;
@@ -1385,9 +1391,11 @@ k_factor7(const int64_t N, const int64_t n_first, const int64_t chunk_len, const
         q1 = fma(zn, is31, r1) * inv;               // column 63: z / d (r is 0 there)
         if constexpr (ROWSTORE) {
             const size_t ro = opaque_uniform((size_t)n * 64);
-            if (rg) rg[ro] = r;                     // r~ rows for k_phi (chunk mode)
-            if (ug) ug[ro] = ut_c;
-            if (wg) wg[ro] = r * inv;
+            if (st_ok) {
+                if (rg) rg[ro] = r;                 // r~ rows for k_phi (chunk mode)
+                if (ug) ug[ro] = ut_c;
+                if (wg) wg[ro] = r * inv;
+            }
         }
         if (lane == 0) { dg[n] = dn; zg[n] = zn; }
     }
@@ -1442,6 +1450,9 @@ struct PhiCursor {
     unsigned long long ustep;
     bool in_u, in_r;
     unsigned lds_u, lds_r;
+    // `rows`: the sweep's state rows (ROWS >= W): the copies fetch the row's first `rows` doubles only -- with the
+    // nominal pass storing no more than that (see its row stores) the padding of the 64-double rows never travels
+    template <int rows = 64>
     __device__ __forceinline__ void init(PhiRing &R, const int lane, const size_t pb, const double *ut_,
                                          const double *rbar_, const double *dbar_, const double *de_,
                                          const double *zbar_) {
@@ -1455,8 +1466,8 @@ struct PhiCursor {
             mask = ~(uintptr_t)15;
             ustep = 8;
         }
-        in_u = lane < 35;
-        in_r = lane < 32;
+        in_u = lane < (rows + 1) / 2 || (lane >= 32 && lane < 35);
+        in_r = lane < (rows + 1) / 2;
         lds_u = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(&R.u[0][0]));
         lds_r = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(&R.r[0][0]));
     }
@@ -1565,7 +1576,7 @@ k_phi7(const int64_t N, const int64_t chunk_len, const int nch, const int ch0, c
     for (int e = lane; e < 16 * PhiGram<NT>::LD; e += 64) (&Gm.hs[0][0])[e] = 0.0;
     if (lane < 16) Gm.sv[lane] = 0.0;
     PhiCursor C;
-    C.init(R, lane, pb, ut_, rbar_, dbar_, de_, zbar_);
+    C.template init<ROWS>(R, lane, pb, ut_, rbar_, dbar_, de_, zbar_);
 #pragma unroll
     for (int m = 0; m < PD - 1; ++m) C.issue(m, 0);
     vm_wait<2 * (PD - 2)>();                        // row 0 has landed
@@ -2230,7 +2241,7 @@ k_phi(const int64_t N, const int64_t chunk_len, const int nch, const int ch0, co
     for (int e = lane; e < 16 * PhiGram<NT>::LD; e += 64) (&Gm.hs[0][0])[e] = 0.0;
     if (lane < 16) Gm.sv[lane] = 0.0;
     PhiCursor C;
-    C.init(R, lane, pb, ut_, rbar_, dbar_, de_, zbar_);
+    C.template init<ROWS>(R, lane, pb, ut_, rbar_, dbar_, de_, zbar_);
 #pragma unroll
     for (int m = 0; m < PD - 1; ++m) C.issue(m, 0);
     vm_wait<2 * (PD - 2)>();

@@ -250,7 +250,20 @@ def measure_cfg2_api(jd=False):
     gb_ll = 8.0 * N * (3 * W + 4) / 1e9
     gb_ai = 8.0 * N * (4 * W + 7) / 1e9
     idx = np.linspace(0, N - 1, 64).astype(int)
-    return {"workload": f"cfg2 through the drop-in GaussianProcess: N={N}, J={J} (W={W}), ONE series "
+    first = None
+    if not jd:
+        # the FIRST compute() of a process, reported apart from the warm latency (a child process: code-object load,
+        # LDS opt-ins, first allocations)
+        import json
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "first_call.py")],
+                               capture_output=True, text=True, timeout=300)
+            first = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        except Exception as e:      # noqa: BLE001  (a diagnostic leg: never fails the run)
+            first = {"error": repr(e)[:200]}
+    return {"first_call": first,
+            "workload": f"cfg2 through the drop-in GaussianProcess: N={N}, J={J} (W={W}), ONE series "
                         "(latency path: exact time-parallel factorisation / sweeps); host arrays in, "
                         "host arrays out (PCIe included)"
                         + ("; time axis = BKJD 0 + n minutes as jd * day (t ~ 2.12e5, phases to 5e9 rad)" if jd else ""),
@@ -263,6 +276,45 @@ def measure_cfg2_api(jd=False):
             "predict_mean_frac": gb_ai / p_ms / HBM_PEAK_GBS,
             "_sample": dict(kind="predict", coeffs=k.get_device_coefficients(), t=t, diag=np.full(N, 900.0),
                             y=y, ts=ts, idx=idx, got_ll=float(ll), got_mu=mu[idx].copy(), got_mus=mus.copy())}
+
+
+def measure_jd_batch():
+    """The headline's workload on a JD-based time axis (BKJD 0 + n minutes, phases of 5e9 rad), at a length that
+    keeps the leg short: 2048 walkers x N = 131 072, J = 30, streamed fused sweep, at the generator period the
+    evaluator calibrates itself to and with exact rows -- next to the same batch on the zero-based axis.  Until
+    round 4 such an axis ran on the materialised-row kernels (phases beyond the in-kernel sincos) and, once fused,
+    needed exact rows (the phase quantum)."""
+    import torch
+    import gadfly_amd
+    from gadfly_amd.synth import jitter_hyperparameters, solar_like_hyperparameters, uniform_times
+    B, N, J = 2048, 131_072, 30
+    base = solar_like_hyperparameters(J)
+    kernels = [gadfly_amd.StellarOscillatorKernel(jitter_hyperparameters(base, 1000 + i), texp=60.0) for i in range(B)]
+    rng = np.random.Generator(np.random.PCG64(12345))
+    y = np.cumsum(rng.normal(size=N)) * 5.0 + 30.0 * rng.normal(size=N)
+    out = {}
+    for name, t0 in (("jd_axis", BKJD0), ("zero_based", 0.0)):
+        t = t0 + uniform_times(N, 60.0)
+        ev = gadfly_amd.BatchedLogLikelihood(kernels, t, y, yerr=30.0)
+        ev.engine.force_streaming = True
+        ev.evaluate()                               # warm-up + generator calibration
+        dt, res = _clock(torch, lambda: _guarded(ev), reps=3, warm=1)
+        period = int(ev.engine.generator_period)
+        ev.auto_generator_period = False
+        ev.engine.generator_period = 1
+        dt1, _ = _clock(torch, lambda: _guarded(ev), reps=2, warm=1)
+        out[name] = {"ms": 1e3 * dt, "generator_period": period, "row_evaluations_per_s": B * N / dt,
+                     "exact_rows_ms": 1e3 * dt1, "path": _path(ev.engine)}
+        if name == "jd_axis":
+            ll = res.cpu().numpy()
+            i = B - 1
+            sample = dict(kind="loglike", index=i, coeffs=kernels[i].get_device_coefficients(), t=t,
+                          diag=np.full(N, 900.0), y=y, got=float(ll[i]))
+        del ev
+        torch.cuda.empty_cache()
+    return {"workload": f"{B} walkers x N={N}, J={J} (W={2 * J}) streamed, on t = BKJD 0 + n minutes as jd * day "
+                        "(phases to 5e9 rad) and on the zero-based axis",
+            **out, "jd_over_zero_based": out["jd_axis"]["ms"] / out["zero_based"]["ms"], "_sample": sample}
 
 
 def measure_runtime_speed():
@@ -329,7 +381,8 @@ def main():
             from gadfly_amd import _lib
             _lib.SO_PATH = os.path.abspath(a[5:])
     fns = dict(cfg2=measure_cfg2_api, cfg2jd=lambda: measure_cfg2_api(jd=True), cfg3=measure_cfg3, cfg4=measure_cfg4,
-               cfg5=measure_cfg5, cfg3s=measure_cfg3_shard, cfg4s=measure_cfg4_shard, runtime=measure_runtime_speed)
+               cfg5=measure_cfg5, cfg3s=measure_cfg3_shard, cfg4s=measure_cfg4_shard, runtime=measure_runtime_speed,
+               jdbatch=measure_jd_batch)
     for fn in ([fns[w] for w in which] if which else fns.values()):
         r = fn()
         r.pop("_sample", None)

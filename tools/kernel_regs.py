@@ -10,12 +10,12 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SO = os.path.join(ROOT, "gadfly_amd", "csrc", "libgadfly_hip.so")
+SO = os.environ.get("GADFLY_SO") or os.path.join(ROOT, "gadfly_amd", "csrc", "libgadfly_hip.so")
 LLVM = "/opt/rocm/lib/llvm/bin"
 pats = sys.argv[1:]
 tmp = tempfile.mkdtemp()
 try:
-    shutil.copy(SO, tmp)
+    shutil.copy(SO, os.path.join(tmp, "libgadfly_hip.so"))
     subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", "libgadfly_hip.so"], cwd=tmp, check=True,
                    stdout=subprocess.DEVNULL)
     rows = []
