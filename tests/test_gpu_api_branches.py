@@ -40,8 +40,17 @@ def test_conditional_distribution_with_another_kernel_and_without_mean(hip, N, J
     diag = prob["diag_user"] + co[6]
     mean = 2.5
     gp = gadfly_amd.GaussianProcess(k, t=t, mean=mean, diag=prob["diag_user"])
-    K = dense.dense_K(co[:6], t, diag)
-    alpha = np.linalg.solve(K, y - mean)
+    if N <= 2000:
+        K = dense.dense_K(co[:6], t, diag)
+        alpha = np.linalg.solve(K, y - mean)
+    else:
+        # (a dense solve of 9000 unknowns takes half a minute: K^-1 (y - mean) from the oracle's recurrences, which
+        # tests/test_oracle.py pins to the dense formulation; the products with K_other below stay dense)
+        from oracle import cref, seq
+        c, a, U, V = util.oracle_matrices(prob, seq)
+        d_ref, W_ref, info = cref.factor(t, c, a, U, V)
+        assert info == 0
+        alpha = cref.solve_upper(t, c, U, W_ref, cref.solve_lower(t, c, U, W_ref, y - mean) / d_ref)
     rng = np.random.default_rng(3)
     ts = np.sort(rng.uniform(t[0], t[-1], 70))
 
@@ -163,9 +172,14 @@ def test_covariance_of_a_long_series_tail_rows_and_slab_budget(hip):
     gp = gadfly_amd.GaussianProcess(k, t=t, diag=prob["diag_user"])
     rng = np.random.default_rng(4)
     ts = np.sort(rng.uniform(t[0], t[-1], 70))
-    K = dense.dense_K(co[:6], t, prob["diag_user"] + co[6])
     Ks = k.get_value(t[:, None] - ts[None, :])
-    cov_ref = k.get_value(ts[:, None] - ts[None, :]) - Ks.T @ np.linalg.solve(K, Ks)
+    # (K^-1 K(t, t*) through the oracle's recurrences: a dense solve of 9001 unknowns takes half a minute)
+    from oracle import cref, seq
+    c, a, U, V = util.oracle_matrices(prob, seq)
+    d_ref, W_ref, info = cref.factor(t, c, a, U, V)
+    assert info == 0
+    sol = cref.solve_upper(t, c, U, W_ref, cref.solve_lower(t, c, U, W_ref, Ks) / d_ref[:, None])
+    cov_ref = k.get_value(ts[:, None] - ts[None, :]) - Ks.T @ sol
     _, cov = gp.predict(y, t=ts, return_cov=True)
     assert _relmax(cov, cov_ref) < TOL_COV
     _, var = gp.predict(y, t=ts, return_var=True)
