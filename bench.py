@@ -478,7 +478,7 @@ def main():
         # guide's gfx950 correction; profiles/r03_traffic.json, else earlier rounds), scaled to this launch
         # shape: a constant measured on this kernel, not a counter of this run
         traffic, traffic_src = None, None
-        for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:
                 tr = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if tr.get("W") == W and fused:

@@ -44,7 +44,7 @@ cfg3)
   sq $O/r04_sq_cfg3_factor7.txt "k_factor7<40" $((65000*256)) tools/cfg3_chunks.py 8128
   sq $O/r04_sq_cfg3_phi7.txt "k_phi7<40" $(((65000-8128)*256)) tools/cfg3_chunks.py 8128
   f=$(pmc fetch FETCH_SIZE tools/cfg3_chunks.py 8128); g=$(pmc write WRITE_SIZE tools/cfg3_chunks.py 8128)
-  python3 $R/tools/pmc_bytes.py $f $g $O/r04_cfg3_traffic.json "k_factor7<40, true" "k_factor7<40, false" "k_phi7<40" k_combine
+  python3 $R/tools/pmc_bytes.py $f $g $O/r04_cfg3_traffic.json "k_factor7<40, true" "k_factor7<40, false" "k_phi7<40" k_combine k_corr_small
   ;;
 cfg3s)
   echo "== cfg3 shard"; prof cfg3s tools/configs.py cfg3s
