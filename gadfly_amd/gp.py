@@ -257,7 +257,22 @@ class GaussianProcess:
         if self._mean_value is None:
             raise RuntimeError(
                 "'compute' must be executed before accessing mean_value")
+        # (a constant mean is kept as the scalar it is -- every use broadcasts -- and expanded for this accessor)
+        if np.ndim(self._mean_value) == 0:
+            return np.full(self._size, float(self._mean_value), dtype=np.float64)
         return self._mean_value
+
+    # the user diagonal as an array (celerite2's `_diag`): a scalar yerr / diag is expanded on first use -- the
+    # device gets it as a fill, and compute() on 1e6 cadences does not spend half a millisecond writing it out
+    @property
+    def _diag(self):
+        if self._diag_arr is None and getattr(self, "_diag_const", None) is not None and self._size is not None:
+            self._diag_arr = np.full(self._size, self._diag_const, dtype=np.float64)
+        return self._diag_arr
+
+    @_diag.setter
+    def _diag(self, value):
+        self._diag_arr = value
 
     # ---- unit handling (reference gp.py:61-165) ----------------------------
     @staticmethod
@@ -379,7 +394,9 @@ class GaussianProcess:
             raise ValueError("The input coordinates must be sorted")
         self._t = t
         self._size = N
-        self._mean_value = self._mean(t)
+        self._mean_value = (float(self._mean.value) if isinstance(self._mean, _ConstantMean) and np.ndim(self._mean.value) == 0
+                            else self._mean(t))
+        self._diag = None
         self._t_dev = self._diag_dev = None
         self._diag_const = 0.0              # a scalar diagonal is made on the device, not uploaded
         if yerr is not None and diag is not None:
@@ -394,8 +411,6 @@ class GaussianProcess:
         elif diag is not None:
             self._diag_const = None
             self._diag = np.array(np.broadcast_to(np.asarray(diag, dtype=np.float64), (N,)))
-        if self._diag_const is not None:
-            self._diag = np.full(N, self._diag_const, dtype=np.float64)        # (one pass: celerite2 keeps it too)
         # statistics of the time axis the engine needs (largest |t|, typical spacing), taken here on the host: as
         # device reductions they cost a 1e6-element sort and two host synchronisations per compute()
         if N > 1:
