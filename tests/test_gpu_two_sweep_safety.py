@@ -158,3 +158,32 @@ def test_two_sweep_condition_estimate_covers_the_true_pivots(hip, Q, yerr):
     assert abs(ll - ref) <= RTOL_LL * abs(ref)
     est = eng.condition_estimate()
     assert est >= 0.99 * true_cond, (est, true_cond)
+
+
+@pytest.mark.parametrize("what", ["W2", "W12", "W62", "mixed-real-terms", "overdamped"])
+def test_single_kernel_corrections_at_every_width(hip, what):
+    """The W <= 63 corrections run in ONE kernel per chunk map on the active width rounded up to 4 (k_corr_small: 4 x 4
+    register tiles, two n x (n + 1) LDS buffers -- 70 KB at W = 62, which needs the large-LDS opt-in): the narrowest and
+    the widest kernels, and kernels with real terms (the one-column-per-lane sweep), two sweeps against three and
+    against the oracle, several chunkings incl. a ragged last chunk."""
+    from tests import util
+    from gadfly_amd.engine import StreamingBatch
+    from oracle import cref
+    if what.startswith("W"):
+        prob = util.solar_problem({"W2": 1, "W12": 6, "W62": 31}[what], 2600, yerr=30.0 if what != "W12" else 0.0)
+    else:
+        prob = util.generic_problem("mixed" if what.startswith("mixed") else "overdamped", 1500)
+    co = prob["kernel"].get_device_coefficients()
+    t, y = prob["t"], prob["y"]
+    ref, info = cref.loglike(co[:6], t, prob["diag_user"] + co[6], y)
+    assert info == 0
+    eng = StreamingBatch([co, co, co], t, y, diag=prob["diag_user"])
+    eng.generator_period = 1
+    for L in (64, 192, 1000):
+        eng.two_sweep = False
+        ll3 = eng.log_likelihood_time_parallel(chunk_len=L).cpu().numpy()
+        eng.two_sweep = True
+        ll2 = eng.log_likelihood_time_parallel(chunk_len=L).cpu().numpy()
+        assert eng._two_sweep_used or eng._tp_chunking(L)[1] == 1
+        assert np.max(np.abs(ll2 - ref)) <= RTOL_LL * abs(ref), (what, L, ll2, ref)
+        assert np.max(np.abs(ll2 - ll3)) <= 1e-10 * abs(ref), (what, L, ll2, ll3)
