@@ -2293,16 +2293,10 @@ k_phi(const int64_t N, const int64_t chunk_len, const int nch, const int ch0, co
 // matrices are stored [j][i] (column-major = the lane-major layout of the sweep states).
 constexpr int CB_LD = 65, CB_LA = 130;
 
-// n (uniform): the map is zero beyond its leading n x n block (state width n <= 64 in a 64 x 64 slot): only that
-// block is fetched -- at W = 40 that is 12.8 of the slot's 32 KB, and the first levels of a tree over 1024+ pairs
-// run at the pace of these loads
 __device__ __forceinline__ void cb_load(double *dst, const double *__restrict__ src, int tid,
-                                        int ld = CB_LD, const int n = 64) {
+                                        int ld = CB_LD) {
     _Pragma("unroll 16")
-    for (int e = tid; e < 4096; e += 256) {
-        const int j = e >> 6, i = e & 63;
-        dst[i * ld + j] = (i < n && j < n) ? src[e] : 0.0;
-    }
+    for (int e = tid; e < 4096; e += 256) { const int j = e >> 6, i = e & 63; dst[i * ld + j] = src[e]; }
 }
 
 // 64 x 64 x 64 products on v_mfma_f64_16x16x4 (256 threads = 4 waves; wave w owns rows 16w..16w+15
@@ -2421,7 +2415,7 @@ __device__ __forceinline__ void cb_apply(double *Xs, double *Au, double *Bs, dou
     // e = tid + 256 q of the [j][i] layout, yreg = element tid)
     constexpr int LD = CB_LD, LA = CB_LA;
     const int tx = tid & 15, ty = tid >> 4;
-    cb_load(Bs, Gg, tid, CB_LD, n);
+    cb_load(Bs, Gg, tid);
     if (tid < 64) vs[tid] = mg[tid];
     __syncthreads();
     {
@@ -2444,7 +2438,7 @@ __device__ __forceinline__ void cb_apply(double *Xs, double *Au, double *Bs, dou
     __syncthreads();
     cb_gauss_jordan(Au, Bs, tid, n);
     // Bs <- Phi ; Xs <- Z = Phi K  (K symmetrised)
-    cb_load(Bs, Pg, tid, CB_LD, n);
+    cb_load(Bs, Pg, tid);
     if (tid < 64) vs[tid] = Au[tid * LA + 128];
     __syncthreads();
     {
@@ -2472,8 +2466,7 @@ __device__ __forceinline__ void cb_apply(double *Xs, double *Au, double *Bs, dou
 #pragma unroll
     for (int q = 0; q < 16; ++q) {              // add Xbar (coalesced) and symmetrise
         const int e = tid + 256 * q, j = e >> 6, i = e & 63;
-        const bool in = i < n && j < n;         // (maps and states are zero beyond their leading n x n block)
-        Xs[i * LD + j] = in ? (Xbar ? Xbar[e] : xreg[q]) + 0.5 * (Au[i * LA + j] + Au[j * LA + i]) : 0.0;
+        Xs[i * LD + j] = (Xbar ? Xbar[e] : xreg[q]) + 0.5 * (Au[i * LA + j] + Au[j * LA + i]);
     }
     if (tid < 64) Ys[tid] = ynew;
     __syncthreads();
@@ -2548,8 +2541,8 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
     const int n = FULL ? 64 : A.n, nt = FULL ? 4 : ((n + 15) >> 4);
     double *w = v1, *vv = v1 + 64, *g2v = v1 + 128, *tmpv = v1 + 192;
     // a. M0 = Xbar1, M1 = G2 ;  AL = I - Xbar1 G2 ; AR = I ; col 128 = Ybar1 - Xbar1 m2
-    cb_load(M0, A.S + L * 4096, tid, CB_LD, n);
-    cb_load(M1, A.G + Rr * 4096, tid, CB_LD, n);
+    cb_load(M0, A.S + L * 4096, tid);
+    cb_load(M1, A.G + Rr * 4096, tid);
     if (tid < 64) tmpv[tid] = A.m[Rr * 64 + tid];
     __syncthreads();
     {
@@ -2571,7 +2564,7 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
     }
     __syncthreads();
     cb_gauss_jordan(Au, M1, tid, n);          // AR = D, col 128 = v   (M1 serves as scratch ...
-    cb_load(M1, A.G + Rr * 4096, tid, CB_LD, n);    // ... so G2 is loaded again)
+    cb_load(M1, A.G + Rr * 4096, tid);      // ... so G2 is loaded again)
     if (tid < 64) vv[tid] = Au[tid * LA + 128];
     __syncthreads();
     if (tid < 64) {                         // g2v = G2 v ;  m12 pieces need it
@@ -2588,7 +2581,7 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
     }
     __syncthreads();
     // d. M0 = Phi2 ;  AL <- Phi2 (D Xbar1) ;  Xbar12 = Xbar2 + AL Phi2^T ;  Ybar12 = Ybar2 + Phi2 v
-    cb_load(M0, A.Phi + Rr * 4096, tid, CB_LD, n);
+    cb_load(M0, A.Phi + Rr * 4096, tid);
     __syncthreads();
     {
         double acc[4][4] = {};
@@ -2614,12 +2607,12 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
         _Pragma("unroll 16")
         for (int e = tid; e < 4096; e += 256) {
             const int j = e >> 6, i = e & 63;
-            if (i < n && j < n) Sr[e] += 0.5 * (Au[i * LA + j] + Au[j * LA + i]);      // (zero beyond: left as it is)
+            Sr[e] += 0.5 * (Au[i * LA + j] + Au[j * LA + i]);
         }
     }
     __syncthreads();
     // e. AL = Phi1 ;  AR <- D Phi1 ;  Phi12 = Phi2 (D Phi1)
-    cb_load(Au, A.Phi + L * 4096, tid, LA, n);
+    cb_load(Au, A.Phi + L * 4096, tid, LA);
     __syncthreads();
     {
         double acc[4][4] = {};
@@ -2635,8 +2628,7 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (cb_col(tx, a) < n && cb_row(ty, c) < n) Pr[(size_t)cb_col(tx, a) * 64 + cb_row(ty, c)] = acc[a][c];
+            for (int c = 0; c < 4; ++c) Pr[(size_t)cb_col(tx, a) * 64 + cb_row(ty, c)] = acc[a][c];
     }
     __syncthreads();
     // f. M1 <- G2 (D Phi1) ;  G12 = G1 + Phi1^T M1 ;  m12 = m1 + Phi1^T (m2 - G2 v)
@@ -2666,7 +2658,7 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
         _Pragma("unroll 16")
         for (int e = tid; e < 4096; e += 256) {
             const int j = e >> 6, i = e & 63;
-            if (i < n && j < n) Gr[e] = Gl[e] + 0.5 * (M0[i * LD + j] + M0[j * LD + i]);
+            Gr[e] = Gl[e] + 0.5 * (M0[i * LD + j] + M0[j * LD + i]);
         }
     }
 }
@@ -2695,11 +2687,10 @@ __global__ void __launch_bounds__(256) k_tree_apply(const TreeArgs A) {
     const int tid = threadIdx.x;
     double *Xr = A.Xst + Rr * 4096, *Xl = A.Xst + L * 4096;
     // s[left] <- s[right] (incoming state) ;  s[right] <- map[left](s[right])
-    const int n = FULL ? 64 : A.n;
     _Pragma("unroll 16")
     for (int e = tid; e < 4096; e += 256) {
         const int j = e >> 6, i = e & 63;
-        const double v = (i < n && j < n) ? Xr[e] : 0.0;       // (states are zero beyond their leading block)
+        const double v = Xr[e];
         Xl[e] = v;
         Xs[i * LD + j] = v;
     }
@@ -2707,7 +2698,7 @@ __global__ void __launch_bounds__(256) k_tree_apply(const TreeArgs A) {
     __syncthreads();
     const double noreg[16] = {};
     cb_apply(Xs, Au, Bs, Ys, vs, A.Phi + L * 4096, A.G + L * 4096, A.m + L * 64,
-             A.S + L * 4096, A.F + L * 64, noreg, 0.0, tid, n);
+             A.S + L * 4096, A.F + L * 64, noreg, 0.0, tid, FULL ? 64 : A.n);
     _Pragma("unroll 16")
     for (int e = tid; e < 4096; e += 256) { const int j = e >> 6, i = e & 63; Xr[e] = Xs[i * LD + j]; }
     if (tid < 64) A.Yst[Rr * 64 + tid] = Ys[tid];
