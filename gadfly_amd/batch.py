@@ -86,13 +86,14 @@ class _Pack(tuple):
 
 
 def _sho_only(kernel, dt_min=None, t_abs_max=0.0):
-    """True when K + diag(>= 0) is positive semi-definite BY CONSTRUCTION: a sum of SHO terms with S0, w0, Q > 0
-    is a covariance function whatever the hyperparameters; its exposure-integrated form (``TermConvolution``,
-    every kernel gadfly builds) is one only where the celerite coefficients represent it exactly, i.e. for lags
-    >= delta -- closer time stamps get the un-integrated form's continuation, which need not be a covariance
-    (``TermConvolution(SHOTerm(S0=1, w0=2, Q=0.7), 1)`` on ``arange(200) * 0.2`` has 33 negative eigenvalues).
-    ``dt_min``: the smallest spacing of the time axis the kernel is evaluated on (None: unknown -> False for an
-    integrated kernel); spacings within the rounding of the time stamps of delta count as delta."""
+    """True when K + diag(>= 0) is positive semi-definite by construction, or so close to it that only rounding
+    or cadence jitter stands in the way: a sum of SHO terms with S0, w0, Q > 0 is a covariance function whatever the
+    hyperparameters; its exposure-integrated form (``TermConvolution``, every kernel gadfly builds) is one only
+    where the celerite coefficients represent it exactly, i.e. for lags >= delta -- closer time stamps get the
+    un-integrated form's continuation, which need not be a covariance (``TermConvolution(SHOTerm(S0=1, w0=2,
+    Q=0.7), 1)`` on ``arange(200) * 0.2`` has 33 negative eigenvalues).  ``dt_min``: the smallest spacing of the
+    time axis the kernel is evaluated on (None: unknown -> False for an integrated kernel); see EXPOSURE_SLACK for
+    stamps marginally closer than delta."""
     from .terms import SHOTerm, TermConvolution
     base = kernel
     if isinstance(kernel, TermConvolution):
@@ -105,15 +106,24 @@ def _sho_only(kernel, dt_min=None, t_abs_max=0.0):
     return len(terms) > 0 and all(type(t) is SHOTerm and t.S0 > 0.0 and t.w0 > 0.0 and t.Q > 0.0 for t in terms)
 
 
+#: how far below the exposure time the closest pair of stamps may sit for the two-sweep route to be taken: real
+#: cadences jitter (barycentric corrections, +-0.2 s in cfg3's jittered variant), and for lags this close to delta the
+#: celerite form departs from the integrated kernel only to second order in the shortfall.  Such a matrix is no longer
+#: a covariance BY CONSTRUCTION -- what guarantees the result there is the corrections' check of every pivot's sign
+#: (gadfly_dense.hip: k_corr_small / k_pchol + k_spd_check), which sends anything indefinite to the final pass.
+#: Grossly unresolved exposures (the advisor's example: stamps 0.2 apart, delta = 1) are indefinite for sure: not taken.
+EXPOSURE_SLACK = 0.1
+
+
 def _exposure_resolved(delta, dt_min, t_abs_max=0.0):
-    """No two time stamps closer than the exposure time ``delta`` (up to the rounding of the stamps themselves:
-    a one-minute cadence on a JD-based axis jitters by 5e-7 of the spacing)."""
+    """No two time stamps closer than (1 - EXPOSURE_SLACK) of the exposure time ``delta`` (and the rounding of the
+    stamps themselves: a one-minute cadence on a JD-based axis jitters by 5e-7 of the spacing)."""
     if delta <= 0.0:
         return True
     if dt_min is None:
         return False
     tol = max(1e-9 * delta, 4.0 * float(np.spacing(abs(t_abs_max))))
-    return dt_min >= delta - tol
+    return dt_min >= (1.0 - EXPOSURE_SLACK) * delta - tol
 
 
 #: diagonal of a missing-data row (ragged batches): a power of two, so that a + 2^1000 and the pivot are 2^1000 exactly

@@ -187,3 +187,24 @@ def test_single_kernel_corrections_at_every_width(hip, what):
         assert eng._two_sweep_used or eng._tp_chunking(L)[1] == 1
         assert np.max(np.abs(ll2 - ref)) <= RTOL_LL * abs(ref), (what, L, ll2, ref)
         assert np.max(np.abs(ll2 - ll3)) <= 1e-10 * abs(ref), (what, L, ll2, ll3)
+
+
+def test_jittered_stamps_keep_the_two_sweep_route(hip):
+    """Real cadences jitter: cfg3's odd stars carry +-0.2 s on a 58.85 s cadence with a 58.85 s exposure, so some pairs
+    of stamps are 0.7 % closer than the exposure.  The route is still taken (batch.EXPOSURE_SLACK) -- the pivot-sign
+    check, not the construction, guards it there -- and every entry matches the oracle."""
+    import gadfly_amd
+    from gadfly_amd.synth import cfg3_light_curves
+    from oracle import cref
+    B, N = 6, 9000
+    hps, t, y, yerr, texp = cfg3_light_curves(B, N, 20, jitter=True)
+    kernels = [gadfly_amd.StellarOscillatorKernel(hp, texp=texp) for hp in hps]
+    assert float(np.min(np.diff(t, axis=1))) < texp * 1e-6
+    ev = gadfly_amd.BatchedLogLikelihood(kernels, t, y, yerr=yerr)
+    assert ev._init_safe
+    ll = ev.evaluate()
+    assert ev.engine._two_sweep_used and ev.guard_reruns == 0
+    for i, k in enumerate(kernels):
+        co = k.get_device_coefficients()
+        ref, info = cref.loglike(co[:6], t[i], yerr[i] ** 2 + co[6], y[i])
+        assert info == 0 and abs(ll[i] - ref) <= RTOL_LL * abs(ref), (i, ll[i], ref)
