@@ -714,7 +714,8 @@ int tree_scan(const TreePlan &T, const Maps &M0, double *Xs0, double *Ys0, doubl
 // ------------------------------------------------------------------------------------------------
 constexpr int SPD_THREADS = 512;
 constexpr double SPD_TOL = 1e-12;       // ~ 30 n eps at n = 176: pivots this far inside rounding count as zero
-constexpr double PCHOL_TOL = 1e-13;     // relative size of a remaining diagonal entry of X that still gets a column
+constexpr double PCHOL_TOL = 1e-11;     // relative size of a remaining diagonal entry of X that still gets a column: below
+                                        // it sits what the combine's rounding left (either sign), not variance
 
 __global__ void __launch_bounds__(SPD_THREADS)
 k_pchol(const int P, const int first, const int count, const int n, const double *__restrict__ X_,
@@ -882,16 +883,15 @@ k_corr_finish(const int P, const int first, const int count, const int WP, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// The corrections of a chunk whose maps live in 64 x 64 slots (celerite width W <= 63), in ONE kernel and entirely
-// through the symmetric form (no LU of I - X G):
-//     X = R R^T  (diagonal pivoting, numerical rank r)        M = I_r - R^T G R = L L^T  (attempt: fails <=> some
-//     log det(I - X G) = log det M = 2 sum log L_kk            pivot of the chunk is not positive -> NaN)
-//     v = (I - X G)^-1 e = e + R M^-1 R^T G e                  (Woodbury; e = Y - X m)
-//     e^T G v - 2 m^T e - m^T X m = (G e)^T v - 2 m^T e - m^T (Y - e)
+// The corrections of a chunk whose maps live in 64 x 64 slots (celerite width W <= 63), in ONE kernel:
+//   the sign of every pivot, through the symmetric form:  X = R R^T  (diagonal pivoting, numerical rank r),
+//       M = I_r - R^T G R = L L^T  (attempt: fails <=> some pivot of the chunk is not positive -> NaN);
+//   the values, through A = I - X G = P L U (partial pivoting):  log det(I - X G),  v = A^-1 e  (e = Y - X m),
+//       e^T G v - 2 m^T e - m^T X m = (G e)^T v - 2 m^T e - m^T (Y - e).
 // One workgroup of 256 threads per map, two n x (n + 1) LDS buffers for the active width n = W rounded up to 4
-// (X -> its Cholesky workspace -> G -> T = G R -> M -> L; and R), products as 4 x 4 register tiles.  Replaces, for
-// these widths, seven launches (two job launches, the batched LU, k_pchol, two GEMM launches, k_spd_check) that cost
-// 0.9 ms for the 2048 maps of cfg3 -- a fifth of its shard's evaluation.
+// (X -> its Cholesky workspace -> G -> T = G R -> M -> L, then X -> A -> L U; and R, then G), products as 4 x 4
+// register tiles.  Replaces, for these widths, seven launches (two job launches, the batched LU, k_pchol, two GEMM
+// launches, k_spd_check) that cost 0.9 ms for the 2048 maps of cfg3 -- a fifth of its shard's evaluation.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_corr_small(const int P, const int first, const int count, const int n, const double *__restrict__ X_,
@@ -1035,12 +1035,6 @@ k_corr_small(const int P, const int first, const int count, const int n, const d
             for (int b = 0; b < 4; ++b)
                 A[(4 * ti + a) * LD + 4 * tj + b] = ((4 * ti + a == 4 * tj + b) ? 1.0 : 0.0) - acc[a][b];
     }
-    // w2 = R^T w1
-    if (tid < n) {
-        double a2 = 0.0;
-        if (tid < rank) for (int i = 0; i < n; ++i) a2 = fma(Rm[i * LD + tid], vw1[i], a2);
-        vw2[tid] = a2;
-    }
     __syncthreads();
     // ---- M = L L^T (attempt, lower triangle, `rank` steps; pivots against their own diagonal entry)
     if (tid < 64) d0[tid] = (tid < rank) ? A[tid * LD + tid] : 1.0;
@@ -1076,34 +1070,105 @@ k_corr_small(const int P, const int first, const int count, const int n, const d
         }
         return;
     }
-    // ---- log det, w3 = M^-1 w2 (one wave: forward and backward substitution), v = e + R w3, the quadratic form
-    if (wave == 0) {
-        double lg = (lane < rank) ? log(A[lane * LD + lane]) : 0.0;
-        lg = wave_sum_x(lg);
-        double x = (lane < rank) ? vw2[lane] : 0.0;             // L z = w2
-        for (int k = 0; k < rank; ++k) {
-            const double zk = __shfl(x, k) / A[k * LD + k];
-            if (lane == k) x = zk;
-            else if (lane > k && lane < rank) x = fma(-A[lane * LD + k], zk, x);
-        }
-        for (int k = rank - 1; k >= 0; --k) {                   // L^T w3 = z
-            const double wk = __shfl(x, k) / A[k * LD + k];
-            if (lane == k) x = wk;
-            else if (lane < k) x = fma(-A[k * LD + lane], wk, x);
-        }
-        if (lane < 64) vw2[lane] = (lane < rank) ? x : 0.0;     // w3
-        if (lane == 0) s_red[0] = 2.0 * lg;
+    // ---- the VALUES come from an LU factorisation of A = I - X G with partial pivoting, not from M: the start states
+    // reach this kernel through the combine's products, and what rounding leaves in the numerically null directions
+    // of X (1e-13 of the diagonal, either sign) meets entries of G that are as large as X's are small there.  In
+    // det(I - X G) the signed residue cancels to first order; R keeps its positive part only, and log det M came
+    // out 1e-4 off on ill-scaled problems (22 of 800 random seeds beyond the 1e-8 bar, tools/random_sweep.py).
+    // X, G again (the factorisations above were in place), A = I - X G as 4 x 4 tiles, then Doolittle with row swaps
+    // carried on the right-hand side e; log |det| from the pivots, its sign from their signs and the swaps.
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, j = e - i * n;
+        A[i * LD + j] = X[i * 64 + j];
+        Rm[i * LD + j] = G[i * 64 + j];
     }
     __syncthreads();
-    double q = 0.0;
-    if (tid < n) {
-        double v = ve[tid];
-        for (int k = 0; k < rank; ++k) v = fma(Rm[tid * LD + k], vw2[k], v);
-        q = vw1[tid] * v - 2.0 * vm[tid] * ve[tid] - vm[tid] * (vy[tid] - ve[tid]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    if (tile) {
+        for (int l = 0; l < n; ++l) {
+            double xa[4], gb[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) xa[a] = A[(4 * ti + a) * LD + l];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) gb[b] = Rm[l * LD + 4 * tj + b];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = fma(xa[a], gb[b], acc[a][b]);
+        }
     }
+    __syncthreads();
+    if (tile) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                A[(4 * ti + a) * LD + 4 * tj + b] = ((4 * ti + a == 4 * tj + b) ? 1.0 : 0.0) - acc[a][b];
+    }
+    if (tid < 64) vw2[tid] = (tid < n) ? ve[tid] : 0.0;        // right-hand side: e
+    if (tid == 0) { s_red[0] = 0.0; s_red[1] = 1.0; }           // log |det|, sign
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        if (wave == 0) {                                        // pivot: largest |a_ik|, i >= k
+            double v = (lane >= k && lane < n) ? fabs(A[lane * LD + k]) : -1.0;
+            int ix = lane;
+#pragma unroll
+            for (int mk = 32; mk >= 1; mk >>= 1) {
+                const double ov = __shfl_xor(v, mk);
+                const int oi = __shfl_xor(ix, mk);
+                if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+            }
+            if (lane == 0) s_p = ix;
+        }
+        __syncthreads();
+        const int p = s_p;
+        if (p != k) {                                           // (uniform) swap rows k and p, and the right-hand side
+            if (tid < n) {
+                const double u = A[k * LD + tid];
+                A[k * LD + tid] = A[p * LD + tid];
+                A[p * LD + tid] = u;
+            }
+            if (tid == 64) { const double u = vw2[k]; vw2[k] = vw2[p]; vw2[p] = u; }
+            __syncthreads();
+        }
+        const double piv = A[k * LD + k];
+        if (tid == 0) {
+            s_red[0] += log(fabs(piv));
+            if (p != k) s_red[1] = -s_red[1];
+            if (!(piv > 0.0)) s_red[1] = (piv < 0.0) ? -s_red[1] : __longlong_as_double(0x7ff8000000000000LL);
+        }
+        const double pinv = 1.0 / piv;
+        // multipliers of the rows below, kept in the column; then the trailing update, rows over the waves
+        const int j = k + 1 + lane;
+        const double ukj = (j < n) ? A[k * LD + j] : 0.0;
+        const double bk = vw2[k];
+        __syncthreads();
+        for (int i = k + 1 + wave; i < n; i += 4) {
+            const double lik = A[i * LD + k] * pinv;
+            if (j < n) A[i * LD + j] = fma(-lik, ukj, A[i * LD + j]);
+            if (lane == 0) vw2[i] = fma(-lik, bk, vw2[i]);
+        }
+        __syncthreads();
+    }
+    // ---- U v = b (one wave, column sweeps), then the quadratic form
     if (wave == 0) {
+        double x = (lane < n) ? vw2[lane] : 0.0;
+        for (int k = n - 1; k >= 0; --k) {
+            const double vk = __shfl(x, k) / A[k * LD + k];
+            if (lane == k) x = vk;
+            else if (lane < k) x = fma(-A[lane * LD + k], vk, x);
+        }
+        double q = 0.0;
+        if (lane < n) q = vw1[lane] * x - 2.0 * vm[lane] * ve[lane] - vm[lane] * (vy[lane] - ve[lane]);
         q = wave_sum_x(q);
-        if (lane == 0) { ld_out[mp] = s_red[0]; quad_out[mp] = q; }
+        if (lane == 0) {
+            const bool positive = s_red[1] > 0.0;               // (NaN: a zero pivot)
+            ld_out[mp] = positive ? s_red[0] : __longlong_as_double(0x7ff8000000000000LL);
+            quad_out[mp] = positive ? q : __longlong_as_double(0x7ff8000000000000LL);
+        }
     }
 }
 

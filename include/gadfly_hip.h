@@ -351,7 +351,9 @@ int gf_wide_combine(int B, int64_t N, int64_t chunk_len, int nch, int Jc,
  * Cholesky attempt on M -- and the caller repeats such an evaluation with a final pass, which also names the failing
  * row (celerite2's LinAlgError semantics, reference gp.py:188-192).
  * gf_chunk_corrections: the W <= 63 route (state slots [B*nch][64*64] / [B*nch][64] after gf_chunk_combine[_tree];
- * W = the celerite width); one kernel per map, everything through the symmetric form (log det M, Woodbury for v);
+ * W = the celerite width); one kernel per map: that check, then log det and v from an LU of I - X G with partial
+ * pivoting (the values must not come from M: rounding residue of either sign in X's null directions cancels in
+ * det(I - X G) and does not in a Cholesky factor);
  * work: gf_chunk_corrections_work(B, nch) doubles; B * nch <= 65535.
  */
 int64_t gf_chunk_corrections_work(int B, int nch);
