@@ -12,7 +12,7 @@ Batch shapes:
                    series of different lengths (real Kepler quarters, /root/reference/gadfly/core.py:509-512,
                    psd.py:483-531): every series is then extended to the longest one with MISSING-DATA rows -- its
                    own cadence continued, y = 0 and the diagonal PAD_DIAG = 2^1000.  Such a row has the pivot 2^1000
-                   exactly, the gain 2^-1000 (no trace in the state at double precision) and z^2 / d = 0: the sums
+                   exactly, the gain 2^-1000 (no trace in the state at double precision) and z^2 / d of order 2^-1000: the sums
                    over the real rows are untouched, and what a pad row does add -- log 2^1000 to sum log d, one more
                    row to N log 2 pi -- is a known constant taken off again per problem.  No kernel knows about it.
 """
