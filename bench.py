@@ -581,6 +581,10 @@ def main():
                 "ms_per_eval": api["recompute_plus_log_likelihood_ms"],
                 "what": "GaussianProcess.recompute() + log_likelihood(y) at N=1e6, J=30: one evaluation at a "
                         "time (exact time-parallel factorisation), host arrays in and out",
+                # the same chain through the batched evaluator with B = 1 (log-likelihoods only: two sweeps, no
+                # stored factor): fresh hyperparameters, coefficient algebra, upload, evaluation, readback per step
+                "evaluator_b1": {"value": 1e3 / api["evaluator_b1_ms"], "unit": "evals/s",
+                                 "ms_per_eval": api["evaluator_b1_ms"]},
             }
     # ---- strong scaling of the sharded configurations (every rank takes part: collectives) ----------
     if dist is not None and world > 1 and not args.no_strong and not args.no_configs:

@@ -250,6 +250,21 @@ def measure_cfg2_api(jd=False):
     gb_ll = 8.0 * N * (3 * W + 4) / 1e9
     gb_ai = 8.0 * N * (4 * W + 7) / 1e9
     idx = np.linspace(0, N - 1, 64).astype(int)
+    # ONE chain through the batched evaluator with B = 1 (what a sampler that only needs log-likelihoods would call):
+    # fresh hyperparameters per step, coefficient algebra + upload + the two-sweep time-parallel evaluation + readback
+    from gadfly_amd.synth import jitter_hyperparameters
+    ev1 = gadfly_amd.BatchedLogLikelihood([k], t, y, yerr=30.0)
+    props = [gadfly_amd.StellarOscillatorKernel(jitter_hyperparameters(solar_like_hyperparameters(J), 5000 + i),
+                                                texp=60.0) for i in range(6)]
+    ev1.evaluate([props[0]])
+    e_ts = []
+    for kk in props[1:]:
+        t0 = time.perf_counter()
+        ev1.evaluate([kk])
+        e_ts.append(time.perf_counter() - t0)
+    e_ms = float(np.median(e_ts))
+    del ev1
+    torch.cuda.empty_cache()
     first = None
     if not jd:
         # the FIRST compute() of a process, reported apart from the warm latency (a child process: code-object load,
@@ -268,6 +283,7 @@ def measure_cfg2_api(jd=False):
                         "host arrays out (PCIe included)"
                         + ("; time axis = BKJD 0 + n minutes as jd * day (t ~ 2.12e5, phases to 5e9 rad)" if jd else ""),
             "route": type(gp._factor).__name__,
+            "evaluator_b1_ms": 1e3 * e_ms,
             "compute_ms": 1e3 * c_ms, "log_likelihood_ms": 1e3 * l_ms,
             "recompute_plus_log_likelihood_ms": 1e3 * r_ms,
             "predict_mean_ms": 1e3 * p_ms, "predict_1000_new_times_ms": 1e3 * q_ms,
