@@ -105,7 +105,7 @@ class GadflyHipError(RuntimeError):
 
 
 HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"]
-_DEPS = [HEADER, os.path.join(CSRC, "fastmath.h"), os.path.join(CSRC, "gf_internal.h")]
+_DEPS = [HEADER] + [os.path.join(CSRC, h) for h in ("fastmath.h", "gf_internal.h", "gf_wave.h")]
 
 
 def hipcc_command(out=SO_PATH):

@@ -31,6 +31,7 @@
 
 #include "../../include/gadfly_hip.h"
 #include "gf_internal.h"
+#include "gf_wave.h"
 
 namespace {
 
@@ -885,13 +886,16 @@ k_corr_finish(const int P, const int first, const int count, const int WP, const
 // ------------------------------------------------------------------------------------------------
 // The corrections of a chunk whose maps live in 64 x 64 slots (celerite width W <= 63), in ONE kernel:
 //   the sign of every pivot, through the symmetric form:  X = R R^T  (diagonal pivoting, numerical rank r),
-//       M = I_r - R^T G R = L L^T  (attempt: fails <=> some pivot of the chunk is not positive -> NaN);
-//   the values, through A = I - X G = P L U (partial pivoting):  log det(I - X G),  v = A^-1 e  (e = Y - X m),
-//       e^T G v - 2 m^T e - m^T X m = (G e)^T v - 2 m^T e - m^T (Y - e).
-// One workgroup of 256 threads per map, two n x (n + 1) LDS buffers for the active width n = W rounded up to 4
-// (X -> its Cholesky workspace -> G -> T = G R -> M -> L, then X -> A -> L U; and R, then G), products as 4 x 4
-// register tiles.  Replaces, for these widths, seven launches (two job launches, the batched LU, k_pchol, two GEMM
-// launches, k_spd_check) that cost 0.9 ms for the 2048 maps of cfg3 -- a fifth of its shard's evaluation.
+//       M = I_r - R^T G R  eliminated without pivoting (fails <=> some pivot of the chunk is not positive -> NaN);
+//   the values, through A = I - X G, Gauss-Jordan with partial pivoting:  log det(I - X G),  v = A^-1 e
+//       (e = Y - X m),  e^T G v - 2 m^T e - m^T X m = (G e)^T v - 2 m^T e - m^T (Y - e).
+// One workgroup of 256 threads per map.  The three eliminations run on REGISTERS (the layout of the tree combine's
+// Gauss-Jordan: lanes = rows, wave w owns the columns c = w mod 4, 16 registers per lane + the right-hand side):
+// per pivot ONE barrier -- the wave that owns the pivot column publishes the multipliers, every wave updates its
+// columns with the pivot row's entries fetched by readlane.  Kept in LDS, with rows of n + 1 doubles (n = W rounded
+// up to 4), the steps took 5500-6700 cycles per pivot (three barriers and dependent LDS round trips; 88 % of the
+// kernel, which at N = 1e6, W = 60 cost more than the final sweep it replaces); in registers < 1500.  The products
+// (T = G R, M, A) stay 4 x 4 register tiles over two n x (n + 1) LDS buffers.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_corr_small(const int P, const int first, const int count, const int n, const double *__restrict__ X_,
@@ -904,69 +908,63 @@ k_corr_small(const int P, const int first, const int count, const int n, const d
     const int LD = n + 1;
     extern __shared__ __attribute__((aligned(16))) double spd_lds[];
     double *A = spd_lds, *Rm = A + n * LD;
-    double *ve = Rm + n * LD, *vw1 = ve + 64, *vw2 = vw1 + 64, *vy = vw2 + 64, *vm = vy + 64, *d0 = vm + 64,
-           *col = d0 + 64;
-    __shared__ int s_done[64];
-    __shared__ int s_p, s_fail, s_rank;
-    __shared__ double s_best, s_red[8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // ---- X -> A (lower triangle is what is used), Y, m; R := 0
+    double *ve = Rm + n * LD, *vw1 = ve + 64, *vy = vw1 + 64, *vm = vy + 64, *fbuf = vm + 64 /* [2][64] */,
+           *pinvbuf = fbuf + 128 /* [2] */;
+    int *pvbuf = reinterpret_cast<int *>(pinvbuf + 2);          // [2]: pivot lane (elimination of A), ok flag (of M)
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    // ---- X -> A, Y, m; R := 0
     for (int e = tid; e < n * n; e += 256) {
         const int i = e / n, j = e - i * n;
         A[i * LD + j] = X[i * 64 + j];
         Rm[i * LD + j] = 0.0;
     }
     if (tid < 64) { vy[tid] = (tid < n) ? Y[tid] : 0.0; vm[tid] = (tid < n) ? mv[tid] : 0.0; }
-    if (tid == 0) { s_fail = 0; s_rank = 0; }
     __syncthreads();
-    // ---- e = Y - X m (X symmetric, full rows are there); original diagonal of X
-    if (tid < n) {
+    // ---- e = Y - X m (X symmetric, full rows are there)
+    if (tid < 64) {
         double acc = vy[tid];
-        for (int j = 0; j < n; ++j) acc = fma(-A[tid * LD + j], vm[j], acc);
+        if (tid < n)
+            for (int j = 0; j < n; ++j) acc = fma(-A[tid * LD + j], vm[j], acc);
         ve[tid] = acc;
-        const double v = A[tid * LD + tid];
-        const bool live = v > 0.0;
-        d0[tid] = live ? 1.0 / v : 0.0;
-        s_done[tid] = live ? 0 : 1;
-    } else if (tid < 64) {
-        ve[tid] = 0.0; d0[tid] = 0.0; s_done[tid] = 1;
     }
-    __syncthreads();
-    // ---- X = R R^T with diagonal pivoting
+    // ---- X = R R^T with diagonal pivoting, on registers: Rg[lc] = element (lane, 4 lc + w); every wave follows the
+    // diagonal by itself (dg: the same numbers in all four, so all four choose the same pivot without talking)
+    double Rg[17];
+#pragma unroll
+    for (int lc = 0; lc < 16; ++lc) {
+        const int cc = 4 * lc + w;
+        Rg[lc] = (lane < n && cc < n) ? A[lane * LD + cc] : 0.0;
+    }
+    Rg[16] = 0.0;
+    double dg = (lane < n) ? A[lane * LD + lane] : 0.0;
+    const double d0 = (dg > 0.0) ? 1.0 / dg : 0.0;
+    bool used = !(dg > 0.0);
     int rank = 0;
     for (int k = 0; k < n; ++k) {
-        if (wave == 0) {
-            double v = -1.0;
-            int ix = lane;
-            if (lane < n && !s_done[lane]) v = A[lane * LD + lane] * d0[lane];
+        const double cand = used ? -1.0 : dg * d0;
+        const double vmx = wave_max(cand);
+        if (!(vmx > PCHOL_TOL)) break;              // (uniform over the workgroup) numerical rank reached
+        const unsigned long long hit = __ballot(cand == vmx);
+        const int p = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)hit) - 1);
+        const int buf = k & 1;
+        if (w == (p & 3)) {                         // this wave owns column p
+            const int lp = p >> 2;
+            double cval = 0.0;
 #pragma unroll
-            for (int mk = 32; mk >= 1; mk >>= 1) {
-                const double ov = __shfl_xor(v, mk);
-                const int oi = __shfl_xor(ix, mk);
-                if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
-            }
-            if (lane == 0) { s_best = v; s_p = ix; }
+            for (int lc = 0; lc < 16; ++lc) cval = (lc == lp) ? Rg[lc] : cval;
+            const double r = 1.0 / sqrt(read_lane(cval, p));
+            const double cl = used ? 0.0 : cval * r;
+            fbuf[buf * 64 + lane] = cl;
+            if (lane < n) Rm[lane * LD + k] = cl;
         }
         __syncthreads();
-        const double best = s_best;
-        const int p = s_p;
-        if (!(best > PCHOL_TOL)) break;             // (uniform) numerical rank reached
-        const double r = 1.0 / sqrt(A[p * LD + p]);
-        if (tid < n) {
-            double v = 0.0;
-            if (!s_done[tid]) v = (tid >= p ? A[tid * LD + p] : A[p * LD + tid]) * r;
-            col[tid] = v;
-            Rm[tid * LD + k] = v;
-        }
-        __syncthreads();
-        if (tid == 0) s_done[p] = 1;
-        for (int i = wave; i < n; i += 4) {
-            if (s_done[i] || i == p) continue;
-            const double ci = col[i];
-            if (lane <= i) A[i * LD + lane] = fma(-ci, col[lane], A[i * LD + lane]);
-        }
+        const double cl = fbuf[buf * 64 + lane];
+#pragma unroll
+        for (int lc = 0; lc < 16; ++lc) Rg[lc] = fma(-cl, read_lane(cl, 4 * lc + w), Rg[lc]);
+        dg = fma(-cl, cl, dg);
+        if (lane == p) used = true;
         rank = k + 1;
-        __syncthreads();
     }
     __syncthreads();
     // ---- G -> A (whole rows), w1 = G e
@@ -1036,47 +1034,43 @@ k_corr_small(const int P, const int first, const int count, const int n, const d
                 A[(4 * ti + a) * LD + 4 * tj + b] = ((4 * ti + a == 4 * tj + b) ? 1.0 : 0.0) - acc[a][b];
     }
     __syncthreads();
-    // ---- M = L L^T (attempt, lower triangle, `rank` steps; pivots against their own diagonal entry)
-    if (tid < 64) d0[tid] = (tid < rank) ? A[tid * LD + tid] : 1.0;
-    __syncthreads();
-    if (tid < rank && !(d0[tid] > 0.0)) s_fail = 1;
-    __syncthreads();
-    for (int k = 0; k < rank && !s_fail; ++k) {
-        const double piv = A[k * LD + k];
-        if (!(piv > SPD_TOL * d0[k])) {
-            __syncthreads();
-            if (tid == 0) s_fail = 1;
-            __syncthreads();
-            break;
-        }
-        const double r = 1.0 / sqrt(piv);
-        __syncthreads();
-        if (tid == 0) A[k * LD + k] = sqrt(piv);
-        if (tid > k && tid < rank) A[tid * LD + k] *= r;
-        __syncthreads();
-        const int j = k + 1 + lane;
-        const double lk = (j < rank) ? A[j * LD + k] : 0.0;
-        for (int i = k + 1 + wave; i < rank; i += 4) {
-            const double lik = A[i * LD + k];
-            if (j <= i) A[i * LD + j] = fma(-lik, lk, A[i * LD + j]);
-        }
-        __syncthreads();
+    // ---- M eliminated without pivoting (the leading `rank` rows / columns): its pivots are those of M = L L^T
+    // squared; each against its own diagonal entry.  Rows below the pivot only.
+#pragma unroll
+    for (int lc = 0; lc < 16; ++lc) {
+        const int cc = 4 * lc + w;
+        Rg[lc] = (lane < rank && cc < rank) ? A[lane * LD + cc] : 0.0;
     }
-    __syncthreads();
-    if (s_fail) {                                   // (uniform) some pivot of the chunk is not positive
-        if (tid == 0) {
-            ld_out[mp] = __longlong_as_double(0x7ff8000000000000LL);
-            quad_out[mp] = __longlong_as_double(0x7ff8000000000000LL);
+    const double dm = (lane < rank) ? A[lane * LD + lane] : 1.0;
+    bool fail = false;
+    static_for([&](auto kc) {
+        constexpr int k = decltype(kc)::value, wo = k & 3, lk = k >> 2, buf = k & 1;
+        if (k >= rank || fail) return;              // (uniform over the workgroup)
+        if (w == wo) {
+            const double cval = Rg[lk];
+            const double piv = read_lane(cval, k);
+            const bool ok = piv > SPD_TOL * read_lane(dm, k);
+            fbuf[buf * 64 + lane] = (ok && lane > k) ? cval * fast_rcp(piv) : 0.0;
+            if (lane == 0) pvbuf[buf] = ok ? 1 : 0;
         }
+        __syncthreads();
+        if (!__builtin_amdgcn_readfirstlane(pvbuf[buf])) { fail = true; return; }
+        const double f = fbuf[buf * 64 + lane];
+#pragma unroll
+        for (int lc = lk; lc < 16; ++lc) Rg[lc] = fma(-f, read_lane(Rg[lc], k), Rg[lc]);
+    }, std::make_integer_sequence<int, 64>{});
+    if (fail) {                                     // (uniform) some pivot of the chunk is not positive
+        if (tid == 0) { ld_out[mp] = nan; quad_out[mp] = nan; }
         return;
     }
-    // ---- the VALUES come from an LU factorisation of A = I - X G with partial pivoting, not from M: the start states
+    __syncthreads();
+    // ---- the VALUES come from an elimination of A = I - X G with partial pivoting, not from M: the start states
     // reach this kernel through the combine's products, and what rounding leaves in the numerically null directions
     // of X (1e-13 of the diagonal, either sign) meets entries of G that are as large as X's are small there.  In
     // det(I - X G) the signed residue cancels to first order; R keeps its positive part only, and log det M came
     // out 1e-4 off on ill-scaled problems (22 of 800 random seeds beyond the 1e-8 bar, tools/random_sweep.py).
-    // X, G again (the factorisations above were in place), A = I - X G as 4 x 4 tiles, then Doolittle with row swaps
-    // carried on the right-hand side e; log |det| from the pivots, its sign from their signs and the swaps.
+    // X, G again (the buffers were reused), A = I - X G as 4 x 4 tiles; Gauss-Jordan with implicit row pivoting on
+    // [A | e]; log |det| from the pivots, its sign from their signs and the parity of the row -> variable map.
     for (int e = tid; e < n * n; e += 256) {
         const int i = e / n, j = e - i * n;
         A[i * LD + j] = X[i * 64 + j];
@@ -1108,66 +1102,61 @@ k_corr_small(const int P, const int first, const int count, const int n, const d
             for (int b = 0; b < 4; ++b)
                 A[(4 * ti + a) * LD + 4 * tj + b] = ((4 * ti + a == 4 * tj + b) ? 1.0 : 0.0) - acc[a][b];
     }
-    if (tid < 64) vw2[tid] = (tid < n) ? ve[tid] : 0.0;        // right-hand side: e
-    if (tid == 0) { s_red[0] = 0.0; s_red[1] = 1.0; }           // log |det|, sign
     __syncthreads();
-    for (int k = 0; k < n; ++k) {
-        if (wave == 0) {                                        // pivot: largest |a_ik|, i >= k
-            double v = (lane >= k && lane < n) ? fabs(A[lane * LD + k]) : -1.0;
-            int ix = lane;
 #pragma unroll
-            for (int mk = 32; mk >= 1; mk >>= 1) {
-                const double ov = __shfl_xor(v, mk);
-                const int oi = __shfl_xor(ix, mk);
-                if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
-            }
-            if (lane == 0) s_p = ix;
-        }
-        __syncthreads();
-        const int p = s_p;
-        if (p != k) {                                           // (uniform) swap rows k and p, and the right-hand side
-            if (tid < n) {
-                const double u = A[k * LD + tid];
-                A[k * LD + tid] = A[p * LD + tid];
-                A[p * LD + tid] = u;
-            }
-            if (tid == 64) { const double u = vw2[k]; vw2[k] = vw2[p]; vw2[p] = u; }
-            __syncthreads();
-        }
-        const double piv = A[k * LD + k];
-        if (tid == 0) {
-            s_red[0] += log(fabs(piv));
-            if (p != k) s_red[1] = -s_red[1];
-            if (!(piv > 0.0)) s_red[1] = (piv < 0.0) ? -s_red[1] : __longlong_as_double(0x7ff8000000000000LL);
-        }
-        const double pinv = 1.0 / piv;
-        // multipliers of the rows below, kept in the column; then the trailing update, rows over the waves
-        const int j = k + 1 + lane;
-        const double ukj = (j < n) ? A[k * LD + j] : 0.0;
-        const double bk = vw2[k];
-        __syncthreads();
-        for (int i = k + 1 + wave; i < n; i += 4) {
-            const double lik = A[i * LD + k] * pinv;
-            if (j < n) A[i * LD + j] = fma(-lik, ukj, A[i * LD + j]);
-            if (lane == 0) vw2[i] = fma(-lik, bk, vw2[i]);
-        }
-        __syncthreads();
+    for (int lc = 0; lc < 16; ++lc) {
+        const int cc = 4 * lc + w;
+        Rg[lc] = (lane < n && cc < n) ? A[lane * LD + cc] : 0.0;
     }
-    // ---- U v = b (one wave, column sweeps), then the quadratic form
-    if (wave == 0) {
-        double x = (lane < n) ? vw2[lane] : 0.0;
-        for (int k = n - 1; k >= 0; --k) {
-            const double vk = __shfl(x, k) / A[k * LD + k];
-            if (lane == k) x = vk;
-            else if (lane < k) x = fma(-A[lane * LD + k], vk, x);
+    Rg[16] = (w == 0) ? ve[lane] : 0.0;             // column 64: the right-hand side (ve is zero beyond n)
+    bool pivoted = false, bad = false;              // row `lane` has served as a pivot; a column without one
+    int myk = lane;                                 // ... of which variable
+    double mypinv = 1.0;                            // ... with which 1 / pivot
+    static_for([&](auto kc) {
+        constexpr int k = decltype(kc)::value, wo = k & 3, lk = k >> 2, buf = k & 1;
+        if (k >= n || bad) return;            // (uniform over the workgroup)
+        if (w == wo) {
+            const double cval = Rg[lk];
+            const double cand = (pivoted || lane >= n) ? -1.0 : fabs(cval);
+            const double vmx = wave_max(cand);
+            const unsigned long long hit = __ballot(cand == vmx);
+            const bool none = hit == 0ull || !(vmx > 0.0);      // (NaNs, or a column of zeros)
+            const int pv = none ? 64 : __builtin_amdgcn_readfirstlane((int)__ffsll((long long)hit) - 1);
+            const double pinv = none ? 0.0 : fast_rcp(read_lane(cval, pv & 63));
+            fbuf[buf * 64 + lane] = (lane == pv) ? 0.0 : cval * pinv;
+            if (lane == 0) { pvbuf[buf] = pv; pinvbuf[buf] = pinv; }
         }
-        double q = 0.0;
-        if (lane < n) q = vw1[lane] * x - 2.0 * vm[lane] * ve[lane] - vm[lane] * (vy[lane] - ve[lane]);
+        __syncthreads();
+        const double f = fbuf[buf * 64 + lane];
+        const int pv = __builtin_amdgcn_readfirstlane(pvbuf[buf]);
+        if (pv == 64) { bad = true; return; }
+        if (lane == pv) { pivoted = true; myk = k; mypinv = pinvbuf[buf]; }
+#pragma unroll
+        for (int lc = lk; lc < 17; ++lc) Rg[lc] = fma(-f, read_lane(Rg[lc], pv), Rg[lc]);
+    }, std::make_integer_sequence<int, 64>{});
+    // ---- row `lane` solved variable myk: v(myk) = (its right-hand side) / pivot; then the quadratic form and the
+    // determinant (wave 0 holds column 64)
+    if (w == 0) {
+        const double v = Rg[16] * mypinv;
+        double q = 0.0, lg = 0.0;
+        if (lane < n) {
+            q = vw1[myk] * v - 2.0 * vm[lane] * ve[lane] - vm[lane] * (vy[lane] - ve[lane]);
+            lg = -log(fabs(mypinv));
+        }
         q = wave_sum_x(q);
+        lg = wave_sum_x(lg);
+        // sign: negative pivots, and the inversions of lane -> myk (identity beyond n)
+        int inv = 0;
+#pragma unroll
+        for (int j = 0; j < 63; ++j) {
+            const int oj = __builtin_amdgcn_readlane(myk, j);
+            inv += (lane > j && oj > myk) ? 1 : 0;
+        }
+        const int odd = (__popcll(__ballot(mypinv < 0.0)) + __popcll(__ballot(inv & 1))) & 1;
         if (lane == 0) {
-            const bool positive = s_red[1] > 0.0;               // (NaN: a zero pivot)
-            ld_out[mp] = positive ? s_red[0] : __longlong_as_double(0x7ff8000000000000LL);
-            quad_out[mp] = positive ? q : __longlong_as_double(0x7ff8000000000000LL);
+            const bool positive = !bad && !odd && lg == lg;
+            ld_out[mp] = positive ? lg : nan;
+            quad_out[mp] = positive ? q : nan;
         }
     }
 }

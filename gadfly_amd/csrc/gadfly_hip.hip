@@ -34,6 +34,7 @@
 // routines, which carry Payne-Hanek reduction for arbitrary arguments.
 #define FM_INLINE __device__ __forceinline__
 #include "fastmath.h"
+#include "gf_wave.h"
 
 // fm_exp with its coefficients formed where they are used.  Written as literals, hipcc hoists the fourteen FP64
 // coefficients out of any loop that contains a call -- also when the call sits on a reset row, one row in 16 to
@@ -118,20 +119,6 @@ namespace {
 // ------------------------------------------------------------------------------------
 // wave-level primitives (64 lanes, DPP; no LDS traffic)
 // ------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_get(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double read_lane(double v, int l) {
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-
 // A wave-uniform index made opaque to the optimiser (it stays in SGPRs, at no cost): `p[opaque(i)]`
 // with a loop-invariant per-lane pointer p is then addressed as p + i inside the branch that uses
 // it, instead of becoming one more per-lane 64-bit pointer that loop strength reduction advances
@@ -166,25 +153,6 @@ __device__ __forceinline__ void wave_sum2(double &a, double &b) {
     a += dpp_get<0x143, 0xf>(a);  b += dpp_get<0x143, 0xf>(b);
     a = read_lane(a, 63);
     b = read_lane(b, 63);
-}
-
-// max over the 64 lanes (same DPP tree), broadcast
-__device__ __forceinline__ double wave_max(double v) {
-    v = fmax(v, dpp_get<0xB1, 0xf>(v));
-    v = fmax(v, dpp_get<0x4E, 0xf>(v));
-    v = fmax(v, dpp_get<0x141, 0xf>(v));
-    v = fmax(v, dpp_get<0x140, 0xf>(v));
-    double r1 = read_lane(v, 15), r2 = read_lane(v, 31), r3 = read_lane(v, 47), r4 = read_lane(v, 63);
-    return fmax(fmax(r1, r2), fmax(r3, r4));
-}
-
-// 1/x for normal positive x: hardware estimate + two Newton steps (error <= ~1 ulp); the
-// IEEE division sequence costs ~14 VALU instructions on a path every row waits for.
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
@@ -2192,10 +2160,6 @@ k_phiw(const int64_t N, const int64_t chunk_len, const int nch, const int ch0, c
 }
 
 // (the archived sweep variants k_factor4/5/6 of rounds 1-3 live outside the package: tools/archive/sweeps_456.inc)
-template <class F, int... K>
-__device__ __forceinline__ void static_for(F &&f, std::integer_sequence<int, K...>) {
-    (f(std::integral_constant<int, K>{}), ...);
-}
 
 // ------------------------------------------------------------------------------------
 // Exact time-parallel evaluation of ONE series (Lainiotis-type partitioning; the numpy

@@ -1151,16 +1151,23 @@ class StreamingBatch:
         return out
 
     # -- exact time-parallel evaluation (few problems, long series) ------------------------
-    def _tp_chunking(self, chunk_len):
+    #: two-sweep evaluations of at most this many rows in all (B N) run on ~1024 chunks instead of ~2048
+    two_sweep_small_rows = 1_500_000
+
+    def _tp_chunking(self, chunk_len, store=False):
         N, B = self.N, self.B
         block = self._pack[5]
         if chunk_len is None:
-            # B * nch ~ 2048 waves = 2 per SIMD, the occupancy the sweep kernels are built for
-            # (measured optimum for B = 1 ... 128 at N = 2.6e5 ... 1e6, W = 60: DESIGN.md 4.3);
-            # below ~512 rows per chunk the extra tree levels cost more than the sweeps save
-            # (+ 1: the last chunk sits out the nominal pass, the first one the final pass; the two-sweep
-            # log-likelihood sweeps all chunks in its nominal pass)
-            nch = max(1, 2048 // B) + (0 if self.two_sweep else 1)
+            # B * nch ~ 2048 waves = 2 per SIMD, the occupancy the sweep kernels are built for; below ~512 rows per
+            # chunk the extra tree levels cost more than the sweeps save.  (+ 1: the last chunk sits out the nominal
+            # pass, the first one the final pass; the two-sweep log-likelihood sweeps all chunks in its nominal pass.)
+            # The two-sweep route pays per chunk (tree levels, corrections) what the three-sweep route pays per row
+            # (the final pass): up to 1.5e6 rows in all it is faster on half the chunks, one wave per SIMD --
+            # B = 1, N = 1e6, W = 60: 4.05 ms on 977 chunks, 4.40 on 1954; 16 x 65 000: 3.39 against 3.81; beyond
+            # 2e6 rows the sweeps dominate and 2048 wins again (grid over B, N, W = 20 / 40 / 60: DESIGN.md 6)
+            two = self.two_sweep and not store
+            waves = 1024 if (two and B * N <= self.two_sweep_small_rows) else 2048
+            nch = max(1, waves // B) + (0 if two else 1)
             chunk_len = max(512, -(-N // nch))
         chunk_len = max(block, (int(chunk_len) + 63) // 64 * 64)
         return chunk_len, -(-N // chunk_len)
@@ -1175,7 +1182,7 @@ class StreamingBatch:
         lib, p = self.lib, _lib.ptr
         N, B = self.N, self.B
         real, comp, diag_add, _, cmax, block, _ = self._pack
-        chunk_len, nch = self._tp_chunking(chunk_len)
+        chunk_len, nch = self._tp_chunking(chunk_len, store)
         opts = (int(self.generator_period), int(self.sweep_variant))
         f64 = dict(dtype=torch.float64, device=self.device)
         key = (chunk_len, nch)
