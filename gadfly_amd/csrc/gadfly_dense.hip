@@ -1109,30 +1109,29 @@ k_corr_small(const int P, const int first, const int count, const int n, const d
         Rg[lc] = (lane < n && cc < n) ? A[lane * LD + cc] : 0.0;
     }
     Rg[16] = (w == 0) ? ve[lane] : 0.0;             // column 64: the right-hand side (ve is zero beyond n)
-    bool pivoted = false, bad = false;              // row `lane` has served as a pivot; a column without one
+    bool pivoted = lane >= n;                       // row `lane` has served as a pivot (or is not one of the system's)
     int myk = lane;                                 // ... of which variable
     double mypinv = 1.0;                            // ... with which 1 / pivot
+    // (the search one step ahead of the elimination, as in the tree combine's cb_gauss_jordan)
+    if (w == 0) gj_search(Rg[0], pivoted, lane, fbuf, pvbuf, pinvbuf);
     static_for([&](auto kc) {
-        constexpr int k = decltype(kc)::value, wo = k & 3, lk = k >> 2, buf = k & 1;
-        if (k >= n || bad) return;            // (uniform over the workgroup)
-        if (w == wo) {
-            const double cval = Rg[lk];
-            const double cand = (pivoted || lane >= n) ? -1.0 : fabs(cval);
-            const double vmx = wave_max(cand);
-            const unsigned long long hit = __ballot(cand == vmx);
-            const bool none = hit == 0ull || !(vmx > 0.0);      // (NaNs, or a column of zeros)
-            const int pv = none ? 64 : __builtin_amdgcn_readfirstlane((int)__ffsll((long long)hit) - 1);
-            const double pinv = none ? 0.0 : fast_rcp(read_lane(cval, pv & 63));
-            fbuf[buf * 64 + lane] = (lane == pv) ? 0.0 : cval * pinv;
-            if (lane == 0) { pvbuf[buf] = pv; pinvbuf[buf] = pinv; }
-        }
+        constexpr int k = decltype(kc)::value, lk = k >> 2, buf = k & 1;
+        constexpr int k1 = k + 1, w1 = k1 & 3, lk1 = k1 >> 2, buf1 = k1 & 1;
+        if (k >= n) return;
         __syncthreads();
         const double f = fbuf[buf * 64 + lane];
         const int pv = __builtin_amdgcn_readfirstlane(pvbuf[buf]);
-        if (pv == 64) { bad = true; return; }
         if (lane == pv) { pivoted = true; myk = k; mypinv = pinvbuf[buf]; }
+        if (k1 < 64 && k1 < n && w == w1) {                     // (wave-uniform) the next column's owner
+            Rg[lk1] = fma(-f, read_lane(Rg[lk1], pv), Rg[lk1]);
+            gj_search(Rg[lk1], pivoted, lane, fbuf + buf1 * 64, pvbuf + buf1, pinvbuf + buf1);
 #pragma unroll
-        for (int lc = lk; lc < 17; ++lc) Rg[lc] = fma(-f, read_lane(Rg[lc], pv), Rg[lc]);
+            for (int lc = lk; lc < 17; ++lc)
+                if (lc != lk1) Rg[lc] = fma(-f, read_lane(Rg[lc], pv), Rg[lc]);
+        } else {
+#pragma unroll
+            for (int lc = lk; lc < 17; ++lc) Rg[lc] = fma(-f, read_lane(Rg[lc], pv), Rg[lc]);
+        }
     }, std::make_integer_sequence<int, 64>{});
     // ---- row `lane` solved variable myk: v(myk) = (its right-hand side) / pivot; then the quadratic form and the
     // determinant (wave 0 holds column 64)
@@ -1154,7 +1153,7 @@ k_corr_small(const int P, const int first, const int count, const int n, const d
         }
         const int odd = (__popcll(__ballot(mypinv < 0.0)) + __popcll(__ballot(inv & 1))) & 1;
         if (lane == 0) {
-            const bool positive = !bad && !odd && lg == lg;
+            const bool positive = !odd && fabs(lg) < 1.0e300;       // (a column without a pivot: inf / NaN)
             ld_out[mp] = positive ? lg : nan;
             quad_out[mp] = positive ? q : nan;
         }

@@ -2311,13 +2311,21 @@ __device__ __forceinline__ void cb_store_lds(double *dst, int ld, const double (
 
 // Gauss-Jordan with IMPLICIT partial pivoting on the 64 x 129 augmented system Au = [A | RHS],
 // held in registers with lanes = rows: wave w (of 4) owns the columns c = w (mod 4), 33 registers
-// per lane.  Step k: the wave that owns column k searches the pivot among the unused rows (DPP
-// arg-max), forms the row multipliers f_i = a_ik / a_pk (lane form, f_p = 0) and publishes them
-// with the pivot's lane index through LDS; after ONE barrier every wave eliminates its columns,
-// fetching the pivot row's entries with readlane (an SGPR operand of the FMA: no LDS traffic in
-// the update).  Rows are never swapped or normalised, eliminated columns are not revisited
-// (updating them is harmless and keeps the loops compile-time).  The multiplier buffer alternates
-// between two halves so that the next owner may write while slower waves still read.
+// per lane.  Step k: the wave that owns column k searches the pivot among the unused rows, forms the
+// row multipliers f_i = a_ik / a_pk (lane form, f_p = 0) and publishes them with the pivot's lane
+// index through LDS; after ONE barrier every wave eliminates its columns, fetching the pivot row's
+// entries with readlane (an SGPR operand of the FMA: no LDS traffic in the update).  Rows are never
+// swapped or normalised, eliminated columns are not revisited (updating them is harmless and keeps
+// the loops compile-time).  The multiplier buffer alternates between two halves so that the next
+// owner may write while slower waves still read.
+// The search runs one step AHEAD: behind the barrier of step k the owner of column k + 1 updates that
+// column first, searches and publishes step k + 1, and only then eliminates the rest of its columns --
+// while the other three waves are still eliminating for step k.  And its dependent chain is short: the
+// magnitudes compare as 32-bit keys (the high word of |a|: exponent + 20 mantissa bits -- a pivot within
+// 1e-6 of the largest is as good), a DPP max per step inside the rows of 16 lanes and scalar maxima
+// across them; every lane has the reciprocal of its own entry ready before the pivot is known.  (A step
+// took 1290 cycles with the search of a 64-bit maximum, its reciprocal and the whole update in sequence;
+// tools/_dbg_tree.py.)
 // scratch >= 140 doubles.  On exit Au[:, 64:129] = A^-1 RHS.
 // n (uniform, <= 64): the system is the identity beyond its leading n x n block with zero right-hand sides there
 // (zero-padded states): the steps k >= n are skipped and those rows of the solution are zeros.
@@ -2336,26 +2344,22 @@ __device__ __forceinline__ void cb_gauss_jordan(double *Au, double *scratch, int
     bool used = false;                      // row `lane` already served as a pivot
     int myk = 0;                            // ... of which variable
     double mypinv = 0.0;                    // ... with which 1 / pivot
-    __syncthreads();
+    if (w == 0 && n > 0) gj_search(R[0], used, lane, fbuf, pvbuf, pinvbuf);
     static_for([&](auto kc) {
-        constexpr int k = decltype(kc)::value, wo = k & 3, lk = k >> 2, buf = k & 1;
+        constexpr int k = decltype(kc)::value, lk = k >> 2, buf = k & 1;
+        constexpr int k1 = k + 1, w1 = k1 & 3, lk1 = k1 >> 2, buf1 = k1 & 1;
         if (k >= n) return;
-        if (w == wo) {                      // wave-uniform: this wave owns column k
-            const double cval = R[lk];
-            const double cand = used ? -1.0 : fabs(cval);
-            const double vm = wave_max(cand);
-            const unsigned long long hit = __ballot(cand == vm);
-            const int pv = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)hit) - 1);
-            const double pinv = fast_rcp(read_lane(cval, pv));
-            fbuf[buf * 64 + lane] = (lane == pv) ? 0.0 : cval * pinv;
-            if (lane == 0) { pvbuf[buf] = pv; pinvbuf[buf] = pinv; }
-        }
         __syncthreads();
         const double f = fbuf[buf * 64 + lane];
         const int pv = __builtin_amdgcn_readfirstlane(pvbuf[buf]);
         if (lane == pv) { used = true; myk = k; mypinv = pinvbuf[buf]; }
-#pragma unroll
-        for (int lc = lk; lc < NC; ++lc) R[lc] = fma(-f, read_lane(R[lc], pv), R[lc]);
+        if (k1 < 64 && k1 < n && w == w1) {                     // (wave-uniform) the next column's owner
+            R[lk1] = fma(-f, read_lane(R[lk1], pv), R[lk1]);
+            gj_search(R[lk1], used, lane, fbuf + buf1 * 64, pvbuf + buf1, pinvbuf + buf1);
+            gj_update<lk, NC, lk1>(R, f, pv);
+        } else {
+            gj_update<lk, NC, -1>(R, f, pv);
+        }
     }, std::make_integer_sequence<int, 64>{});
     // row `lane` solved variable myk:  x(myk, :) = (right part of the row) / pivot
 #pragma unroll
