@@ -368,6 +368,23 @@ class BatchedLogLikelihood:
 
     def evaluate(self, kernels=None):
         out = self.evaluate_device(None if kernels is None else self.pack(kernels))
+        if (self.auto_generator_period and self._last_cond is not None and len(self._unresolved) <= 1
+                and (not self._unresolved or self._unresolved[0][0] is out)):
+            # the common case -- nothing else pending: the values, the guard's flags and the two numbers the
+            # period calibration reads come back in ONE copy (a chain of single evaluations paid four round trips)
+            torch = self.engine.torch
+            dmin, amax = self._last_cond
+            parts = [out, dmin.min().reshape(1), amax.max().reshape(1)]
+            if self._unresolved:
+                parts.append(self._unresolved[0][1].to(out.dtype))
+            host = torch.cat(parts).cpu().numpy()
+            B = out.shape[0]
+            if not self._unresolved or not host[B + 2:].any():
+                self._unresolved = []
+                eng = self.engine
+                cond = host[B + 1] / host[B] if host[B] > 0.0 else float("inf")
+                eng.generator_period = eng.period_for_condition(float(cond), self.generator_target)
+                return host[:B].copy()
         self.resolve()
         res = out.cpu().numpy()
         if self.auto_generator_period:

@@ -1005,7 +1005,19 @@ class StreamingBatch:
         block = 64
         while block > 1 and (block - 1) * x > 28.0:
             block //= 2
-        return dev(real), dev(comp), dev(diag_add), dev(c), dev(cmax), block, dmax
+        # ONE host-to-device copy for the five arrays (a chain of single evaluations pays every copy's latency
+        # before its first kernel starts): views into one buffer, each starting on a 16-byte boundary
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (real, comp, diag_add, c, cmax)]
+        offs, total = [], 0
+        for a in arrs:
+            offs.append(total)
+            total += (a.size + 1) // 2 * 2
+        host = np.zeros(max(total, 2), dtype=np.float64)
+        for a, o in zip(arrs, offs):
+            host[o:o + a.size] = a.reshape(-1)
+        buf = dev(host)
+        real, comp, diag_add, c, cmax = (buf[o:o + a.size].view(a.shape) for a, o in zip(arrs, offs))
+        return real, comp, diag_add, c, cmax, block, dmax
 
     def pack_coefficients(self, coeffs_list):
         if len(coeffs_list) != self.B:
