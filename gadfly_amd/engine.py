@@ -1208,10 +1208,16 @@ class StreamingBatch:
             return x
 
         if getattr(self, "_tp_key", None) != key:
+            # chunk maps and states: one slot per (problem, chunk).  ONE problem on enough chunks for the tree
+            # combine gets the power-of-two slot count the scan works on (slot = chunk there: the scan runs in
+            # place, the padding slots are refilled per evaluation -- no copies into and out of a padded set)
+            ns = B * nch
+            if B == 1 and nch >= self.tree_min_chunks:
+                ns = 1 << (nch - 1).bit_length()
             self._tp = dict(
-                S=torch.empty((B * nch, 4096), **f64), F=torch.empty((B * nch, 64), **f64),
-                Phi=torch.empty((B * nch, 4096), **f64), G=torch.empty((B * nch, 4096), **f64),
-                m=torch.empty((B * nch, 64), **f64),
+                S=torch.empty((ns, 4096), **f64), F=torch.empty((ns, 64), **f64),
+                Phi=torch.empty((ns, 4096), **f64), G=torch.empty((ns, 4096), **f64),
+                m=torch.empty((ns, 64), **f64),
                 # (eight spare rows: the transition sweep fetches r-bar / d-bar rows ahead, unconditionally)
                 d=rows(), z=rows(), r=rows(64), Un=rows(64), den=rows(),
                 info=torch.zeros((B * nch,), dtype=torch.int32, device=self.device),
@@ -1338,7 +1344,7 @@ class StreamingBatch:
 
     def _clear_slots(self, x, nch, *slots):
         """Zero the chunk slots `slots` of every problem in x ([B * nch, n]): one strided fill kernel each."""
-        v = x.view(self.B, nch, -1)
+        v = x[:self.B * nch].view(self.B, nch, -1)      # (B = 1: x may carry the tree's padding slots behind)
         for s in slots:
             v[:, s].zero_()
 
@@ -1353,19 +1359,24 @@ class StreamingBatch:
             _lib.check(rc, "gf_chunk_combine")
             return
         P = 1 << (nch - 1).bit_length()
+        in_place = nch == P or (B == 1 and w["S"].shape[0] == P)
         tr = w.get("tree")
         if tr is None or tr["P"] != P:
             f64 = dict(dtype=torch.float64, device=self.device)
-            big = ("G", "X") if nch == P else ("Phi", "G", "S", "X")
-            small = ("m", "Y") if nch == P else ("m", "F", "Y")
+            big = ("G", "X") if in_place else ("Phi", "G", "S", "X")
+            small = ("m", "Y") if in_place else ("m", "F", "Y")
             tr = w["tree"] = dict(
                 P=P, eye=torch.eye(64, **f64).reshape(4096),
                 **{k: torch.empty((B, P, 4096), **f64) for k in big},
                 **{k: torch.empty((B, P, 64), **f64) for k in small})
-        if nch == P:
-            # no padding: the scan works on the chunk maps where they are (it overwrites them: G and m, which the
+        if in_place:
+            # the scan works on the chunk maps where they are (it overwrites them: G and m, which the
             # two-sweep corrections read afterwards, go through copies) and its output buffers change places
-            # with the state slots instead of being copied back
+            # with the state slots instead of being copied back.  (One problem: its padding slots are identity maps)
+            if nch < P:
+                w["Phi"][nch:] = tr["eye"]
+                for k in ("G", "S", "m", "F"):
+                    w[k][nch:].zero_()
             tr["G"].copy_(w["G"].view(B, P, 4096))
             tr["m"].copy_(w["m"].view(B, P, 64))
             rc = lib.gf_chunk_combine_tree(B, P, self.W, p(w["Phi"]), p(tr["G"]), p(tr["m"]), p(w["S"]),
