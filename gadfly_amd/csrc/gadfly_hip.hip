@@ -2475,6 +2475,18 @@ k_combine(const int nch, const int n_, const double *__restrict__ Phi_, const do
         }
         if (tid < 64) { ybar = Fg[tid]; Fg[tid] = Ys[tid]; }
         if (c == nch - 1) break;
+        if (c == 0) {
+            // from the zero state a chunk's map returns its own nominal end state (K = 0, v = 0): no solve
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int e = tid + 256 * q, j = e >> 6, i = e & 63;
+                Xs[i * LD + j] = xbar[q];
+            }
+            if (tid < 64) Ys[tid] = ybar;
+            __syncthreads();
+            continue;
+        }
         cb_apply(Xs, Au, Bs, Ys, vs, Phi_ + slot * 4096, G_ + slot * 4096, m_ + slot * 64,
                  nullptr, nullptr, xbar, ybar, tid, n);
     }
@@ -2631,12 +2643,16 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
     }
 }
 
-// the down-sweep starts from a zero state in the last slot of every problem (one launch: a memset per problem
-// and array was 2 B launches per scan)
-__global__ void __launch_bounds__(256) k_tree_root(const int P, double *__restrict__ Xst, double *__restrict__ Yst) {
-    const size_t slot = (size_t)blockIdx.x * P + P - 1;
-    for (int e = threadIdx.x; e < 4096; e += 256) Xst[slot * 4096 + e] = 0.0;
-    if (threadIdx.x < 64) Yst[slot * 64 + threadIdx.x] = 0.0;
+// The top of the down-sweep: the whole range starts from the zero state, and a map applied to the zero state
+// returns its own nominal end state (K = 0, v = 0) -- so  s[left half's last slot] <- 0,
+// s[last slot] <- (Xbar, Ybar) of the left half's composite: a copy instead of the root's memset and one
+// level of k_tree_apply (a level costs one workgroup's latency whatever it holds: 55 us).
+__global__ void __launch_bounds__(256) k_tree_top(const int P, const double *__restrict__ S,
+                                                  const double *__restrict__ F, double *__restrict__ Xst,
+                                                  double *__restrict__ Yst) {
+    const size_t l = (size_t)blockIdx.x * P + P / 2 - 1, r = (size_t)blockIdx.x * P + P - 1;
+    for (int e = threadIdx.x; e < 4096; e += 256) { Xst[l * 4096 + e] = 0.0; Xst[r * 4096 + e] = S[l * 4096 + e]; }
+    if (threadIdx.x < 64) { Yst[l * 64 + threadIdx.x] = 0.0; Yst[r * 64 + threadIdx.x] = F[l * 64 + threadIdx.x]; }
 }
 
 template <bool FULL>
@@ -5218,13 +5234,15 @@ int gf_chunk_combine_tree(int B, int P, int W, double *Phi, double *G, double *m
     if (!lds_opt_in(1, st, fn, 4, lds)) return set_err("gf_chunk_combine_tree: cannot opt in to %s%lld bytes of LDS", "", (long long)lds);
     TreeArgs A;
     A.P = P; A.n = W; A.Phi = Phi; A.G = G; A.S = S; A.F = F; A.m = m; A.Xst = Xst; A.Yst = Yst;
-    for (int d = 1; d < P; d *= 2) {        // up-sweep
+    // up-sweep.  Its top level would compose the whole range into the last slot -- a map the down-sweep never
+    // applies (it uses LEFT children only): left out, one level's latency less
+    for (int d = 1; d < P / 2; d *= 2) {
         A.d = d;
         if (W > 48) hipLaunchKernelGGL(k_tree_compose<true>, dim3(B * (P / (2 * d))), dim3(256), lds, st, A);
         else hipLaunchKernelGGL(k_tree_compose<false>, dim3(B * (P / (2 * d))), dim3(256), lds, st, A);
     }
-    hipLaunchKernelGGL(k_tree_root, dim3(B), dim3(256), 0, st, P, Xst, Yst);   // root state = zero
-    for (int d = P / 2; d >= 1; d /= 2) {   // down-sweep
+    hipLaunchKernelGGL(k_tree_top, dim3(B), dim3(256), 0, st, P, S, F, Xst, Yst);   // root state = zero, first level
+    for (int d = P / 4; d >= 1; d /= 2) {   // down-sweep
         A.d = d;
         if (W > 48) hipLaunchKernelGGL(k_tree_apply<true>, dim3(B * (P / (2 * d))), dim3(256), lds, st, A);
         else hipLaunchKernelGGL(k_tree_apply<false>, dim3(B * (P / (2 * d))), dim3(256), lds, st, A);
