@@ -2278,7 +2278,25 @@ __device__ __forceinline__ void cb_mm(double (&acc)[4][4], FA a_of, FB b_of, int
     d4 C[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) C[q] = d4{0.0, 0.0, 0.0, 0.0};
-    if (w < nt) {
+    if (nt == 4) {
+        // the full width as straight-line code: with a loop the accumulators travel between the vector and the
+        // accumulation registers on every trip (64 moves per 16 MFMAs)
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const double av = a_of(16 * w + i, 4 * ks + k);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) C[q] = GF_MFMA64(av, b_of(4 * ks + k, 16 * q + i), C[q]);
+        }
+    } else if (nt == 3) {                               // (widths 33 .. 48: cfg3's W = 40)
+        if (w < 3) {
+#pragma unroll
+            for (int ks = 0; ks < 12; ++ks) {
+                const double av = a_of(16 * w + i, 4 * ks + k);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) C[q] = GF_MFMA64(av, b_of(4 * ks + k, 16 * q + i), C[q]);
+            }
+        }
+    } else if (w < nt) {
 #pragma unroll 4
         for (int ks = 0; ks < 4 * nt; ++ks) {
             const double av = a_of(16 * w + i, 4 * ks + k);
