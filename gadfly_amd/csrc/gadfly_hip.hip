@@ -2347,6 +2347,7 @@ __device__ __forceinline__ void cb_store_lds(double *dst, int ld, const double (
 // scratch >= 140 doubles.  On exit Au[:, 64:129] = A^-1 RHS.
 // n (uniform, <= 64): the system is the identity beyond its leading n x n block with zero right-hand sides there
 // (zero-padded states): the steps k >= n are skipped and those rows of the solution are zeros.
+template <bool SMALL = false>
 __device__ __forceinline__ void cb_gauss_jordan(double *Au, double *scratch, int tid, const int n = 64) {
     constexpr int LA = CB_LA, NC = 33;
     const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2374,9 +2375,9 @@ __device__ __forceinline__ void cb_gauss_jordan(double *Au, double *scratch, int
         if (k1 < 64 && k1 < n && w == w1) {                     // (wave-uniform) the next column's owner
             R[lk1] = fma(-f, read_lane(R[lk1], pv), R[lk1]);
             gj_search(R[lk1], used, lane, fbuf + buf1 * 64, pvbuf + buf1, pinvbuf + buf1);
-            gj_update<lk, NC, lk1>(R, f, pv);
+            gj_update<lk, NC, lk1, SMALL>(R, f, pv);
         } else {
-            gj_update<lk, NC, -1>(R, f, pv);
+            gj_update<lk, NC, -1, SMALL>(R, f, pv);
         }
     }, std::make_integer_sequence<int, 64>{});
     // row `lane` solved variable myk:  x(myk, :) = (right part of the row) / pivot
@@ -2391,6 +2392,7 @@ __device__ __forceinline__ void cb_gauss_jordan(double *Au, double *scratch, int
 // One application of a chunk map to a state, in LDS:  on entry Xs = X, Ys = Y (LDS); Phi, G, m,
 // Xbar, Ybar of the map are read from global.  On exit Xs = X+, Ys = Y+.
 //   A = I - X G ;  [K | v] = A^-1 [X | Y - X m] ;  X+ = Xbar + Phi K Phi^T ;  Y+ = Ybar + Phi v
+template <bool SMALL = false>
 __device__ __forceinline__ void cb_apply(double *Xs, double *Au, double *Bs, double *Ys, double *vs,
                                          const double *__restrict__ Pg, const double *__restrict__ Gg,
                                          const double *__restrict__ mg, const double *__restrict__ Xbar,
@@ -2422,7 +2424,7 @@ __device__ __forceinline__ void cb_apply(double *Xs, double *Au, double *Bs, dou
         Au[tid * LA + 128] = sacc;
     }
     __syncthreads();
-    cb_gauss_jordan(Au, Bs, tid, n);
+    cb_gauss_jordan<SMALL>(Au, Bs, tid, n);
     // Bs <- Phi ; Xs <- Z = Phi K  (K symmetrised)
     cb_load(Bs, Pg, tid);
     if (tid < 64) vs[tid] = Au[tid * LA + 128];
@@ -2505,8 +2507,8 @@ k_combine(const int nch, const int n_, const double *__restrict__ Phi_, const do
             __syncthreads();
             continue;
         }
-        cb_apply(Xs, Au, Bs, Ys, vs, Phi_ + slot * 4096, G_ + slot * 4096, m_ + slot * 64,
-                 nullptr, nullptr, xbar, ybar, tid, n);
+        cb_apply<!FULL>(Xs, Au, Bs, Ys, vs, Phi_ + slot * 4096, G_ + slot * 4096, m_ + slot * 64,
+                        nullptr, nullptr, xbar, ybar, tid, n);
     }
 }
 
@@ -2561,7 +2563,7 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
         Au[tid * LA + 128] = sacc;
     }
     __syncthreads();
-    cb_gauss_jordan(Au, M1, tid, n);          // AR = D, col 128 = v   (M1 serves as scratch ...
+    cb_gauss_jordan<!FULL>(Au, M1, tid, n);   // AR = D, col 128 = v   (M1 serves as scratch ...
     cb_load(M1, A.G + Rr * 4096, tid);      // ... so G2 is loaded again)
     if (tid < 64) vv[tid] = Au[tid * LA + 128];
     __syncthreads();
@@ -2699,8 +2701,8 @@ __global__ void __launch_bounds__(256) k_tree_apply(const TreeArgs A) {
     if (tid < 64) { const double v = A.Yst[Rr * 64 + tid]; A.Yst[L * 64 + tid] = v; Ys[tid] = v; }
     __syncthreads();
     const double noreg[16] = {};
-    cb_apply(Xs, Au, Bs, Ys, vs, A.Phi + L * 4096, A.G + L * 4096, A.m + L * 64,
-             A.S + L * 4096, A.F + L * 64, noreg, 0.0, tid, FULL ? 64 : A.n);
+    cb_apply<!FULL>(Xs, Au, Bs, Ys, vs, A.Phi + L * 4096, A.G + L * 4096, A.m + L * 64,
+                    A.S + L * 4096, A.F + L * 64, noreg, 0.0, tid, FULL ? 64 : A.n);
     _Pragma("unroll 16")
     for (int e = tid; e < 4096; e += 256) { const int j = e >> 6, i = e & 63; Xr[e] = Xs[i * LD + j]; }
     if (tid < 64) A.Yst[Rr * 64 + tid] = Ys[tid];

@@ -75,18 +75,22 @@ __device__ __forceinline__ void static_for(F &&f, std::integer_sequence<int, K..
 // readlane into SGPR pairs, GJ_BATCH columns at a time and then their FMAs: one column at a time the compiler reuses
 // a single SGPR pair, and every FMA waits for its own two readlanes (~30 cycles per column).
 constexpr int GJ_BATCH = 8;
-template <int L0, int NC, int SKIP, int N>
+// SMALL (the 64 x 129 systems of the chunk combines at widths <= 48): the columns 48 .. 63 and 112 .. 127 -- the
+// registers 12 .. 15 and 28 .. 31 of every wave -- are zero in every row that can become a pivot row (zero padding
+// of the states): their updates would add zeros and are left out.
+template <int L0, int NC, int SKIP, bool SMALL = false, int N>
 __device__ __forceinline__ void gj_update(double (&R)[N], const double f, const int pv) {
     static_for([&](auto bc) {
         constexpr int l0 = L0 + GJ_BATCH * decltype(bc)::value;
+        auto live = [](int lc) { return lc < NC && lc != SKIP && !(SMALL && ((lc >= 12 && lc < 16) || (lc >= 28 && lc < 32))); };
         double pr[GJ_BATCH];
 #pragma unroll
         for (int j = 0; j < GJ_BATCH; ++j)
-            if (l0 + j < NC && l0 + j != SKIP) pr[j] = read_lane(R[l0 + j], pv);
+            if (live(l0 + j)) pr[j] = read_lane(R[l0 + j], pv);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < GJ_BATCH; ++j)
-            if (l0 + j < NC && l0 + j != SKIP) R[l0 + j] = fma(-f, pr[j], R[l0 + j]);
+            if (live(l0 + j)) R[l0 + j] = fma(-f, pr[j], R[l0 + j]);
         __builtin_amdgcn_sched_barrier(0);
     }, std::make_integer_sequence<int, (NC - L0 + GJ_BATCH - 1) / GJ_BATCH>{});
 }
