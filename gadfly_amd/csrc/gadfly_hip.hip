@@ -2255,12 +2255,24 @@ k_phi(const int64_t N, const int64_t chunk_len, const int nch, const int ch0, co
 // ---- dense 64x64 helpers for the chunk combines (one workgroup of 256 threads) ---------------
 // LDS matrices are row-major with leading dimension CB_LD (conflict-free rows); global
 // matrices are stored [j][i] (column-major = the lane-major layout of the sweep states).
-constexpr int CB_LD = 65, CB_LA = 130;
+// NS = 64, or 48 for the widths <= 48 (every LDS matrix then has 48 rows and columns: 77 KB per workgroup
+// instead of 135 KB, TWO workgroups per CU -- the levels of the tree scan with more pairs than CUs run two rounds
+// instead of four; the slots in global memory stay 64 x 64, zero beyond the width).
+template <int NS> struct CbDims {
+    static constexpr int LD = NS + 1;           // a matrix' row stride
+    static constexpr int LA = 2 * NS + 2;       // the augmented system's: [A | RHS | one vector]
+    static constexpr int VC = 2 * NS;           // the vector's column
+    static constexpr int NC = NS / 2 + 1;       // Gauss-Jordan: registers per lane (columns c = 4 lc + wave <= VC)
+    static constexpr int R0 = NS / 4;           // ... the first one of the right-hand sides
+};
+constexpr int CB_LD = CbDims<64>::LD, CB_LA = CbDims<64>::LA;
 
+template <int NS = 64>
 __device__ __forceinline__ void cb_load(double *dst, const double *__restrict__ src, int tid,
-                                        int ld = CB_LD) {
-    _Pragma("unroll 16")
-    for (int e = tid; e < 4096; e += 256) { const int j = e >> 6, i = e & 63; dst[i * ld + j] = src[e]; }
+                                        int ld = CbDims<NS>::LD) {
+    if (NS < 64 && (tid & 63) >= NS) return;            // (element e = [j][i]: row i = e & 63, column j = e >> 6)
+#pragma unroll
+    for (int q = 0; q < NS / 4; ++q) { const int e = tid + 256 * q, j = e >> 6, i = e & 63; dst[i * ld + j] = src[e]; }
 }
 
 // 64 x 64 x 64 products on v_mfma_f64_16x16x4 (256 threads = 4 waves; wave w owns rows 16w..16w+15
@@ -2320,9 +2332,11 @@ __device__ __forceinline__ void cb_matmul(double (&acc)[4][4], const double *A, 
           [&](int k, int col) { return TB ? B[col * ldb + k] : B[k * ldb + col]; }, tx, ty, nt);
 }
 
+template <int NS = 64>
 __device__ __forceinline__ void cb_store_lds(double *dst, int ld, const double (&acc)[4][4], int tx, int ty) {
+    if (NS < 64 && 16 * (ty >> 2) >= NS) return;        // (wave ty >> 2 holds the rows 16 (ty >> 2) ...)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < NS / 16; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dst[cb_row(ty, r) * ld + cb_col(tx, q)] = acc[q][r];
 }
@@ -2347,20 +2361,21 @@ __device__ __forceinline__ void cb_store_lds(double *dst, int ld, const double (
 // scratch >= 140 doubles.  On exit Au[:, 64:129] = A^-1 RHS.
 // n (uniform, <= 64): the system is the identity beyond its leading n x n block with zero right-hand sides there
 // (zero-padded states): the steps k >= n are skipped and those rows of the solution are zeros.
-template <bool SMALL = false>
-__device__ __forceinline__ void cb_gauss_jordan(double *Au, double *scratch, int tid, const int n = 64) {
-    constexpr int LA = CB_LA, NC = 33;
+template <int NS = 64>
+__device__ __forceinline__ void cb_gauss_jordan(double *Au, double *scratch, int tid, const int n = NS) {
+    constexpr int LA = CbDims<NS>::LA, NC = CbDims<NS>::NC, VC = CbDims<NS>::VC, R0 = CbDims<NS>::R0;
     const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *fbuf = scratch;                                     // [2][64] multipliers
     double *pinvbuf = scratch + 128;                            // [2]
     int *pvbuf = reinterpret_cast<int *>(scratch + 130);        // [2]
+    const bool dead = NS < 64 && lane >= NS;                    // (no such row)
     double R[NC];
 #pragma unroll
     for (int lc = 0; lc < NC; ++lc) {
         const int c = 4 * lc + w;
-        R[lc] = (c <= 128) ? Au[lane * LA + c] : 0.0;
+        R[lc] = (c <= VC && !dead) ? Au[lane * LA + c] : 0.0;
     }
-    bool used = false;                      // row `lane` already served as a pivot
+    bool used = dead;                       // row `lane` already served as a pivot (or does not exist)
     int myk = 0;                            // ... of which variable
     double mypinv = 0.0;                    // ... with which 1 / pivot
     if (w == 0 && n > 0) gj_search(R[0], used, lane, fbuf, pvbuf, pinvbuf);
@@ -2372,19 +2387,20 @@ __device__ __forceinline__ void cb_gauss_jordan(double *Au, double *scratch, int
         const double f = fbuf[buf * 64 + lane];
         const int pv = __builtin_amdgcn_readfirstlane(pvbuf[buf]);
         if (lane == pv) { used = true; myk = k; mypinv = pinvbuf[buf]; }
-        if (k1 < 64 && k1 < n && w == w1) {                     // (wave-uniform) the next column's owner
+        if (k1 < NS && k1 < n && w == w1) {                     // (wave-uniform) the next column's owner
             R[lk1] = fma(-f, read_lane(R[lk1], pv), R[lk1]);
             gj_search(R[lk1], used, lane, fbuf + buf1 * 64, pvbuf + buf1, pinvbuf + buf1);
-            gj_update<lk, NC, lk1, SMALL>(R, f, pv);
+            gj_update<lk, NC, lk1>(R, f, pv);
         } else {
-            gj_update<lk, NC, -1, SMALL>(R, f, pv);
+            gj_update<lk, NC, -1>(R, f, pv);
         }
-    }, std::make_integer_sequence<int, 64>{});
+    }, std::make_integer_sequence<int, NS>{});
     // row `lane` solved variable myk:  x(myk, :) = (right part of the row) / pivot
+    const bool piv = used && !dead;
 #pragma unroll
-    for (int lc = 16; lc < NC; ++lc) {
+    for (int lc = R0; lc < NC; ++lc) {
         const int c = 4 * lc + w;
-        if (c <= 128) Au[(used ? myk : lane) * LA + c] = used ? R[lc] * mypinv : 0.0;   // (rows >= n: never pivots)
+        if (c <= VC && !dead) Au[(piv ? myk : lane) * LA + c] = piv ? R[lc] * mypinv : 0.0;   // (rows >= n: never pivots)
     }
     __syncthreads();
 }
@@ -2392,18 +2408,18 @@ __device__ __forceinline__ void cb_gauss_jordan(double *Au, double *scratch, int
 // One application of a chunk map to a state, in LDS:  on entry Xs = X, Ys = Y (LDS); Phi, G, m,
 // Xbar, Ybar of the map are read from global.  On exit Xs = X+, Ys = Y+.
 //   A = I - X G ;  [K | v] = A^-1 [X | Y - X m] ;  X+ = Xbar + Phi K Phi^T ;  Y+ = Ybar + Phi v
-template <bool SMALL = false>
+template <int NS = 64>
 __device__ __forceinline__ void cb_apply(double *Xs, double *Au, double *Bs, double *Ys, double *vs,
                                          const double *__restrict__ Pg, const double *__restrict__ Gg,
                                          const double *__restrict__ mg, const double *__restrict__ Xbar,
                                          const double *__restrict__ Ybar, const double (&xreg)[16],
-                                         const double yreg, int tid, const int n = 64) {
-    const int nt = (n + 15) >> 4;             // (maps of width n <= 64, zero-padded: cb_mm / cb_gauss_jordan)
+                                         const double yreg, int tid, const int n = NS) {
+    const int nt = (n + 15) >> 4;             // (maps of width n <= NS, zero-padded: cb_mm / cb_gauss_jordan)
     // Xbar/Ybar: global pointers, or nullptr to take them from registers (xreg[q] = element
     // e = tid + 256 q of the [j][i] layout, yreg = element tid)
-    constexpr int LD = CB_LD, LA = CB_LA;
+    constexpr int LD = CbDims<NS>::LD, LA = CbDims<NS>::LA, VC = CbDims<NS>::VC;
     const int tx = tid & 15, ty = tid >> 4;
-    cb_load(Bs, Gg, tid);
+    cb_load<NS>(Bs, Gg, tid);
     if (tid < 64) vs[tid] = mg[tid];
     __syncthreads();
     {
@@ -2414,32 +2430,34 @@ __device__ __forceinline__ void cb_apply(double *Xs, double *Au, double *Bs, dou
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
                 const int i = cb_row(ty, cc), j = cb_col(tx, a);
-                Au[i * LA + j] = ((i == j) ? 1.0 : 0.0) - acc[a][cc];
-                Au[i * LA + 64 + j] = Xs[i * LD + j];
+                if (NS == 64 || (i < NS && j < NS)) {
+                    Au[i * LA + j] = ((i == j) ? 1.0 : 0.0) - acc[a][cc];
+                    Au[i * LA + NS + j] = Xs[i * LD + j];
+                }
             }
     }
-    if (tid < 64) {                         // rhs = Y - X m
+    if (tid < NS) {                         // rhs = Y - X m
         double sacc = Ys[tid];
         for (int k = 0; k < n; ++k) sacc = fma(-Xs[tid * LD + k], vs[k], sacc);
-        Au[tid * LA + 128] = sacc;
+        Au[tid * LA + VC] = sacc;
     }
     __syncthreads();
-    cb_gauss_jordan<SMALL>(Au, Bs, tid, n);
+    cb_gauss_jordan<NS>(Au, Bs, tid, n);
     // Bs <- Phi ; Xs <- Z = Phi K  (K symmetrised)
-    cb_load(Bs, Pg, tid);
-    if (tid < 64) vs[tid] = Au[tid * LA + 128];
+    cb_load<NS>(Bs, Pg, tid);
+    if (tid < NS) vs[tid] = Au[tid * LA + VC];
     __syncthreads();
     {
         double acc[4][4] = {};
         cb_mm(acc,
               [&](int row, int k) { return Bs[row * LD + k]; },
-              [&](int k, int col) { return 0.5 * (Au[k * LA + 64 + col] + Au[col * LA + 64 + k]); },
+              [&](int k, int col) { return 0.5 * (Au[k * LA + NS + col] + Au[col * LA + NS + k]); },
               tx, ty, nt);
         __syncthreads();
-        cb_store_lds(Xs, LD, acc, tx, ty);
+        cb_store_lds<NS>(Xs, LD, acc, tx, ty);
     }
     double ynew = 0.0;
-    if (tid < 64) {                         // Y+ = Ybar + Phi v
+    if (tid < NS) {                         // Y+ = Ybar + Phi v
         ynew = Ybar ? Ybar[tid] : yreg;
         for (int k = 0; k < n; ++k) ynew = fma(Bs[tid * LD + k], vs[k], ynew);
     }
@@ -2448,13 +2466,15 @@ __device__ __forceinline__ void cb_apply(double *Xs, double *Au, double *Bs, dou
         double acc[4][4] = {};
         cb_matmul<false, true>(acc, Xs, LD, Bs, LD, tx, ty, nt);
         __syncthreads();
-        cb_store_lds(Au, LA, acc, tx, ty);
+        cb_store_lds<NS>(Au, LA, acc, tx, ty);
     }
     __syncthreads();
+    if (NS == 64 || (tid & 63) < NS) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {              // add Xbar (coalesced) and symmetrise
-        const int e = tid + 256 * q, j = e >> 6, i = e & 63;
-        Xs[i * LD + j] = (Xbar ? Xbar[e] : xreg[q]) + 0.5 * (Au[i * LA + j] + Au[j * LA + i]);
+        for (int q = 0; q < NS / 4; ++q) {          // add Xbar (coalesced) and symmetrise
+            const int e = tid + 256 * q, j = e >> 6, i = e & 63;
+            Xs[i * LD + j] = (Xbar ? Xbar[e] : xreg[q]) + 0.5 * (Au[i * LA + j] + Au[j * LA + i]);
+        }
     }
     if (tid < 64) Ys[tid] = ynew;
     __syncthreads();
@@ -2468,30 +2488,30 @@ __global__ void __launch_bounds__(256)
 k_combine(const int nch, const int n_, const double *__restrict__ Phi_, const double *__restrict__ G_,
           const double *__restrict__ m_, double *__restrict__ S_state,
           double *__restrict__ F_state) {
-    constexpr int LD = CB_LD, LA = CB_LA;
+    constexpr int NS = FULL ? 64 : 48, LD = CbDims<NS>::LD, LA = CbDims<NS>::LA;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *Xs = lds;                       // [64][LD]
-    double *Au = Xs + 64 * LD;              // [64][LA]
-    double *Bs = Au + 64 * LA;              // [64][LD]
-    double *Ys = Bs + 64 * LD;              // [64]
+    double *Xs = lds;                       // [NS][LD]
+    double *Au = Xs + NS * LD;              // [NS][LA]
+    double *Bs = Au + NS * LA;              // [NS][LD]
+    double *Ys = Bs + NS * LD;              // [64]
     double *vs = Ys + 64;                   // [64]
     const int pr = blockIdx.x;
     const int tid = threadIdx.x;
     const int n = FULL ? 64 : n_;
-    for (int e = tid; e < 64 * LD; e += 256) Xs[e] = 0.0;
+    const bool in = NS == 64 || (tid & 63) < NS;    // this thread's elements e = tid + 256 q lie in rows < NS
+    for (int e = tid; e < NS * LD; e += 256) Xs[e] = 0.0;
     if (tid < 64) Ys[tid] = 0.0;
     __syncthreads();
     for (int c = 0; c < nch; ++c) {
         const size_t slot = (size_t)pr * nch + c;
         double *Sg = S_state + slot * 4096;
         double *Fg = F_state + slot * 64;
-        // keep this chunk's nominal end state, publish its TRUE start state
+        // keep this chunk's nominal end state, publish its TRUE start state (beyond NS the slots hold zeros, and keep them)
         double xbar[16], ybar = 0.0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < NS / 4; ++q) {
             const int e = tid + 256 * q, j = e >> 6, i = e & 63;
-            xbar[q] = Sg[e];
-            Sg[e] = Xs[i * LD + j];
+            if (in) { xbar[q] = Sg[e]; Sg[e] = Xs[i * LD + j]; }
         }
         if (tid < 64) { ybar = Fg[tid]; Fg[tid] = Ys[tid]; }
         if (c == nch - 1) break;
@@ -2499,16 +2519,16 @@ k_combine(const int nch, const int n_, const double *__restrict__ Phi_, const do
             // from the zero state a chunk's map returns its own nominal end state (K = 0, v = 0): no solve
             __syncthreads();
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < NS / 4; ++q) {
                 const int e = tid + 256 * q, j = e >> 6, i = e & 63;
-                Xs[i * LD + j] = xbar[q];
+                if (in) Xs[i * LD + j] = xbar[q];
             }
             if (tid < 64) Ys[tid] = ybar;
             __syncthreads();
             continue;
         }
-        cb_apply<!FULL>(Xs, Au, Bs, Ys, vs, Phi_ + slot * 4096, G_ + slot * 4096, m_ + slot * 64,
-                        nullptr, nullptr, xbar, ybar, tid, n);
+        cb_apply<NS>(Xs, Au, Bs, Ys, vs, Phi_ + slot * 4096, G_ + slot * 4096, m_ + slot * 64,
+                     nullptr, nullptr, xbar, ybar, tid, n);
     }
 }
 
@@ -2527,22 +2547,24 @@ struct TreeArgs {
 
 template <bool FULL>
 __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
-    constexpr int LD = CB_LD, LA = CB_LA;
+    constexpr int NS = FULL ? 64 : 48, LD = CbDims<NS>::LD, LA = CbDims<NS>::LA, VC = CbDims<NS>::VC;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *M0 = lds;                       // [64][LD]
-    double *Au = M0 + 64 * LD;              // [64][LA]  = AL | AR
-    double *M1 = Au + 64 * LA;              // [64][LD]
-    double *v1 = M1 + 64 * LD;              // [64] x 4 small vectors
+    double *M0 = lds;                       // [NS][LD]
+    double *Au = M0 + NS * LD;              // [NS][LA]  = AL | AR | one vector
+    double *M1 = Au + NS * LA;              // [NS][LD]
+    double *v1 = M1 + NS * LD;              // [64] x 4 small vectors
     const int pairs = A.P / (2 * A.d);
     const int pr = blockIdx.x / pairs, k = blockIdx.x - pr * pairs;
     const int ir = (k + 1) * 2 * A.d - 1, il = ir - A.d;
     const size_t L = (size_t)pr * A.P + il, Rr = (size_t)pr * A.P + ir;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int n = FULL ? 64 : A.n, nt = FULL ? 4 : ((n + 15) >> 4);
+    const bool in = NS == 64 || (tid & 63) < NS;    // this thread's slot elements e = tid + 256 q lie in rows < NS
+    const bool vin = tid < NS;                      // ... its vector element exists
     double *w = v1, *vv = v1 + 64, *g2v = v1 + 128, *tmpv = v1 + 192;
-    // a. M0 = Xbar1, M1 = G2 ;  AL = I - Xbar1 G2 ; AR = I ; col 128 = Ybar1 - Xbar1 m2
-    cb_load(M0, A.S + L * 4096, tid);
-    cb_load(M1, A.G + Rr * 4096, tid);
+    // a. M0 = Xbar1, M1 = G2 ;  AL = I - Xbar1 G2 ; AR = I ; the vector column = Ybar1 - Xbar1 m2
+    cb_load<NS>(M0, A.S + L * 4096, tid);
+    cb_load<NS>(M1, A.G + Rr * 4096, tid);
     if (tid < 64) tmpv[tid] = A.m[Rr * 64 + tid];
     __syncthreads();
     {
@@ -2553,45 +2575,49 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int i = cb_row(ty, c), j = cb_col(tx, a);
-                Au[i * LA + j] = ((i == j) ? 1.0 : 0.0) - acc[a][c];
-                Au[i * LA + 64 + j] = (i == j) ? 1.0 : 0.0;
+                if (NS == 64 || (i < NS && j < NS)) {
+                    Au[i * LA + j] = ((i == j) ? 1.0 : 0.0) - acc[a][c];
+                    Au[i * LA + NS + j] = (i == j) ? 1.0 : 0.0;
+                }
             }
     }
-    if (tid < 64) {
+    if (vin) {
         double sacc = A.F[L * 64 + tid];
         for (int kk = 0; kk < n; ++kk) sacc = fma(-M0[tid * LD + kk], tmpv[kk], sacc);
-        Au[tid * LA + 128] = sacc;
+        Au[tid * LA + VC] = sacc;
     }
     __syncthreads();
-    cb_gauss_jordan<!FULL>(Au, M1, tid, n);   // AR = D, col 128 = v   (M1 serves as scratch ...
-    cb_load(M1, A.G + Rr * 4096, tid);      // ... so G2 is loaded again)
-    if (tid < 64) vv[tid] = Au[tid * LA + 128];
+    cb_gauss_jordan<NS>(Au, M1, tid, n);    // AR = D, the vector column = v   (M1 serves as scratch ...
+    cb_load<NS>(M1, A.G + Rr * 4096, tid);  // ... so G2 is loaded again)
+    if (tid < 64) vv[tid] = vin ? Au[tid * LA + VC] : 0.0;
     __syncthreads();
     if (tid < 64) {                         // g2v = G2 v ;  m12 pieces need it
         double sacc = 0.0;
-        for (int kk = 0; kk < n; ++kk) sacc = fma(M1[tid * LD + kk], vv[kk], sacc);
+        if (vin)
+            for (int kk = 0; kk < n; ++kk) sacc = fma(M1[tid * LD + kk], vv[kk], sacc);
         g2v[tid] = sacc;
     }
     // c. AL = D Xbar1
     {
         double acc[4][4] = {};
-        cb_matmul<false, false>(acc, Au + 64, LA, M0, LD, tx, ty, nt);
+        cb_matmul<false, false>(acc, Au + NS, LA, M0, LD, tx, ty, nt);
         __syncthreads();
-        cb_store_lds(Au, LA, acc, tx, ty);
+        cb_store_lds<NS>(Au, LA, acc, tx, ty);
     }
     __syncthreads();
     // d. M0 = Phi2 ;  AL <- Phi2 (D Xbar1) ;  Xbar12 = Xbar2 + AL Phi2^T ;  Ybar12 = Ybar2 + Phi2 v
-    cb_load(M0, A.Phi + Rr * 4096, tid);
+    cb_load<NS>(M0, A.Phi + Rr * 4096, tid);
     __syncthreads();
     {
         double acc[4][4] = {};
         cb_matmul<false, false>(acc, M0, LD, Au, LA, tx, ty, nt);
         __syncthreads();
-        cb_store_lds(Au, LA, acc, tx, ty);
+        cb_store_lds<NS>(Au, LA, acc, tx, ty);
     }
     if (tid < 64) {
         double sacc = A.F[Rr * 64 + tid];
-        for (int kk = 0; kk < n; ++kk) sacc = fma(M0[tid * LD + kk], vv[kk], sacc);
+        if (vin)
+            for (int kk = 0; kk < n; ++kk) sacc = fma(M0[tid * LD + kk], vv[kk], sacc);
         w[tid] = sacc;                      // Ybar12 (stored at the end)
     }
     __syncthreads();
@@ -2599,31 +2625,31 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
         double acc[4][4] = {};
         cb_matmul<false, true>(acc, Au, LA, M0, LD, tx, ty, nt);
         __syncthreads();
-        cb_store_lds(Au, LA, acc, tx, ty);
+        cb_store_lds<NS>(Au, LA, acc, tx, ty);
     }
     __syncthreads();
-    {
+    if (in) {
         double *Sr = A.S + Rr * 4096;
-        _Pragma("unroll 16")
-        for (int e = tid; e < 4096; e += 256) {
-            const int j = e >> 6, i = e & 63;
+#pragma unroll
+        for (int q = 0; q < NS / 4; ++q) {
+            const int e = tid + 256 * q, j = e >> 6, i = e & 63;
             Sr[e] += 0.5 * (Au[i * LA + j] + Au[j * LA + i]);
         }
     }
     __syncthreads();
     // e. AL = Phi1 ;  AR <- D Phi1 ;  Phi12 = Phi2 (D Phi1)
-    cb_load(Au, A.Phi + L * 4096, tid, LA);
+    cb_load<NS>(Au, A.Phi + L * 4096, tid, LA);
     __syncthreads();
     {
         double acc[4][4] = {};
-        cb_matmul<false, false>(acc, Au + 64, LA, Au, LA, tx, ty, nt);
+        cb_matmul<false, false>(acc, Au + NS, LA, Au, LA, tx, ty, nt);
         __syncthreads();
-        cb_store_lds(Au + 64, LA, acc, tx, ty);
+        cb_store_lds<NS>(Au + NS, LA, acc, tx, ty);
     }
     __syncthreads();
     {
         double acc[4][4] = {};
-        cb_matmul<false, false>(acc, M0, LD, Au + 64, LA, tx, ty, nt);
+        cb_matmul<false, false>(acc, M0, LD, Au + NS, LA, tx, ty, nt);
         double *Pr = A.Phi + Rr * 4096;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -2634,30 +2660,31 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
     // f. M1 <- G2 (D Phi1) ;  G12 = G1 + Phi1^T M1 ;  m12 = m1 + Phi1^T (m2 - G2 v)
     {
         double acc[4][4] = {};
-        cb_matmul<false, false>(acc, M1, LD, Au + 64, LA, tx, ty, nt);
+        cb_matmul<false, false>(acc, M1, LD, Au + NS, LA, tx, ty, nt);
         __syncthreads();
-        cb_store_lds(M1, LD, acc, tx, ty);
+        cb_store_lds<NS>(M1, LD, acc, tx, ty);
     }
     __syncthreads();
     {
         double acc[4][4] = {};
         cb_matmul<true, false>(acc, Au, LA, M1, LD, tx, ty, nt);
         __syncthreads();
-        cb_store_lds(M0, LD, acc, tx, ty);  // Phi2 no longer needed
+        cb_store_lds<NS>(M0, LD, acc, tx, ty);  // Phi2 no longer needed
     }
     if (tid < 64) {
         double sacc = A.m[L * 64 + tid];
-        for (int kk = 0; kk < n; ++kk) sacc = fma(Au[kk * LA + tid], tmpv[kk] - g2v[kk], sacc);
+        if (vin)
+            for (int kk = 0; kk < n; ++kk) sacc = fma(Au[kk * LA + tid], tmpv[kk] - g2v[kk], sacc);
         A.m[Rr * 64 + tid] = sacc;
         A.F[Rr * 64 + tid] = w[tid];
     }
     __syncthreads();
-    {
+    if (in) {
         double *Gr = A.G + Rr * 4096;
         const double *Gl = A.G + L * 4096;
-        _Pragma("unroll 16")
-        for (int e = tid; e < 4096; e += 256) {
-            const int j = e >> 6, i = e & 63;
+#pragma unroll
+        for (int q = 0; q < NS / 4; ++q) {
+            const int e = tid + 256 * q, j = e >> 6, i = e & 63;
             Gr[e] = Gl[e] + 0.5 * (M0[i * LD + j] + M0[j * LD + i]);
         }
     }
@@ -2677,12 +2704,12 @@ __global__ void __launch_bounds__(256) k_tree_top(const int P, const double *__r
 
 template <bool FULL>
 __global__ void __launch_bounds__(256) k_tree_apply(const TreeArgs A) {
-    constexpr int LD = CB_LD, LA = CB_LA;
+    constexpr int NS = FULL ? 64 : 48, LD = CbDims<NS>::LD, LA = CbDims<NS>::LA;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *Xs = lds;
-    double *Au = Xs + 64 * LD;
-    double *Bs = Au + 64 * LA;
-    double *Ys = Bs + 64 * LD;
+    double *Au = Xs + NS * LD;
+    double *Bs = Au + NS * LA;
+    double *Ys = Bs + NS * LD;
     double *vs = Ys + 64;
     const int pairs = A.P / (2 * A.d);
     const int pr = blockIdx.x / pairs, k = blockIdx.x - pr * pairs;
@@ -2691,20 +2718,25 @@ __global__ void __launch_bounds__(256) k_tree_apply(const TreeArgs A) {
     const int tid = threadIdx.x;
     double *Xr = A.Xst + Rr * 4096, *Xl = A.Xst + L * 4096;
     // s[left] <- s[right] (incoming state) ;  s[right] <- map[left](s[right])
+    // (the whole slot is handed to the left child -- its padding too: state slots are not cleared between scans;
+    // of the right child's slot the leading NS x NS block is rewritten, the rest holds zeros already)
+    const bool in = NS == 64 || (tid & 63) < NS;
     _Pragma("unroll 16")
     for (int e = tid; e < 4096; e += 256) {
         const int j = e >> 6, i = e & 63;
         const double v = Xr[e];
         Xl[e] = v;
-        Xs[i * LD + j] = v;
+        if (NS == 64 || (in && j < NS)) Xs[i * LD + j] = v;
     }
     if (tid < 64) { const double v = A.Yst[Rr * 64 + tid]; A.Yst[L * 64 + tid] = v; Ys[tid] = v; }
     __syncthreads();
     const double noreg[16] = {};
-    cb_apply<!FULL>(Xs, Au, Bs, Ys, vs, A.Phi + L * 4096, A.G + L * 4096, A.m + L * 64,
-                    A.S + L * 4096, A.F + L * 64, noreg, 0.0, tid, FULL ? 64 : A.n);
-    _Pragma("unroll 16")
-    for (int e = tid; e < 4096; e += 256) { const int j = e >> 6, i = e & 63; Xr[e] = Xs[i * LD + j]; }
+    cb_apply<NS>(Xs, Au, Bs, Ys, vs, A.Phi + L * 4096, A.G + L * 4096, A.m + L * 64,
+                 A.S + L * 4096, A.F + L * 64, noreg, 0.0, tid, FULL ? 64 : A.n);
+    if (in) {
+#pragma unroll
+        for (int q = 0; q < NS / 4; ++q) { const int e = tid + 256 * q, j = e >> 6, i = e & 63; Xr[e] = Xs[i * LD + j]; }
+    }
     if (tid < 64) A.Yst[Rr * 64 + tid] = Ys[tid];
 }
 
@@ -5220,9 +5252,9 @@ static bool lds_opt_in(int which, hipStream_t st, const void *const *funcs, int 
     return gf_internal_lds_opt_in(which, st, funcs, nfuncs, bytes);
 }
 
-static size_t cb_lds_bytes(bool with_xn) {
-    (void)with_xn;
-    return sizeof(double) * (64 * CB_LD + 64 * CB_LA + 64 * CB_LD + 256);
+static size_t cb_lds_bytes(int W) {      // widths <= 48: 48 x 48 matrices, two workgroups per CU
+    const int NS = W > 48 ? 64 : 48;
+    return sizeof(double) * ((size_t)NS * (2 * (NS + 1) + 2 * NS + 2) + 256);
 }
 
 int gf_chunk_combine(int B, int nch, int W, const double *Phi, const double *G, const double *m,
@@ -5230,9 +5262,9 @@ int gf_chunk_combine(int B, int nch, int W, const double *Phi, const double *G, 
     if (B < 1 || nch < 1) return set_err("gf_chunk_combine: empty problem%s", "");
     if (W < 1 || W > 64) return set_err("gf_chunk_combine: width %s%lld unsupported (1..64)", "", W);
     if (!Phi || !G || !m || !S_state || !F_state) return set_err("gf_chunk_combine: null pointer%s", "");
-    const size_t lds = cb_lds_bytes(true);
+    const size_t lds = cb_lds_bytes(W);
     const void *fn[2] = {(const void *)k_combine<true>, (const void *)k_combine<false>};
-    if (!lds_opt_in(0, (hipStream_t)stream, fn, 2, lds)) return set_err("gf_chunk_combine: cannot opt in to %s%lld bytes of LDS", "", (long long)lds);
+    if (!lds_opt_in(0, (hipStream_t)stream, fn, 2, cb_lds_bytes(64))) return set_err("gf_chunk_combine: cannot opt in to %s%lld bytes of LDS", "", (long long)lds);
     if (W > 48) hipLaunchKernelGGL(k_combine<true>, dim3(B), dim3(256), lds, (hipStream_t)stream, nch, W, Phi, G, m, S_state, F_state);
     else hipLaunchKernelGGL(k_combine<false>, dim3(B), dim3(256), lds, (hipStream_t)stream, nch, W, Phi, G, m, S_state, F_state);
     return check_launch("gf_chunk_combine");
@@ -5248,10 +5280,10 @@ int gf_chunk_combine_tree(int B, int P, int W, double *Phi, double *G, double *m
     if (W < 1 || W > 64) return set_err("gf_chunk_combine_tree: width %s%lld unsupported (1..64)", "", W);
     if (!Phi || !G || !m || !S || !F || !Xst || !Yst) return set_err("gf_chunk_combine_tree: null pointer%s", "");
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = cb_lds_bytes(false);
+    const size_t lds = cb_lds_bytes(W);
     const void *fn[4] = {(const void *)k_tree_compose<true>, (const void *)k_tree_apply<true>,
                          (const void *)k_tree_compose<false>, (const void *)k_tree_apply<false>};
-    if (!lds_opt_in(1, st, fn, 4, lds)) return set_err("gf_chunk_combine_tree: cannot opt in to %s%lld bytes of LDS", "", (long long)lds);
+    if (!lds_opt_in(1, st, fn, 4, cb_lds_bytes(64))) return set_err("gf_chunk_combine_tree: cannot opt in to %s%lld bytes of LDS", "", (long long)lds);
     TreeArgs A;
     A.P = P; A.n = W; A.Phi = Phi; A.G = G; A.S = S; A.F = F; A.m = m; A.Xst = Xst; A.Yst = Yst;
     // up-sweep.  Its top level would compose the whole range into the last slot -- a map the down-sweep never

@@ -75,14 +75,11 @@ __device__ __forceinline__ void static_for(F &&f, std::integer_sequence<int, K..
 // readlane into SGPR pairs, GJ_BATCH columns at a time and then their FMAs: one column at a time the compiler reuses
 // a single SGPR pair, and every FMA waits for its own two readlanes (~30 cycles per column).
 constexpr int GJ_BATCH = 8;
-// SMALL (the 64 x 129 systems of the chunk combines at widths <= 48): the columns 48 .. 63 and 112 .. 127 -- the
-// registers 12 .. 15 and 28 .. 31 of every wave -- are zero in every row that can become a pivot row (zero padding
-// of the states): their updates would add zeros and are left out.
-template <int L0, int NC, int SKIP, bool SMALL = false, int N>
+template <int L0, int NC, int SKIP, int N>
 __device__ __forceinline__ void gj_update(double (&R)[N], const double f, const int pv) {
     static_for([&](auto bc) {
         constexpr int l0 = L0 + GJ_BATCH * decltype(bc)::value;
-        auto live = [](int lc) { return lc < NC && lc != SKIP && !(SMALL && ((lc >= 12 && lc < 16) || (lc >= 28 && lc < 32))); };
+        auto live = [](int lc) { return lc < NC && lc != SKIP; };
         double pr[GJ_BATCH];
 #pragma unroll
         for (int j = 0; j < GJ_BATCH; ++j)
