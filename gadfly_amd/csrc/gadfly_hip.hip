@@ -2483,12 +2483,13 @@ __device__ __forceinline__ void cb_apply(double *Xs, double *Au, double *Bs, dou
 // Sequential LFT combine over the chunks of each problem (one workgroup per problem).
 // S_state/F_state slot c holds (Xbar_end, Ybar_end) of chunk c on entry and the TRUE start
 // state of chunk c on exit (slot 0 <- 0).
-template <bool FULL>                    // FULL: widths beyond 48 take the whole 64 x 64 slots (compile-time bounds)
+template <int NS>                       // LDS matrix size: 64 (widths beyond 48: compile-time bounds), 48 or 32
 __global__ void __launch_bounds__(256)
 k_combine(const int nch, const int n_, const double *__restrict__ Phi_, const double *__restrict__ G_,
           const double *__restrict__ m_, double *__restrict__ S_state,
           double *__restrict__ F_state) {
-    constexpr int NS = FULL ? 64 : 48, LD = CbDims<NS>::LD, LA = CbDims<NS>::LA;
+    constexpr bool FULL = NS == 64;
+    constexpr int LD = CbDims<NS>::LD, LA = CbDims<NS>::LA;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *Xs = lds;                       // [NS][LD]
     double *Au = Xs + NS * LD;              // [NS][LA]
@@ -2545,9 +2546,10 @@ struct TreeArgs {
     double *Xst, *Yst;                      // states [B*P][4096] / [64]
 };
 
-template <bool FULL>
+template <int NS>
 __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
-    constexpr int NS = FULL ? 64 : 48, LD = CbDims<NS>::LD, LA = CbDims<NS>::LA, VC = CbDims<NS>::VC;
+    constexpr bool FULL = NS == 64;
+    constexpr int LD = CbDims<NS>::LD, LA = CbDims<NS>::LA, VC = CbDims<NS>::VC;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *M0 = lds;                       // [NS][LD]
     double *Au = M0 + NS * LD;              // [NS][LA]  = AL | AR | one vector
@@ -2702,9 +2704,10 @@ __global__ void __launch_bounds__(256) k_tree_top(const int P, const double *__r
     if (threadIdx.x < 64) { Yst[l * 64 + threadIdx.x] = 0.0; Yst[r * 64 + threadIdx.x] = F[l * 64 + threadIdx.x]; }
 }
 
-template <bool FULL>
+template <int NS>
 __global__ void __launch_bounds__(256) k_tree_apply(const TreeArgs A) {
-    constexpr int NS = FULL ? 64 : 48, LD = CbDims<NS>::LD, LA = CbDims<NS>::LA;
+    constexpr bool FULL = NS == 64;
+    constexpr int LD = CbDims<NS>::LD, LA = CbDims<NS>::LA;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *Xs = lds;
     double *Au = Xs + NS * LD;
@@ -5252,8 +5255,9 @@ static bool lds_opt_in(int which, hipStream_t st, const void *const *funcs, int 
     return gf_internal_lds_opt_in(which, st, funcs, nfuncs, bytes);
 }
 
-static size_t cb_lds_bytes(int W) {      // widths <= 48: 48 x 48 matrices, two workgroups per CU
-    const int NS = W > 48 ? 64 : 48;
+static int cb_ns(int W) { return W > 48 ? 64 : (W > 32 ? 48 : 32); }
+static size_t cb_lds_bytes(int W) {      // 48 x 48 matrices: two workgroups per CU; 32 x 32: four
+    const int NS = cb_ns(W);
     return sizeof(double) * ((size_t)NS * (2 * (NS + 1) + 2 * NS + 2) + 256);
 }
 
@@ -5263,10 +5267,14 @@ int gf_chunk_combine(int B, int nch, int W, const double *Phi, const double *G, 
     if (W < 1 || W > 64) return set_err("gf_chunk_combine: width %s%lld unsupported (1..64)", "", W);
     if (!Phi || !G || !m || !S_state || !F_state) return set_err("gf_chunk_combine: null pointer%s", "");
     const size_t lds = cb_lds_bytes(W);
-    const void *fn[2] = {(const void *)k_combine<true>, (const void *)k_combine<false>};
-    if (!lds_opt_in(0, (hipStream_t)stream, fn, 2, cb_lds_bytes(64))) return set_err("gf_chunk_combine: cannot opt in to %s%lld bytes of LDS", "", (long long)lds);
-    if (W > 48) hipLaunchKernelGGL(k_combine<true>, dim3(B), dim3(256), lds, (hipStream_t)stream, nch, W, Phi, G, m, S_state, F_state);
-    else hipLaunchKernelGGL(k_combine<false>, dim3(B), dim3(256), lds, (hipStream_t)stream, nch, W, Phi, G, m, S_state, F_state);
+    const void *fn[3] = {(const void *)k_combine<64>, (const void *)k_combine<48>, (const void *)k_combine<32>};
+    if (!lds_opt_in(0, (hipStream_t)stream, fn, 3, cb_lds_bytes(64))) return set_err("gf_chunk_combine: cannot opt in to %s%lld bytes of LDS", "", (long long)lds);
+    hipStream_t st = (hipStream_t)stream;
+    switch (cb_ns(W)) {
+    case 64: hipLaunchKernelGGL(k_combine<64>, dim3(B), dim3(256), lds, st, nch, W, Phi, G, m, S_state, F_state); break;
+    case 48: hipLaunchKernelGGL(k_combine<48>, dim3(B), dim3(256), lds, st, nch, W, Phi, G, m, S_state, F_state); break;
+    default: hipLaunchKernelGGL(k_combine<32>, dim3(B), dim3(256), lds, st, nch, W, Phi, G, m, S_state, F_state); break;
+    }
     return check_launch("gf_chunk_combine");
 }
 
@@ -5281,23 +5289,29 @@ int gf_chunk_combine_tree(int B, int P, int W, double *Phi, double *G, double *m
     if (!Phi || !G || !m || !S || !F || !Xst || !Yst) return set_err("gf_chunk_combine_tree: null pointer%s", "");
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = cb_lds_bytes(W);
-    const void *fn[4] = {(const void *)k_tree_compose<true>, (const void *)k_tree_apply<true>,
-                         (const void *)k_tree_compose<false>, (const void *)k_tree_apply<false>};
-    if (!lds_opt_in(1, st, fn, 4, cb_lds_bytes(64))) return set_err("gf_chunk_combine_tree: cannot opt in to %s%lld bytes of LDS", "", (long long)lds);
+    const void *fn[6] = {(const void *)k_tree_compose<64>, (const void *)k_tree_apply<64>,
+                         (const void *)k_tree_compose<48>, (const void *)k_tree_apply<48>,
+                         (const void *)k_tree_compose<32>, (const void *)k_tree_apply<32>};
+    if (!lds_opt_in(1, st, fn, 6, cb_lds_bytes(64))) return set_err("gf_chunk_combine_tree: cannot opt in to %s%lld bytes of LDS", "", (long long)lds);
     TreeArgs A;
     A.P = P; A.n = W; A.Phi = Phi; A.G = G; A.S = S; A.F = F; A.m = m; A.Xst = Xst; A.Yst = Yst;
+    const int ns = cb_ns(W);
     // up-sweep.  Its top level would compose the whole range into the last slot -- a map the down-sweep never
     // applies (it uses LEFT children only): left out, one level's latency less
     for (int d = 1; d < P / 2; d *= 2) {
         A.d = d;
-        if (W > 48) hipLaunchKernelGGL(k_tree_compose<true>, dim3(B * (P / (2 * d))), dim3(256), lds, st, A);
-        else hipLaunchKernelGGL(k_tree_compose<false>, dim3(B * (P / (2 * d))), dim3(256), lds, st, A);
+        const dim3 grid(B * (P / (2 * d)));
+        if (ns == 64) hipLaunchKernelGGL(k_tree_compose<64>, grid, dim3(256), lds, st, A);
+        else if (ns == 48) hipLaunchKernelGGL(k_tree_compose<48>, grid, dim3(256), lds, st, A);
+        else hipLaunchKernelGGL(k_tree_compose<32>, grid, dim3(256), lds, st, A);
     }
     hipLaunchKernelGGL(k_tree_top, dim3(B), dim3(256), 0, st, P, S, F, Xst, Yst);   // root state = zero, first level
     for (int d = P / 4; d >= 1; d /= 2) {   // down-sweep
         A.d = d;
-        if (W > 48) hipLaunchKernelGGL(k_tree_apply<true>, dim3(B * (P / (2 * d))), dim3(256), lds, st, A);
-        else hipLaunchKernelGGL(k_tree_apply<false>, dim3(B * (P / (2 * d))), dim3(256), lds, st, A);
+        const dim3 grid(B * (P / (2 * d)));
+        if (ns == 64) hipLaunchKernelGGL(k_tree_apply<64>, grid, dim3(256), lds, st, A);
+        else if (ns == 48) hipLaunchKernelGGL(k_tree_apply<48>, grid, dim3(256), lds, st, A);
+        else hipLaunchKernelGGL(k_tree_apply<32>, grid, dim3(256), lds, st, A);
     }
     return check_launch("gf_chunk_combine_tree");
 }
