@@ -1163,7 +1163,7 @@ class StreamingBatch:
         return out
 
     # -- exact time-parallel evaluation (few problems, long series) ------------------------
-    #: two-sweep evaluations of at most this many rows in all (B N) run on ~1024 chunks instead of ~2048
+    #: two-sweep evaluations of at most this many rows in all (B N), at widths beyond 48, run on ~1024 chunks instead of ~2048
     two_sweep_small_rows = 1_500_000
 
     def _tp_chunking(self, chunk_len, store=False):
@@ -1174,11 +1174,13 @@ class StreamingBatch:
             # chunk the extra tree levels cost more than the sweeps save.  (+ 1: the last chunk sits out the nominal
             # pass, the first one the final pass; the two-sweep log-likelihood sweeps all chunks in its nominal pass.)
             # The two-sweep route pays per chunk (tree levels, corrections) what the three-sweep route pays per row
-            # (the final pass): up to 1.5e6 rows in all it is faster on half the chunks, one wave per SIMD --
-            # B = 1, N = 1e6, W = 60: 4.05 ms on 977 chunks, 4.40 on 1954; 16 x 65 000: 3.39 against 3.81; beyond
-            # 2e6 rows the sweeps dominate and 2048 wins again (grid over B, N, W = 20 / 40 / 60: DESIGN.md 6)
+            # (the final pass).  At widths beyond 48 -- whose combine kernels fit one workgroup per CU -- it is
+            # faster on half the chunks, one wave per SIMD, up to 1.5e6 rows in all: B = 1, N = 1e6, W = 60: 3.67 ms
+            # on 977 chunks, 3.89 on 1954; 16 x 65 000: 3.16 against 3.44; beyond 2e6 rows the sweeps dominate and
+            # 2048 wins again.  At widths <= 48 (two or four combine workgroups per CU) 2048 wins throughout
+            # (grid over B, N, W = 20 / 40 / 60: DESIGN.md 6)
             two = self.two_sweep and not store
-            waves = 1024 if (two and B * N <= self.two_sweep_small_rows) else 2048
+            waves = 1024 if (two and self.W > 48 and B * N <= self.two_sweep_small_rows) else 2048
             nch = max(1, waves // B) + (0 if two else 1)
             chunk_len = max(512, -(-N // nch))
         chunk_len = max(block, (int(chunk_len) + 63) // 64 * 64)
