@@ -323,6 +323,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", str(rank))            # (a forced one-rank group started without a launcher)
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(device))
         else:
