@@ -2542,6 +2542,7 @@ k_combine(const int nch, const int n_, const double *__restrict__ Phi_, const do
 // Slots are (problem, index) with P = power-of-two indices per problem; identity maps pad.
 struct TreeArgs {
     int P, d, n;                            // level: pairs (idx - d, idx), idx = (k+1) 2d - 1; n = state width
+    int nch, pairs;                         // real chunks per problem (slots >= nch: padding, never read); pairs launched
     double *Phi, *G, *S, *F, *m;            // maps [B*P][...]
     double *Xst, *Yst;                      // states [B*P][4096] / [64]
 };
@@ -2555,12 +2556,22 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
     double *Au = M0 + NS * LD;              // [NS][LA]  = AL | AR | one vector
     double *M1 = Au + NS * LA;              // [NS][LD]
     double *v1 = M1 + NS * LD;              // [64] x 4 small vectors
-    const int pairs = A.P / (2 * A.d);
+    const int pairs = A.pairs;              // (the pairs whose left range holds a real chunk: the others are not launched)
     const int pr = blockIdx.x / pairs, k = blockIdx.x - pr * pairs;
     const int ir = (k + 1) * 2 * A.d - 1, il = ir - A.d;
     const size_t L = (size_t)pr * A.P + il, Rr = (size_t)pr * A.P + ir;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int n = FULL ? 64 : A.n, nt = FULL ? 4 : ((n + 15) >> 4);
+    if (il + 1 >= A.nch) {
+        // the right range [il + 1, ir] is padding (an identity map, nowhere stored): the composite is the left map
+        for (int e = tid; e < 4096; e += 256) {
+            A.Phi[Rr * 4096 + e] = A.Phi[L * 4096 + e];
+            A.G[Rr * 4096 + e] = A.G[L * 4096 + e];
+            A.S[Rr * 4096 + e] = A.S[L * 4096 + e];
+        }
+        if (tid < 64) { A.F[Rr * 64 + tid] = A.F[L * 64 + tid]; A.m[Rr * 64 + tid] = A.m[L * 64 + tid]; }
+        return;
+    }
     const bool in = NS == 64 || (tid & 63) < NS;    // this thread's slot elements e = tid + 256 q lie in rows < NS
     const bool vin = tid < NS;                      // ... its vector element exists
     double *w = v1, *vv = v1 + 64, *g2v = v1 + 128, *tmpv = v1 + 192;
@@ -2714,12 +2725,18 @@ __global__ void __launch_bounds__(256) k_tree_apply(const TreeArgs A) {
     double *Bs = Au + NS * LA;
     double *Ys = Bs + NS * LD;
     double *vs = Ys + 64;
-    const int pairs = A.P / (2 * A.d);
+    const int pairs = A.pairs;
     const int pr = blockIdx.x / pairs, k = blockIdx.x - pr * pairs;
     const int ir = (k + 1) * 2 * A.d - 1, il = ir - A.d;
     const size_t L = (size_t)pr * A.P + il, Rr = (size_t)pr * A.P + ir;
     const int tid = threadIdx.x;
     double *Xr = A.Xst + Rr * 4096, *Xl = A.Xst + L * 4096;
+    if (il + 1 >= A.nch) {
+        // the right range is padding: nobody reads its states -- the left child inherits the parent's, no solve
+        for (int e = tid; e < 4096; e += 256) Xl[e] = Xr[e];
+        if (tid < 64) A.Yst[L * 64 + tid] = A.Yst[Rr * 64 + tid];
+        return;
+    }
     // s[left] <- s[right] (incoming state) ;  s[right] <- map[left](s[right])
     // (the whole slot is handed to the left child -- its padding too: state slots are not cleared between scans;
     // of the right child's slot the leading NS x NS block is rewritten, the rest holds zeros already)
@@ -5278,13 +5295,15 @@ int gf_chunk_combine(int B, int nch, int W, const double *Phi, const double *G, 
     return check_launch("gf_chunk_combine");
 }
 
-// Tree (log-depth) version of gf_chunk_combine.  Maps live in slots [B][P] with P a power of two
-// >= nch; the caller fills slots c < nch with the chunk maps (Phi, G, m and Xbar/Ybar = the
-// nominal end states) and the rest with identity maps (Phi = I, everything else 0).  On exit
-// Xst/Yst slot c hold the TRUE start state of chunk c.  The map arrays are overwritten.
-int gf_chunk_combine_tree(int B, int P, int W, double *Phi, double *G, double *m, double *S, double *F,
+// Tree (log-depth) version of gf_chunk_combine.  Maps live in slots [B][P] with P the power of two
+// P / 2 < nch <= P; the caller fills slots c < nch with the chunk maps (Phi, G, m and Xbar/Ybar = the
+// nominal end states); the slots beyond stand for identity maps and are neither read nor initialised (a pair
+// whose right range is padding copies its left map, one that is padding altogether is not launched).  On exit
+// Xst/Yst slot c < nch hold the TRUE start state of chunk c.  The map arrays are overwritten.
+int gf_chunk_combine_tree(int B, int P, int nch, int W, double *Phi, double *G, double *m, double *S, double *F,
                           double *Xst, double *Yst, void *stream) {
     if (B < 1 || P < 2 || (P & (P - 1))) return set_err("gf_chunk_combine_tree: P=%s%lld must be a power of two >= 2", "", P);
+    if (nch <= P / 2 || nch > P) return set_err("gf_chunk_combine_tree: nch=%s%lld must lie in (P / 2, P]", "", nch);
     if (W < 1 || W > 64) return set_err("gf_chunk_combine_tree: width %s%lld unsupported (1..64)", "", W);
     if (!Phi || !G || !m || !S || !F || !Xst || !Yst) return set_err("gf_chunk_combine_tree: null pointer%s", "");
     hipStream_t st = (hipStream_t)stream;
@@ -5294,21 +5313,23 @@ int gf_chunk_combine_tree(int B, int P, int W, double *Phi, double *G, double *m
                          (const void *)k_tree_compose<32>, (const void *)k_tree_apply<32>};
     if (!lds_opt_in(1, st, fn, 6, cb_lds_bytes(64))) return set_err("gf_chunk_combine_tree: cannot opt in to %s%lld bytes of LDS", "", (long long)lds);
     TreeArgs A;
-    A.P = P; A.n = W; A.Phi = Phi; A.G = G; A.S = S; A.F = F; A.m = m; A.Xst = Xst; A.Yst = Yst;
+    A.P = P; A.n = W; A.nch = nch; A.Phi = Phi; A.G = G; A.S = S; A.F = F; A.m = m; A.Xst = Xst; A.Yst = Yst;
     const int ns = cb_ns(W);
+    // pairs of a level whose left range [2 d k, 2 d k + d - 1] holds a real chunk; the rest is padding: not launched
+    auto real_pairs = [&](int d) { return (nch + 2 * d - 1) / (2 * d); };
     // up-sweep.  Its top level would compose the whole range into the last slot -- a map the down-sweep never
     // applies (it uses LEFT children only): left out, one level's latency less
     for (int d = 1; d < P / 2; d *= 2) {
-        A.d = d;
-        const dim3 grid(B * (P / (2 * d)));
+        A.d = d; A.pairs = real_pairs(d);
+        const dim3 grid(B * A.pairs);
         if (ns == 64) hipLaunchKernelGGL(k_tree_compose<64>, grid, dim3(256), lds, st, A);
         else if (ns == 48) hipLaunchKernelGGL(k_tree_compose<48>, grid, dim3(256), lds, st, A);
         else hipLaunchKernelGGL(k_tree_compose<32>, grid, dim3(256), lds, st, A);
     }
     hipLaunchKernelGGL(k_tree_top, dim3(B), dim3(256), 0, st, P, S, F, Xst, Yst);   // root state = zero, first level
     for (int d = P / 4; d >= 1; d /= 2) {   // down-sweep
-        A.d = d;
-        const dim3 grid(B * (P / (2 * d)));
+        A.d = d; A.pairs = real_pairs(d);
+        const dim3 grid(B * A.pairs);
         if (ns == 64) hipLaunchKernelGGL(k_tree_apply<64>, grid, dim3(256), lds, st, A);
         else if (ns == 48) hipLaunchKernelGGL(k_tree_apply<48>, grid, dim3(256), lds, st, A);
         else hipLaunchKernelGGL(k_tree_apply<32>, grid, dim3(256), lds, st, A);

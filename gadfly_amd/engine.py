@@ -1368,32 +1368,27 @@ class StreamingBatch:
             big = ("G", "X") if in_place else ("Phi", "G", "S", "X")
             small = ("m", "Y") if in_place else ("m", "F", "Y")
             tr = w["tree"] = dict(
-                P=P, eye=torch.eye(64, **f64).reshape(4096),
+                P=P,
                 **{k: torch.empty((B, P, 4096), **f64) for k in big},
                 **{k: torch.empty((B, P, 64), **f64) for k in small})
         if in_place:
             # the scan works on the chunk maps where they are (it overwrites them: G and m, which the
             # two-sweep corrections read afterwards, go through copies) and its output buffers change places
-            # with the state slots instead of being copied back.  (One problem: its padding slots are identity maps)
-            if nch < P:
-                w["Phi"][nch:] = tr["eye"]
-                for k in ("G", "S", "m", "F"):
-                    w[k][nch:].zero_()
+            # with the state slots instead of being copied back.  (One problem: its padding slots stand for identity
+            # maps; the scan neither reads nor writes them)
             tr["G"].copy_(w["G"].view(B, P, 4096))
             tr["m"].copy_(w["m"].view(B, P, 64))
-            rc = lib.gf_chunk_combine_tree(B, P, self.W, p(w["Phi"]), p(tr["G"]), p(tr["m"]), p(w["S"]),
+            rc = lib.gf_chunk_combine_tree(B, P, nch, self.W, p(w["Phi"]), p(tr["G"]), p(tr["m"]), p(w["S"]),
                                            p(w["F"]), p(tr["X"]), p(tr["Y"]), st)
             _lib.check(rc, "gf_chunk_combine_tree")
             w["S"], tr["X"] = tr["X"].view(B * P, 4096), w["S"].view(B, P, 4096)
             w["F"], tr["Y"] = tr["Y"].view(B * P, 64), w["F"].view(B, P, 64)
             return
+        # (several problems: slot = problem * P + chunk in the scan, problem * nch + chunk in the sweeps -- copies;
+        # the padding slots stay as they are: never read)
         for k, n in (("Phi", 4096), ("G", 4096), ("S", 4096), ("m", 64), ("F", 64)):
             tr[k][:, :nch].copy_(w[k].view(B, nch, n))
-            if k == "Phi":
-                tr[k][:, nch:] = tr["eye"]
-            else:
-                tr[k][:, nch:].zero_()
-        rc = lib.gf_chunk_combine_tree(B, P, self.W, p(tr["Phi"]), p(tr["G"]), p(tr["m"]), p(tr["S"]),
+        rc = lib.gf_chunk_combine_tree(B, P, nch, self.W, p(tr["Phi"]), p(tr["G"]), p(tr["m"]), p(tr["S"]),
                                        p(tr["F"]), p(tr["X"]), p(tr["Y"]), st)
         _lib.check(rc, "gf_chunk_combine_tree")
         w["S"].view(B, nch, 4096).copy_(tr["X"][:, :nch])

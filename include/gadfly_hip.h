@@ -191,12 +191,12 @@ int gf_loglike_fused(int B, int64_t N, int64_t n_first, int Jr, int Jc, int bloc
  *                          the combine zeros for the first chunk's Phi, G, m.
  *   3. gf_chunk_combine    sequential LFT combine over the chunks (64x64 pivoted solves in LDS):
  *                          S_state/F_state slot c <- TRUE start state of chunk c.
- *      gf_chunk_combine_tree  the same result in 2 log2(P) levels (Blelloch scan over the chunk
- *                          maps): maps in slots [B][P], P a power of two >= nch,
- *                          slots c < nch = (Phi, G, m, S = nominal end X, F = nominal end Y) of
- *                          chunk c, the rest identity maps (Phi = I, others 0).  The map arrays
- *                          are overwritten; Xst [B*P][64*64] / Yst [B*P][64] slot c <- TRUE start
- *                          state of chunk c.
+ *      gf_chunk_combine_tree  the same result in 2 (log2(P) - 1) levels (Blelloch scan over the chunk
+ *                          maps): maps in slots [B][P], P the power of two with
+ *                          P / 2 < nch <= P, slots c < nch = (Phi, G, m, S = nominal end X, F = nominal
+ *                          end Y) of chunk c; the slots beyond stand for identity maps and are neither
+ *                          read nor initialised.  The map arrays are overwritten; Xst [B*P][64*64] /
+ *                          Yst [B*P][64] slot c < nch <- TRUE start state of chunk c.
  *   4. gf_chunk_sweep      final pass from those states (r_out = NULL): d, z equal the
  *                          sequential result to rounding; reduce with gf_reduce_tile.  With
  *                          Ut_out, Wt_out [B][N][64] and de_out [B][N] the pass also stores the
@@ -253,7 +253,7 @@ int gf_chunk_transition_wide(int B, int64_t N, int64_t chunk_len, int nch, int c
  * pivoted solves and matrix products are carried out on the leading W rows and columns only) */
 int gf_chunk_combine(int B, int nch, int W, const double *Phi, const double *G, const double *m,
                      double *S_state, double *F_state, void *stream);
-int gf_chunk_combine_tree(int B, int P, int W, double *Phi, double *G, double *m, double *S, double *F,
+int gf_chunk_combine_tree(int B, int P, int nch, int W, double *Phi, double *G, double *m, double *S, double *F,
                           double *Xst, double *Yst, void *stream);
 
 /*

@@ -2,8 +2,9 @@
 The chunk combines at every width class and slot layout (round 4): the tree scan's kernels come in two LDS sizes
 (48 x 48 matrices for widths <= 48 with two workgroups per CU, 64 x 64 beyond), their products in unrolled forms for
 three and four 16-column tiles and a loop for fewer, ONE problem scans in place on a power-of-two slot set whose
-padding slots are refilled per evaluation, several problems go through padded copies unless their chunk count is a
-power of two, the scan leaves out its top levels, and the sequential combine skips the first chunk's solve.
+padding slots are never initialised (the scan knows the real chunk count: pairs with a padding right range copy,
+pairs of padding are not launched), several problems go through copies unless their chunk count is a power of two,
+the scan leaves out its top levels, and the sequential combine skips the first chunk's solve.
 
 Every case: log-likelihood by the two-sweep and the three-sweep route against the oracle's C restatement at 1e-8, the
 first failing row of a matrix that is not positive definite, and the stored factor's solve at 1e-6.  Widths
@@ -48,7 +49,7 @@ def test_every_width_class_and_slot_layout(hip, J, B, N, L):
     nch = eng._tp_chunking(L)[1]
     for two in (True, False):
         eng.two_sweep = two
-        for _ in range(2):              # (the second evaluation finds the slot sets of the first: padding refilled)
+        for _ in range(2):              # (the second evaluation finds the slot sets the first one left behind)
             ll = eng.log_likelihood_time_parallel(chunk_len=L).cpu().numpy()
             assert eng._tp_used and eng._two_sweep_used == two
             assert np.max(np.abs(ll - refs) / np.abs(refs)) <= RTOL_LL, (two, nch, ll, refs)
