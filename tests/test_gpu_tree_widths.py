@@ -1,6 +1,6 @@
 """
-The chunk combines at every width class and slot layout (round 4): the tree scan's kernels come in two LDS sizes
-(48 x 48 matrices for widths <= 48 with two workgroups per CU, 64 x 64 beyond), their products in unrolled forms for
+The chunk combines at every width class and slot layout (round 4): the combines' kernels come in three LDS sizes
+(32 x 32 matrices for widths <= 32, 48 x 48 up to 48 -- four and two workgroups per CU --, 64 x 64 beyond), their products in unrolled forms for
 three and four 16-column tiles and a loop for fewer, ONE problem scans in place on a power-of-two slot set whose
 padding slots are never initialised (the scan knows the real chunk count: pairs with a padding right range copy,
 pairs of padding are not launched), several problems go through copies unless their chunk count is a power of two,
