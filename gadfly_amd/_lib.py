@@ -78,7 +78,8 @@ SIGNATURES = {
     "gf_chunk_transition": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int, _int] + [_vp] * 9 + [_vp]),
     "gf_chunk_transition_wide": (_int, [_int, _i64, _i64, _int, _int, _int, _int] + [_vp] * 7 + [_vp]),
     "gf_chunk_combine": (_int, [_int, _int, _int] + [_vp] * 5 + [_vp]),
-    "gf_chunk_combine_tree": (_int, [_int, _int, _int, _int] + [_vp] * 7 + [_vp]),
+    "gf_chunk_combine_tree_work": (_i64, [_int, _int, _int]),
+    "gf_chunk_combine_tree": (_int, [_int, _int, _int, _int] + [_vp] * 8 + [_vp]),
     "gf_reduce_work": (_i64, [_i64]),
     "gf_reduce_tile": (_int, [_int, _i64] + [_vp] * 4 + [_int, _vp]),
     "gf_loglike_finish": (_int, [_int, _i64] + [_vp] * 4 + [_vp]),

@@ -2542,10 +2542,26 @@ k_combine(const int nch, const int n_, const double *__restrict__ Phi_, const do
 // Slots are (problem, index) with P = power-of-two indices per problem; identity maps pad.
 struct TreeArgs {
     int P, d, n;                            // level: pairs (idx - d, idx), idx = (k+1) 2d - 1; n = state width
-    int nch, pairs;                         // real chunks per problem (slots >= nch: padding, never read); pairs launched
-    double *Phi, *G, *S, *F, *m;            // maps [B*P][...]
-    double *Xst, *Yst;                      // states [B*P][4096] / [64]
+    int nch, pairs;                         // real chunks per problem; pairs launched per problem at this level
+    double *Phi, *G, *S, *F, *m;            // maps   [B*nch][...]: the slots idx < nch, where the sweeps put them
+    double *Xst, *Yst;                      // states [B*nch][4096] / [64]
+    double *oPhi, *oG, *oS, *oF, *om, *oX, *oY;     // the slots nch <= idx < P (composites that reach into the padding
+                                                    // and their states): [B*(P - nch)][...] in the caller's work buffer
 };
+struct TreeSlot { double *Phi, *G, *S, *F, *m, *X, *Y; };
+__device__ __forceinline__ TreeSlot tree_slot(const TreeArgs &A, const int pr, const int idx) {
+    TreeSlot t;
+    if (idx < A.nch) {
+        const size_t s = (size_t)pr * A.nch + idx;
+        t.Phi = A.Phi + s * 4096; t.G = A.G + s * 4096; t.S = A.S + s * 4096; t.X = A.Xst + s * 4096;
+        t.F = A.F + s * 64; t.m = A.m + s * 64; t.Y = A.Yst + s * 64;
+    } else {
+        const size_t s = (size_t)pr * (A.P - A.nch) + (idx - A.nch);
+        t.Phi = A.oPhi + s * 4096; t.G = A.oG + s * 4096; t.S = A.oS + s * 4096; t.X = A.oX + s * 4096;
+        t.F = A.oF + s * 64; t.m = A.om + s * 64; t.Y = A.oY + s * 64;
+    }
+    return t;
+}
 
 template <int NS>
 __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
@@ -2559,26 +2575,26 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
     const int pairs = A.pairs;              // (the pairs whose left range holds a real chunk: the others are not launched)
     const int pr = blockIdx.x / pairs, k = blockIdx.x - pr * pairs;
     const int ir = (k + 1) * 2 * A.d - 1, il = ir - A.d;
-    const size_t L = (size_t)pr * A.P + il, Rr = (size_t)pr * A.P + ir;
+    const TreeSlot SL = tree_slot(A, pr, il), SR = tree_slot(A, pr, ir);
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int n = FULL ? 64 : A.n, nt = FULL ? 4 : ((n + 15) >> 4);
     if (il + 1 >= A.nch) {
         // the right range [il + 1, ir] is padding (an identity map, nowhere stored): the composite is the left map
         for (int e = tid; e < 4096; e += 256) {
-            A.Phi[Rr * 4096 + e] = A.Phi[L * 4096 + e];
-            A.G[Rr * 4096 + e] = A.G[L * 4096 + e];
-            A.S[Rr * 4096 + e] = A.S[L * 4096 + e];
+            SR.Phi[e] = SL.Phi[e];
+            SR.G[e] = SL.G[e];
+            SR.S[e] = SL.S[e];
         }
-        if (tid < 64) { A.F[Rr * 64 + tid] = A.F[L * 64 + tid]; A.m[Rr * 64 + tid] = A.m[L * 64 + tid]; }
+        if (tid < 64) { SR.F[tid] = SL.F[tid]; SR.m[tid] = SL.m[tid]; }
         return;
     }
     const bool in = NS == 64 || (tid & 63) < NS;    // this thread's slot elements e = tid + 256 q lie in rows < NS
     const bool vin = tid < NS;                      // ... its vector element exists
     double *w = v1, *vv = v1 + 64, *g2v = v1 + 128, *tmpv = v1 + 192;
     // a. M0 = Xbar1, M1 = G2 ;  AL = I - Xbar1 G2 ; AR = I ; the vector column = Ybar1 - Xbar1 m2
-    cb_load<NS>(M0, A.S + L * 4096, tid);
-    cb_load<NS>(M1, A.G + Rr * 4096, tid);
-    if (tid < 64) tmpv[tid] = A.m[Rr * 64 + tid];
+    cb_load<NS>(M0, SL.S, tid);
+    cb_load<NS>(M1, SR.G, tid);
+    if (tid < 64) tmpv[tid] = SR.m[tid];
     __syncthreads();
     {
         double acc[4][4] = {};
@@ -2595,13 +2611,13 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
             }
     }
     if (vin) {
-        double sacc = A.F[L * 64 + tid];
+        double sacc = SL.F[tid];
         for (int kk = 0; kk < n; ++kk) sacc = fma(-M0[tid * LD + kk], tmpv[kk], sacc);
         Au[tid * LA + VC] = sacc;
     }
     __syncthreads();
     cb_gauss_jordan<NS>(Au, M1, tid, n);    // AR = D, the vector column = v   (M1 serves as scratch ...
-    cb_load<NS>(M1, A.G + Rr * 4096, tid);  // ... so G2 is loaded again)
+    cb_load<NS>(M1, SR.G, tid);  // ... so G2 is loaded again)
     if (tid < 64) vv[tid] = vin ? Au[tid * LA + VC] : 0.0;
     __syncthreads();
     if (tid < 64) {                         // g2v = G2 v ;  m12 pieces need it
@@ -2619,7 +2635,7 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
     }
     __syncthreads();
     // d. M0 = Phi2 ;  AL <- Phi2 (D Xbar1) ;  Xbar12 = Xbar2 + AL Phi2^T ;  Ybar12 = Ybar2 + Phi2 v
-    cb_load<NS>(M0, A.Phi + Rr * 4096, tid);
+    cb_load<NS>(M0, SR.Phi, tid);
     __syncthreads();
     {
         double acc[4][4] = {};
@@ -2628,7 +2644,7 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
         cb_store_lds<NS>(Au, LA, acc, tx, ty);
     }
     if (tid < 64) {
-        double sacc = A.F[Rr * 64 + tid];
+        double sacc = SR.F[tid];
         if (vin)
             for (int kk = 0; kk < n; ++kk) sacc = fma(M0[tid * LD + kk], vv[kk], sacc);
         w[tid] = sacc;                      // Ybar12 (stored at the end)
@@ -2642,7 +2658,7 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
     }
     __syncthreads();
     if (in) {
-        double *Sr = A.S + Rr * 4096;
+        double *Sr = SR.S;
 #pragma unroll
         for (int q = 0; q < NS / 4; ++q) {
             const int e = tid + 256 * q, j = e >> 6, i = e & 63;
@@ -2651,7 +2667,7 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
     }
     __syncthreads();
     // e. AL = Phi1 ;  AR <- D Phi1 ;  Phi12 = Phi2 (D Phi1)
-    cb_load<NS>(Au, A.Phi + L * 4096, tid, LA);
+    cb_load<NS>(Au, SL.Phi, tid, LA);
     __syncthreads();
     {
         double acc[4][4] = {};
@@ -2663,7 +2679,7 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
     {
         double acc[4][4] = {};
         cb_matmul<false, false>(acc, M0, LD, Au + NS, LA, tx, ty, nt);
-        double *Pr = A.Phi + Rr * 4096;
+        double *Pr = SR.Phi;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -2685,16 +2701,16 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
         cb_store_lds<NS>(M0, LD, acc, tx, ty);  // Phi2 no longer needed
     }
     if (tid < 64) {
-        double sacc = A.m[L * 64 + tid];
+        double sacc = SL.m[tid];
         if (vin)
             for (int kk = 0; kk < n; ++kk) sacc = fma(Au[kk * LA + tid], tmpv[kk] - g2v[kk], sacc);
-        A.m[Rr * 64 + tid] = sacc;
-        A.F[Rr * 64 + tid] = w[tid];
+        SR.m[tid] = sacc;
+        SR.F[tid] = w[tid];
     }
     __syncthreads();
     if (in) {
-        double *Gr = A.G + Rr * 4096;
-        const double *Gl = A.G + L * 4096;
+        double *Gr = SR.G;
+        const double *Gl = SL.G;
 #pragma unroll
         for (int q = 0; q < NS / 4; ++q) {
             const int e = tid + 256 * q, j = e >> 6, i = e & 63;
@@ -2707,12 +2723,10 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
 // returns its own nominal end state (K = 0, v = 0) -- so  s[left half's last slot] <- 0,
 // s[last slot] <- (Xbar, Ybar) of the left half's composite: a copy instead of the root's memset and one
 // level of k_tree_apply (a level costs one workgroup's latency whatever it holds: 55 us).
-__global__ void __launch_bounds__(256) k_tree_top(const int P, const double *__restrict__ S,
-                                                  const double *__restrict__ F, double *__restrict__ Xst,
-                                                  double *__restrict__ Yst) {
-    const size_t l = (size_t)blockIdx.x * P + P / 2 - 1, r = (size_t)blockIdx.x * P + P - 1;
-    for (int e = threadIdx.x; e < 4096; e += 256) { Xst[l * 4096 + e] = 0.0; Xst[r * 4096 + e] = S[l * 4096 + e]; }
-    if (threadIdx.x < 64) { Yst[l * 64 + threadIdx.x] = 0.0; Yst[r * 64 + threadIdx.x] = F[l * 64 + threadIdx.x]; }
+__global__ void __launch_bounds__(256) k_tree_top(const TreeArgs A) {
+    const TreeSlot l = tree_slot(A, blockIdx.x, A.P / 2 - 1), r = tree_slot(A, blockIdx.x, A.P - 1);
+    for (int e = threadIdx.x; e < 4096; e += 256) { l.X[e] = 0.0; r.X[e] = l.S[e]; }
+    if (threadIdx.x < 64) { l.Y[threadIdx.x] = 0.0; r.Y[threadIdx.x] = l.F[threadIdx.x]; }
 }
 
 template <int NS>
@@ -2728,13 +2742,13 @@ __global__ void __launch_bounds__(256) k_tree_apply(const TreeArgs A) {
     const int pairs = A.pairs;
     const int pr = blockIdx.x / pairs, k = blockIdx.x - pr * pairs;
     const int ir = (k + 1) * 2 * A.d - 1, il = ir - A.d;
-    const size_t L = (size_t)pr * A.P + il, Rr = (size_t)pr * A.P + ir;
+    const TreeSlot SL = tree_slot(A, pr, il), SR = tree_slot(A, pr, ir);
     const int tid = threadIdx.x;
-    double *Xr = A.Xst + Rr * 4096, *Xl = A.Xst + L * 4096;
+    double *Xr = SR.X, *Xl = SL.X;
     if (il + 1 >= A.nch) {
         // the right range is padding: nobody reads its states -- the left child inherits the parent's, no solve
         for (int e = tid; e < 4096; e += 256) Xl[e] = Xr[e];
-        if (tid < 64) A.Yst[L * 64 + tid] = A.Yst[Rr * 64 + tid];
+        if (tid < 64) SL.Y[tid] = SR.Y[tid];
         return;
     }
     // s[left] <- s[right] (incoming state) ;  s[right] <- map[left](s[right])
@@ -2748,16 +2762,16 @@ __global__ void __launch_bounds__(256) k_tree_apply(const TreeArgs A) {
         Xl[e] = v;
         if (NS == 64 || (in && j < NS)) Xs[i * LD + j] = v;
     }
-    if (tid < 64) { const double v = A.Yst[Rr * 64 + tid]; A.Yst[L * 64 + tid] = v; Ys[tid] = v; }
+    if (tid < 64) { const double v = SR.Y[tid]; SL.Y[tid] = v; Ys[tid] = v; }
     __syncthreads();
     const double noreg[16] = {};
-    cb_apply<NS>(Xs, Au, Bs, Ys, vs, A.Phi + L * 4096, A.G + L * 4096, A.m + L * 64,
-                 A.S + L * 4096, A.F + L * 64, noreg, 0.0, tid, FULL ? 64 : A.n);
+    cb_apply<NS>(Xs, Au, Bs, Ys, vs, SL.Phi, SL.G, SL.m,
+                 SL.S, SL.F, noreg, 0.0, tid, FULL ? 64 : A.n);
     if (in) {
 #pragma unroll
         for (int q = 0; q < NS / 4; ++q) { const int e = tid + 256 * q, j = e >> 6, i = e & 63; Xr[e] = Xs[i * LD + j]; }
     }
-    if (tid < 64) A.Yst[Rr * 64 + tid] = Ys[tid];
+    if (tid < 64) SR.Y[tid] = Ys[tid];
 }
 
 // ------------------------------------------------------------------------------------
@@ -5295,17 +5309,24 @@ int gf_chunk_combine(int B, int nch, int W, const double *Phi, const double *G, 
     return check_launch("gf_chunk_combine");
 }
 
-// Tree (log-depth) version of gf_chunk_combine.  Maps live in slots [B][P] with P the power of two
-// P / 2 < nch <= P; the caller fills slots c < nch with the chunk maps (Phi, G, m and Xbar/Ybar = the
-// nominal end states); the slots beyond stand for identity maps and are neither read nor initialised (a pair
-// whose right range is padding copies its left map, one that is padding altogether is not launched).  On exit
-// Xst/Yst slot c < nch hold the TRUE start state of chunk c.  The map arrays are overwritten.
+// Tree (log-depth) version of gf_chunk_combine, on the same arrays [B * nch] (Phi, G, m and S/F = the nominal end
+// states; Xst/Yst [B * nch] receive the TRUE start states).  The scan works on P slots per problem, P the power of
+// two with P / 2 < nch <= P: the slots beyond nch stand for identity maps and are never read (a pair whose right
+// range is padding copies its left map, one that is padding altogether is not launched); what the scan writes at
+// such an index -- composites that reach into the padding, their states -- lives in `work`
+// (gf_chunk_combine_tree_work doubles).  The map arrays are overwritten.
+int64_t gf_chunk_combine_tree_work(int B, int P, int nch) {
+    if (B < 1 || P < 2 || nch < 1 || nch > P) return -1;
+    const int64_t n = (int64_t)B * (P - nch);
+    return n * (4 * 4096 + 3 * 64) + 8;
+}
+
 int gf_chunk_combine_tree(int B, int P, int nch, int W, double *Phi, double *G, double *m, double *S, double *F,
-                          double *Xst, double *Yst, void *stream) {
+                          double *Xst, double *Yst, double *work, void *stream) {
     if (B < 1 || P < 2 || (P & (P - 1))) return set_err("gf_chunk_combine_tree: P=%s%lld must be a power of two >= 2", "", P);
     if (nch <= P / 2 || nch > P) return set_err("gf_chunk_combine_tree: nch=%s%lld must lie in (P / 2, P]", "", nch);
     if (W < 1 || W > 64) return set_err("gf_chunk_combine_tree: width %s%lld unsupported (1..64)", "", W);
-    if (!Phi || !G || !m || !S || !F || !Xst || !Yst) return set_err("gf_chunk_combine_tree: null pointer%s", "");
+    if (!Phi || !G || !m || !S || !F || !Xst || !Yst || !work) return set_err("gf_chunk_combine_tree: null pointer%s", "");
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = cb_lds_bytes(W);
     const void *fn[6] = {(const void *)k_tree_compose<64>, (const void *)k_tree_apply<64>,
@@ -5314,6 +5335,11 @@ int gf_chunk_combine_tree(int B, int P, int nch, int W, double *Phi, double *G, 
     if (!lds_opt_in(1, st, fn, 6, cb_lds_bytes(64))) return set_err("gf_chunk_combine_tree: cannot opt in to %s%lld bytes of LDS", "", (long long)lds);
     TreeArgs A;
     A.P = P; A.n = W; A.nch = nch; A.Phi = Phi; A.G = G; A.S = S; A.F = F; A.m = m; A.Xst = Xst; A.Yst = Yst;
+    {
+        const size_t no = (size_t)B * (P - nch);
+        A.oPhi = work; A.oG = A.oPhi + no * 4096; A.oS = A.oG + no * 4096; A.oX = A.oS + no * 4096;
+        A.oF = A.oX + no * 4096; A.om = A.oF + no * 64; A.oY = A.om + no * 64;
+    }
     const int ns = cb_ns(W);
     // pairs of a level whose left range [2 d k, 2 d k + d - 1] holds a real chunk; the rest is padding: not launched
     auto real_pairs = [&](int d) { return (nch + 2 * d - 1) / (2 * d); };
@@ -5326,7 +5352,8 @@ int gf_chunk_combine_tree(int B, int P, int nch, int W, double *Phi, double *G, 
         else if (ns == 48) hipLaunchKernelGGL(k_tree_compose<48>, grid, dim3(256), lds, st, A);
         else hipLaunchKernelGGL(k_tree_compose<32>, grid, dim3(256), lds, st, A);
     }
-    hipLaunchKernelGGL(k_tree_top, dim3(B), dim3(256), 0, st, P, S, F, Xst, Yst);   // root state = zero, first level
+    A.d = P / 2; A.pairs = 1;
+    hipLaunchKernelGGL(k_tree_top, dim3(B), dim3(256), 0, st, A);                    // root state = zero, first level
     for (int d = P / 4; d >= 1; d /= 2) {   // down-sweep
         A.d = d; A.pairs = real_pairs(d);
         const dim3 grid(B * A.pairs);

@@ -1210,12 +1210,7 @@ class StreamingBatch:
             return x
 
         if getattr(self, "_tp_key", None) != key:
-            # chunk maps and states: one slot per (problem, chunk).  ONE problem on enough chunks for the tree
-            # combine gets the power-of-two slot count the scan works on (slot = chunk there: the scan runs in
-            # place, the padding slots are refilled per evaluation -- no copies into and out of a padded set)
-            ns = B * nch
-            if B == 1 and nch >= self.tree_min_chunks:
-                ns = 1 << (nch - 1).bit_length()
+            ns = B * nch                    # chunk maps and states: one slot per (problem, chunk)
             self._tp = dict(
                 S=torch.empty((ns, 4096), **f64), F=torch.empty((ns, 64), **f64),
                 Phi=torch.empty((ns, 4096), **f64), G=torch.empty((ns, 4096), **f64),
@@ -1346,7 +1341,7 @@ class StreamingBatch:
 
     def _clear_slots(self, x, nch, *slots):
         """Zero the chunk slots `slots` of every problem in x ([B * nch, n]): one strided fill kernel each."""
-        v = x[:self.B * nch].view(self.B, nch, -1)      # (B = 1: x may carry the tree's padding slots behind)
+        v = x.view(self.B, nch, -1)
         for s in slots:
             v[:, s].zero_()
 
@@ -1360,39 +1355,25 @@ class StreamingBatch:
                                       p(w["F"]), st)
             _lib.check(rc, "gf_chunk_combine")
             return
+        # The scan runs on the chunk maps where the sweeps put them (slot = problem * nch + chunk) and overwrites
+        # them: G and m, which the two-sweep corrections read afterwards, go through copies; its output buffers
+        # change places with the state slots instead of being copied back.  Its own slots beyond nch (P per problem,
+        # the power of two at or above nch) live in a work buffer.
         P = 1 << (nch - 1).bit_length()
-        in_place = nch == P or (B == 1 and w["S"].shape[0] == P)
         tr = w.get("tree")
-        if tr is None or tr["P"] != P:
+        if tr is None or tr["key"] != (P, nch):
             f64 = dict(dtype=torch.float64, device=self.device)
-            big = ("G", "X") if in_place else ("Phi", "G", "S", "X")
-            small = ("m", "Y") if in_place else ("m", "F", "Y")
             tr = w["tree"] = dict(
-                P=P,
-                **{k: torch.empty((B, P, 4096), **f64) for k in big},
-                **{k: torch.empty((B, P, 64), **f64) for k in small})
-        if in_place:
-            # the scan works on the chunk maps where they are (it overwrites them: G and m, which the
-            # two-sweep corrections read afterwards, go through copies) and its output buffers change places
-            # with the state slots instead of being copied back.  (One problem: its padding slots stand for identity
-            # maps; the scan neither reads nor writes them)
-            tr["G"].copy_(w["G"].view(B, P, 4096))
-            tr["m"].copy_(w["m"].view(B, P, 64))
-            rc = lib.gf_chunk_combine_tree(B, P, nch, self.W, p(w["Phi"]), p(tr["G"]), p(tr["m"]), p(w["S"]),
-                                           p(w["F"]), p(tr["X"]), p(tr["Y"]), st)
-            _lib.check(rc, "gf_chunk_combine_tree")
-            w["S"], tr["X"] = tr["X"].view(B * P, 4096), w["S"].view(B, P, 4096)
-            w["F"], tr["Y"] = tr["Y"].view(B * P, 64), w["F"].view(B, P, 64)
-            return
-        # (several problems: slot = problem * P + chunk in the scan, problem * nch + chunk in the sweeps -- copies;
-        # the padding slots stay as they are: never read)
-        for k, n in (("Phi", 4096), ("G", 4096), ("S", 4096), ("m", 64), ("F", 64)):
-            tr[k][:, :nch].copy_(w[k].view(B, nch, n))
-        rc = lib.gf_chunk_combine_tree(B, P, nch, self.W, p(tr["Phi"]), p(tr["G"]), p(tr["m"]), p(tr["S"]),
-                                       p(tr["F"]), p(tr["X"]), p(tr["Y"]), st)
+                key=(P, nch), G=torch.empty((B * nch, 4096), **f64), X=torch.empty((B * nch, 4096), **f64),
+                m=torch.empty((B * nch, 64), **f64), Y=torch.empty((B * nch, 64), **f64),
+                work=torch.empty((int(lib.gf_chunk_combine_tree_work(B, P, nch)),), **f64))
+        tr["G"].copy_(w["G"])
+        tr["m"].copy_(w["m"])
+        rc = lib.gf_chunk_combine_tree(B, P, nch, self.W, p(w["Phi"]), p(tr["G"]), p(tr["m"]), p(w["S"]),
+                                       p(w["F"]), p(tr["X"]), p(tr["Y"]), p(tr["work"]), st)
         _lib.check(rc, "gf_chunk_combine_tree")
-        w["S"].view(B, nch, 4096).copy_(tr["X"][:, :nch])
-        w["F"].view(B, nch, 64).copy_(tr["Y"][:, :nch])
+        w["S"], tr["X"] = tr["X"], w["S"]
+        w["F"], tr["Y"] = tr["Y"], w["F"]
 
     # -- exact time-parallel evaluation of FEW series with a wide kernel -----------------------------
     #: shortest series for which the wide time-parallel run replaces the sequential sweep

@@ -1,10 +1,10 @@
 """
 The chunk combines at every width class and slot layout (round 4): the combines' kernels come in three LDS sizes
 (32 x 32 matrices for widths <= 32, 48 x 48 up to 48 -- four and two workgroups per CU --, 64 x 64 beyond), their products in unrolled forms for
-three and four 16-column tiles and a loop for fewer, ONE problem scans in place on a power-of-two slot set whose
-padding slots are never initialised (the scan knows the real chunk count: pairs with a padding right range copy,
-pairs of padding are not launched), several problems go through copies unless their chunk count is a power of two,
-the scan leaves out its top levels, and the sequential combine skips the first chunk's solve.
+three and four 16-column tiles and a loop for fewer, the scan runs on the sweeps' own slot arrays whatever the
+chunk count (it knows the real one: pairs with a padding right range copy, pairs of padding are not launched, its
+slots beyond the real chunks live in a work buffer), it leaves out its top levels, and the sequential combine skips
+the first chunk's solve.
 
 Every case: log-likelihood by the two-sweep and the three-sweep route against the oracle's C restatement at 1e-8, the
 first failing row of a matrix that is not positive definite, and the stored factor's solve at 1e-6.  Widths
@@ -53,9 +53,9 @@ def test_every_width_class_and_slot_layout(hip, J, B, N, L):
             ll = eng.log_likelihood_time_parallel(chunk_len=L).cpu().numpy()
             assert eng._tp_used and eng._two_sweep_used == two
             assert np.max(np.abs(ll - refs) / np.abs(refs)) <= RTOL_LL, (two, nch, ll, refs)
-    # one problem on enough chunks for the tree: the scan ran in place on a power-of-two slot set
-    if B == 1 and nch >= eng.tree_min_chunks:
-        assert eng._tp["S"].shape[0] == 1 << (nch - 1).bit_length()
+    # enough chunks for the tree: the scan ran on the sweeps' own slot arrays (no padded copies)
+    if nch >= eng.tree_min_chunks:
+        assert eng._tp["S"].shape[0] == B * nch and eng._tp["tree"]["X"].shape[0] == B * nch
     # the stored factor (three sweeps with stores) and one solve
     from oracle import cref, seq
     fac = eng.stored_factor(chunk_len=L)
