@@ -2252,12 +2252,12 @@ k_phi(const int64_t N, const int64_t chunk_len, const int nch, const int ch0, co
     phi_gram_store<NT>(acc, macc, G_out + (size_t)b * (64 * 64), m_out + (size_t)b * 64, lane, lane);
 }
 
-// ---- dense 64x64 helpers for the chunk combines (one workgroup of 256 threads) ---------------
-// LDS matrices are row-major with leading dimension CB_LD (conflict-free rows); global
-// matrices are stored [j][i] (column-major = the lane-major layout of the sweep states).
-// NS = 64, or 48 for the widths <= 48 (every LDS matrix then has 48 rows and columns: 77 KB per workgroup
-// instead of 135 KB, TWO workgroups per CU -- the levels of the tree scan with more pairs than CUs run two rounds
-// instead of four; the slots in global memory stay 64 x 64, zero beyond the width).
+// ---- dense helpers for the chunk combines (one workgroup of 256 threads) ---------------------
+// LDS matrices are NS x NS, row-major with the odd leading dimension NS + 1 (conflict-free rows); global
+// matrices are 64 x 64 slots stored [j][i] (column-major = the lane-major layout of the sweep states), zero
+// beyond the width.  NS = 64, 48 for the widths <= 48, 32 for those <= 32: 135 / 77 / 36 KB of LDS per workgroup,
+// one / two / four workgroups per CU -- the levels of the tree scan with more pairs than CUs run in half / a
+// quarter of the rounds.
 template <int NS> struct CbDims {
     static constexpr int LD = NS + 1;           // a matrix' row stride
     static constexpr int LA = 2 * NS + 2;       // the augmented system's: [A | RHS | one vector]
@@ -2265,7 +2265,6 @@ template <int NS> struct CbDims {
     static constexpr int NC = NS / 2 + 1;       // Gauss-Jordan: registers per lane (columns c = 4 lc + wave <= VC)
     static constexpr int R0 = NS / 4;           // ... the first one of the right-hand sides
 };
-constexpr int CB_LD = CbDims<64>::LD, CB_LA = CbDims<64>::LA;
 
 template <int NS = 64>
 __device__ __forceinline__ void cb_load(double *dst, const double *__restrict__ src, int tid,
