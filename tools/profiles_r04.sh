@@ -1,10 +1,10 @@
 # end-of-round profile set of round 4 (run from the repo root on the GPU box through gpurun):
-#   bash tools/profiles_r04.sh [bench|cfg3|cfg4s|cfg5|solar|tools ...]      (no argument: everything)
+#   bash tools/profiles_r04.sh [bench|cfg2|cfg3|cfg3s|cfg4|cfg4s|cfg5|solar|tools ...]      (no argument: everything)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r04
 mkdir -p $O
-WHAT="$*"; [ -z "$WHAT" ] && WHAT="bench cfg3 cfg3s cfg4 cfg4s cfg5 solar tools"
+WHAT="$*"; [ -z "$WHAT" ] && WHAT="bench cfg2 cfg3 cfg3s cfg4 cfg4s cfg5 solar tools"
 prof() {  # name script args... -> $O/r04_NAME_kernel_stats.csv
   local name=$1; shift; local script=$R/$1; shift
   rm -rf $O/prof_$name
@@ -35,6 +35,12 @@ bench)
   python3 $R/tools/pmc_traffic.py $f $g k_factor7 8192 2048 60 $O/r04_traffic.json
   rm -f $O/r04_sq_k_factor7.txt
   sq $O/r04_sq_k_factor7.txt k_factor7 $((8192*2048)) $BA
+  ;;
+cfg2)
+  echo "== cfg2: the drop-in class and one chain through the batched evaluator"
+  prof cfg2_compute tools/cfg2_once.py compute
+  prof cfg2_predict tools/cfg2_once.py predict
+  prof b1_evaluator tools/b1_loop.py
   ;;
 cfg3)
   echo "== cfg3"; prof cfg3 tools/configs.py cfg3
