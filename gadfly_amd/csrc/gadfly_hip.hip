@@ -2795,7 +2795,13 @@ struct LinArgs {
     int R;
 };
 
-constexpr int LIN1_AHEAD = 8;
+// Rows in flight per lane.  The sweep itself is a DPP reduction and two FMAs per row (~400 cycles): what it waits
+// for is memory.  u~ / w~ of a row are one double per lane each: a register ring LIN1_RING rows deep, every slot
+// refilled with the row LIN1_RING ahead as soon as its row is used (static indices: the row loop is unrolled over the
+// ring).  The per-row scalars y, de, d are wave-uniform: fetched 64 rows at a time, lane j its row, one block ahead,
+// parked in LDS and read back as broadcasts a row before their use.  (Two batches of eight rows with five registers
+// per row and lane -- 241 VGPRs -- left every eighth row waiting on HBM: 0.18 of a pass' 0.45 ms at N = 1e6.)
+constexpr int LIN1_RING = 24;
 __global__ void __launch_bounds__(64) k_lin1(const LinArgs A) {
     const int lane = threadIdx.x, b = blockIdx.x;
     const int pr = b / A.nch, ch = b - pr * A.nch;
@@ -2812,78 +2818,75 @@ __global__ void __launch_bounds__(64) k_lin1(const LinArgs A) {
     const double cj = (lane < A.W) ? A.c[(size_t)pr * A.W + lane] : 0.0;
     const bool up = A.mode == GF_SOLVE_UPPER, mm = A.mode == GF_MATMUL_LOWER;
     double F = A.store ? Fg[lane] : 0.0;            // (the local pass starts from zero)
-    // Rows are fetched LIN1_AHEAD rows ahead of their use, LIN1_AHEAD at a time (the loads used to sit at
-    // their point of use: one memory round trip per row, 1.1 us -- the sweep itself is a DPP reduction and
-    // two FMAs per row).
-    constexpr int G = LIN1_AHEAD;
-    struct RowIn { double y, u, w, e, d; };
-    RowIn cur[G], nxt[G];
-    auto fetch = [&](RowIn (&q)[G], const int64_t s0) {
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-            int64_t s = s0 + j;
-            if (s > rows - 1) s = rows - 1;
-            const int64_t n = up ? (rows - 1 - s) : s;
-            q[j].y = Yg[n];
-            q[j].u = Ug[(size_t)n * 64];
-            q[j].w = Wg[(size_t)n * 64];
-            q[j].e = eg[n];
-            q[j].d = A.scale ? dg[n] : 1.0;
-        }
+    constexpr int D = LIN1_RING;
+    // step s of the sweep works on row n(s): ascending, or descending for the upper solve (clamped: reads past
+    // the chunk's last step fetch its last row again and are never used)
+    auto row_of = [&](int64_t s) { s = (s > rows - 1) ? rows - 1 : s; return up ? (rows - 1 - s) : s; };
+    __shared__ double sc[2][3][64];                 // y, de, d of 64 steps, two blocks
+    double ys, es, dv;                              // the block after those: this lane's step
+    auto load_sc = [&](const int64_t blk) {
+        const int64_t n = row_of(64 * blk + lane);
+        ys = Yg[n]; es = eg[n]; dv = A.scale ? dg[n] : 1.0;
     };
-    fetch(nxt, 0);
-    if (!up) {
-        double carry = 0.0, wprev = 0.0;            // pending F += w~_{n-1} * carry
-        for (int64_t s0 = 0; s0 < rows; s0 += G) {
+    auto put_sc = [&](const int buf) { sc[buf][0][lane] = ys; sc[buf][1][lane] = es; sc[buf][2][lane] = dv; };
+    load_sc(0);
+    double qu[D], qw[D];
 #pragma unroll
-            for (int j = 0; j < G; ++j) cur[j] = nxt[j];
-            fetch(nxt, s0 + G);
+    for (int j = 0; j < D; ++j) { const int64_t n = row_of(j); qu[j] = Ug[(size_t)n * 64]; qw[j] = Wg[(size_t)n * 64]; }
+    put_sc(0);
+    load_sc(1);
+    wave_lds_fence();
+    double y_n = sc[0][0][0], e_n = sc[0][1][0], d_n = sc[0][2][0];       // step 0's scalars
+    double carry = 0.0, prev = 0.0, de_up = -1.0;   // pending F += prev * carry (w~_{n-1} z_{n-1}, or u~_{n+1} z_{n+1})
+    for (int64_t s0 = 0; s0 < rows; s0 += D) {
 #pragma unroll
-            for (int j = 0; j < G; ++j) {
-                const int64_t n = s0 + j;
-                if (n < rows) {
-                    double yn = cur[j].y;
-                    if (A.scale) yn = mm ? yn * sqrt(cur[j].d) : yn / cur[j].d;
-                    const double de = cur[j].e;
-                    F = fma(wprev, carry, F);
+        for (int j = 0; j < D; ++j) {
+            const int64_t s = s0 + j;
+            if (s < rows) {                         // (wave-uniform)
+                const int64_t n = up ? (rows - 1 - s) : s;
+                const double u = qu[j], w = qw[j];
+                double yn = y_n;
+                const double de = e_n, dd = d_n;
+                // the next step's scalars (a block boundary first hands the parked block over)
+                const int li = (int)(s & 63);
+                if (li == 63) { put_sc((int)(((s >> 6) + 1) & 1)); load_sc((s >> 6) + 2); wave_lds_fence(); }
+                {
+                    const int64_t s1 = s + 1;
+                    const int b1 = (int)((s1 >> 6) & 1), l1 = (int)(s1 & 63);
+                    y_n = sc[b1][0][l1]; e_n = sc[b1][1][l1]; d_n = sc[b1][2][l1];
+                }
+                if (!up) {
+                    if (A.scale) yn = mm ? yn * sqrt(dd) : yn / dd;
+                    F = fma(prev, carry, F);
                     if (de >= 0.0) F *= fm_exp(-cj * de);
-                    const double dot = wave_sum(cur[j].u * F);
+                    const double dot = wave_sum(u * F);
                     const double zn = mm ? (yn + dot) : (yn - dot);
                     if (A.store && lane == 0) Zg[n] = zn;
                     carry = mm ? yn : zn;
-                    wprev = cur[j].w;
-                }
-            }
-        }
-        Fg[lane] = fma(wprev, carry, F);            // pending folded, decay left to the next chunk
-    } else {
-        // the state handed DOWN to this chunk already carries the decay of the boundary it crossed
-        double carry = 0.0, uprev = 0.0, de_up = -1.0;      // row n+1's quantities
-        for (int64_t s0 = 0; s0 < rows; s0 += G) {
-#pragma unroll
-            for (int j = 0; j < G; ++j) cur[j] = nxt[j];
-            fetch(nxt, s0 + G);
-#pragma unroll
-            for (int j = 0; j < G; ++j) {
-                const int64_t n = rows - 1 - (s0 + j);
-                if (n >= 0) {
-                    double yn = cur[j].y;
-                    if (A.scale) yn = yn / cur[j].d;
-                    F = fma(uprev, carry, F);
+                    prev = w;
+                } else {
+                    // the state handed DOWN to this chunk already carries the decay of the boundary it crossed
+                    if (A.scale) yn = yn / dd;
+                    F = fma(prev, carry, F);
                     if (de_up >= 0.0) F *= fm_exp(-cj * de_up);
-                    const double dot = wave_sum(cur[j].w * F);
+                    const double dot = wave_sum(w * F);
                     const double zn = yn - dot;
                     if (A.store && lane == 0) Zg[n] = zn;
                     carry = zn;
-                    uprev = cur[j].u;
-                    de_up = cur[j].e;
+                    prev = u;
+                    de_up = de;
                 }
             }
+            {   // the slot's next tenant: the row LIN1_RING steps ahead
+                const int64_t n2 = row_of(s + D);
+                qu[j] = Ug[(size_t)n2 * 64];
+                qw[j] = Wg[(size_t)n2 * 64];
+            }
         }
-        F = fma(uprev, carry, F);
-        if (de_up >= 0.0) F *= fm_exp(-cj * de_up);     // cross the chunk's first-row boundary
-        Fg[lane] = F;
     }
+    F = fma(prev, carry, F);                        // pending folded (lower: decay left to the next chunk)
+    if (up && de_up >= 0.0) F *= fm_exp(-cj * de_up);       // upper: cross the chunk's first-row boundary
+    Fg[lane] = F;
 }
 
 // R right-hand sides: lane r owns column r of Y/Z and F[:, r] (ROWS doubles in VGPRs); the
