@@ -4382,19 +4382,30 @@ __global__ void __launch_bounds__(64) k_gmm_chunk(const GmmArgs A, const GmmChun
 __global__ void __launch_bounds__(256) k_gmm_scan(const int CTW, const GmmChunk C) {
     const int b = blockIdx.x, dir = blockIdx.y;
     const size_t base = ((size_t)b * 2 + dir) * C.nch * CTW;
+    // sixteen chunks' (D, F_loc) are fetched before their sixteen dependent FMAs: one memory round trip per
+    // chunk made the scan 0.28 ms for the 1024 chunks of a 1e6-row series (a tenth of predict at new times)
+    constexpr int GB = 16;
     for (int j = threadIdx.x; j < CTW; j += 256) {
         double F = 0.0;
-        if (dir == 0) {
-            for (int c = 0; c < C.nch; ++c) {
+        for (int s0 = 0; s0 < C.nch; s0 += GB) {
+            double d[GB], f[GB];
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+                int sidx = s0 + k;
+                sidx = (sidx < C.nch) ? sidx : C.nch - 1;
+                const int c = (dir == 0) ? sidx : C.nch - 1 - sidx;
                 const size_t o = base + (size_t)c * CTW + j;
-                C.Fstart[o] = F;
-                F = fma(C.Dloc[o], F, C.Floc[o]);
+                d[k] = C.Dloc[o];
+                f[k] = C.Floc[o];
             }
-        } else {
-            for (int c = C.nch - 1; c >= 0; --c) {
-                const size_t o = base + (size_t)c * CTW + j;
-                C.Fstart[o] = F;
-                F = fma(C.Dloc[o], F, C.Floc[o]);
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+                const int sidx = s0 + k;
+                if (sidx < C.nch) {
+                    const int c = (dir == 0) ? sidx : C.nch - 1 - sidx;
+                    C.Fstart[base + (size_t)c * CTW + j] = F;
+                    F = fma(d[k], F, f[k]);
+                }
             }
         }
     }
