@@ -3344,12 +3344,24 @@ k_lincombine(const int nch, const int seg_len, const int mode, const int R,
     if (PHASE == 2 && w == 0) cur = *Vg;
     if (PHASE == 0 && mm) {                         // diagonal transitions: one wave does it all
         if (w != 0) return;
-        for (int s = 0; s < nch; ++s) {
-            const size_t slot = (size_t)pr * nch + s;
-            double *Fg = F_state + slot * 64 * R + (size_t)i * R + r;
-            const double loc = *Fg;
-            *Fg = cur;
-            cur = fma(Dch_[slot * 64 + i], cur, loc);
+        constexpr int GB = 16;                      // (loads of sixteen chunks ahead of their dependent FMAs)
+        for (int s0 = 0; s0 < nch; s0 += GB) {
+            double loc[GB], dd[GB];
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+                const int s = (s0 + k < nch) ? s0 + k : nch - 1;
+                const size_t slot = (size_t)pr * nch + s;
+                loc[k] = F_state[slot * 64 * R + (size_t)i * R + r];
+                dd[k] = Dch_[slot * 64 + i];
+            }
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+                if (s0 + k < nch) {
+                    const size_t slot = (size_t)pr * nch + s0 + k;
+                    F_state[slot * 64 * R + (size_t)i * R + r] = cur;
+                    cur = fma(dd[k], cur, loc[k]);
+                }
+            }
         }
         return;
     }
