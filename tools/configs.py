@@ -239,13 +239,13 @@ def measure_cfg2_api(jd=False):
     rng = np.random.Generator(np.random.PCG64(12345))
     y = np.cumsum(rng.normal(size=N)) * 5.0 + 30.0 * rng.normal(size=N)
     gp = gadfly_amd.GaussianProcess(k)
-    c_ms, _ = _clock(torch, lambda: gp.compute(t, yerr=30.0), reps=2, warm=1)
-    l_ms, ll = _clock(torch, lambda: gp.log_likelihood(y), reps=3, warm=1)
-    r_ms, _ = _clock(torch, lambda: (gp.recompute(), gp.log_likelihood(y)), reps=3, warm=1)
+    c_ms, _ = _clock(torch, lambda: gp.compute(t, yerr=30.0), reps=7, warm=2)
+    l_ms, ll = _clock(torch, lambda: gp.log_likelihood(y), reps=7, warm=1)
+    r_ms, _ = _clock(torch, lambda: (gp.recompute(), gp.log_likelihood(y)), reps=7, warm=1)
     _ = gp._engine
-    p_ms, mu = _clock(torch, lambda: gp.predict(y), reps=3, warm=1)
+    p_ms, mu = _clock(torch, lambda: gp.predict(y), reps=7, warm=1)
     ts = np.sort(rng.uniform(t[0], t[-1], 1000))
-    q_ms, mus = _clock(torch, lambda: gp.predict(y, t=ts), reps=2, warm=1)
+    q_ms, mus = _clock(torch, lambda: gp.predict(y, t=ts), reps=5, warm=1)
     W = 2 * J
     gb_ll = 8.0 * N * (3 * W + 4) / 1e9
     gb_ai = 8.0 * N * (4 * W + 7) / 1e9
