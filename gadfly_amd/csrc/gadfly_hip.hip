@@ -4428,10 +4428,29 @@ __global__ void __launch_bounds__(256) k_gmm_scan(const int CTW, const GmmChunk 
 // [B][N][R] layout the multi-RHS sweeps take (conditional variance / covariance:
 // celerite2's ConditionalDistribution builds the same dense block on the host).
 //   K = sum_r a_r e^{-c_r tau} + sum_c (a_c cos d_c tau + b_c sin d_c tau) e^{-c_c tau},
-//   tau = |t_n - t*_r|.  One thread per (n, r); coefficients staged in LDS.
+//   tau = |t_n - t*_r|.
+// A term is Re[(a - i b) w(tau)] with w(tau) = e^{(-c + i d) tau}, and w(tau_b + delta) = w(tau_b) w(delta): one
+// workgroup takes 256 rows, whose times span [tmin, tmax].  A query at or beyond tmax has tau = (t* - tmax) +
+// (tmax - t_n), one at or before tmin tau = (tmin - t*) + (t_n - tmin) -- both parts non-negative, both factors
+// decaying.  So per workgroup and term: (a - i b) w(t* - tmax) or w(tmin - t*) for every query (a table in LDS), and
+// per row w(tmax - t_n), w(t_n - tmin); an entry is then TWO FMAs per term instead of a sine, a cosine and an
+// exponential (1.9e9 of each per 64 queries at N = 1e6, J = 30: 5.3 ms, half of predict(return_var=True)).  Queries
+// inside the workgroup's span are evaluated entry by entry, as before (one workgroup per query).  Lane = row, RT
+// accumulators per lane; the row's RT entries leave as one contiguous run.
 // The exposure-integrated kernel differs from its coefficient form for tau < delta; the caller
 // patches those (at most a few per query) entries.
 // ------------------------------------------------------------------------------------
+__device__ __forceinline__ void cross_w(const double cc, const double dd, const double x, double &re, double &im) {
+    const double e = fm_exp(-cc * x);               // x >= 0
+    if (dd == 0.0) { re = e; im = 0.0; return; }    // (real term)
+    double si, cs;
+    const double ph = dd * x;
+    if (fabs(ph) < FM_SINCOS_RANGE) fm_sincos(ph, &si, &cs); else sincos(ph, &si, &cs);
+    re = e * cs;
+    im = e * si;
+}
+
+template <int RT>
 __global__ void __launch_bounds__(256)
 k_cross(const int64_t N, const int R, const int Jr, const int Jc,
         const double *__restrict__ ar_, const double *__restrict__ cr_,
@@ -4439,32 +4458,99 @@ k_cross(const int64_t N, const int R, const int Jr, const int Jc,
         const double *__restrict__ cc_, const double *__restrict__ dc_,
         const double *__restrict__ t_, const int64_t t_bs,
         const double *__restrict__ ts_, const int64_t ts_bs, double *__restrict__ out) {
-    extern __shared__ double lds[];             // [2 Jr + 4 Jc] coefficients, then [R] query times
-    const int b = blockIdx.y;
-    double *co = lds, *tq = lds + 2 * Jr + 4 * Jc;
-    for (int i = threadIdx.x; i < Jr; i += 256) { co[2 * i] = ar_[(size_t)b * Jr + i]; co[2 * i + 1] = cr_[(size_t)b * Jr + i]; }
-    for (int i = threadIdx.x; i < Jc; i += 256) {
-        double *p = co + 2 * Jr + 4 * i;
-        p[0] = ac_[(size_t)b * Jc + i]; p[1] = bc_[(size_t)b * Jc + i];
-        p[2] = cc_[(size_t)b * Jc + i]; p[3] = dc_[(size_t)b * Jc + i];
-    }
-    for (int i = threadIdx.x; i < R; i += 256) tq[i] = ts_[(size_t)b * ts_bs + i];
-    __syncthreads();
-    const int64_t total = N * R;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int64_t n = e / R;
-        const int r = (int)(e - n * R);
-        const double tau = fabs(t_[(size_t)b * t_bs + n] - tq[r]);
-        double k = 0.0;
-        for (int i = 0; i < Jr; ++i) k = fma(co[2 * i], fm_exp(-co[2 * i + 1] * tau), k);
-        for (int i = 0; i < Jc; ++i) {
-            const double *p = co + 2 * Jr + 4 * i;
-            double si, cs;
-            const double x = p[3] * tau;
-            if (fabs(x) < FM_SINCOS_RANGE) fm_sincos(x, &si, &cs); else sincos(x, &si, &cs);
-            k = fma(fma(p[0], cs, p[1] * si), fm_exp(-p[2] * tau), k);
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int J = Jr + Jc, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *co = lds;                               // [J][4]: a, b, c, d (real terms: b = d = 0)
+    double2 *AE = reinterpret_cast<double2 *>(co + 4 * J);      // [RT][J]: (a - i b) w(tau_b), zero for queries inside
+    double *tq = reinterpret_cast<double *>(AE + (size_t)RT * J);  // [RT]
+    __shared__ double s_mm[2][4];
+    __shared__ unsigned long long s_side[3];        // bit r: query at / beyond tmax, at / before tmin, inside
+    for (int i = tid; i < J; i += 256) {
+        double *q = co + 4 * i;
+        if (i < Jr) { q[0] = ar_[(size_t)b * Jr + i]; q[1] = 0.0; q[2] = cr_[(size_t)b * Jr + i]; q[3] = 0.0; }
+        else {
+            const size_t o = (size_t)b * Jc + (i - Jr);
+            q[0] = ac_[o]; q[1] = bc_[o]; q[2] = cc_[o]; q[3] = dc_[o];
         }
-        out[(size_t)b * total + e] = k;
+    }
+    const int64_t n = (int64_t)blockIdx.x * 256 + tid;
+    const bool row = n < N;
+    const double tn = t_[(size_t)b * t_bs + (row ? n : N - 1)];
+    {
+        const double hi = wave_max(tn), lo = -wave_max(-tn);
+        if (lane == 0) { s_mm[0][wave] = hi; s_mm[1][wave] = lo; }
+    }
+    __syncthreads();
+    const double tmax = fmax(fmax(s_mm[0][0], s_mm[0][1]), fmax(s_mm[0][2], s_mm[0][3]));
+    const double tmin = fmin(fmin(s_mm[1][0], s_mm[1][1]), fmin(s_mm[1][2], s_mm[1][3]));
+    const double dL = tmax - tn, dR = tn - tmin;   // >= 0
+    double *og = out + ((size_t)b * N + (row ? n : 0)) * R;
+    for (int r0 = 0; r0 < R; r0 += RT) {
+        const int rt = (R - r0 < RT) ? R - r0 : RT;
+        __syncthreads();
+        if (tid < 64) {
+            const double q = (tid < rt) ? ts_[(size_t)b * ts_bs + r0 + tid] : 0.0;
+            if (tid < RT) tq[tid] = q;
+            const bool L = tid < rt && q >= tmax, Rr = tid < rt && !L && q <= tmin, in = tid < rt && !L && !Rr;
+            const unsigned long long mL = __ballot(L), mR = __ballot(Rr), mI = __ballot(in);
+            if (tid == 0) { s_side[0] = mL; s_side[1] = mR; s_side[2] = mI; }
+        }
+        __syncthreads();
+        const unsigned long long mL = s_side[0], mR = s_side[1], mI = s_side[2];
+        for (int e = tid; e < rt * J; e += 256) {
+            const int r = e / J, i = e - r * J;
+            const double *q = co + 4 * i;
+            double re = 0.0, im = 0.0;
+            if (!((mI >> r) & 1ull)) {
+                const double taub = ((mL >> r) & 1ull) ? tq[r] - tmax : tmin - tq[r];
+                double wr, wi;
+                cross_w(q[2], q[3], taub, wr, wi);
+                re = fma(q[0], wr, q[1] * wi);      // (a - i b)(wr + i wi)
+                im = fma(q[0], wi, -q[1] * wr);
+            }
+            AE[(size_t)r * J + i] = double2{re, im};
+        }
+        __syncthreads();
+        double acc[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r] = 0.0;
+        // (the masks as scalars: the tests below become scalar branches, not exec-mask switches)
+        const unsigned mLlo = __builtin_amdgcn_readfirstlane((unsigned)mL), mLhi = __builtin_amdgcn_readfirstlane((unsigned)(mL >> 32));
+        const unsigned mRlo = __builtin_amdgcn_readfirstlane((unsigned)mR), mRhi = __builtin_amdgcn_readfirstlane((unsigned)(mR >> 32));
+        for (int i = 0; i < J; ++i) {
+            const double *q = co + 4 * i;
+            double lr = 0.0, li = 0.0, rr = 0.0, ri = 0.0;
+            if (mL) cross_w(q[2], q[3], dL, lr, li);            // (workgroup-uniform)
+            if (mR) cross_w(q[2], q[3], dR, rr, ri);
+            const double2 *ae = AE + i;
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const bool isL = ((r < 32 ? mLlo : mLhi) >> (r & 31)) & 1u, isR = ((r < 32 ? mRlo : mRhi) >> (r & 31)) & 1u;
+                if (isL) { const double2 v = ae[(size_t)r * J]; acc[r] = fma(v.x, lr, fma(-v.y, li, acc[r])); }
+                else if (isR) { const double2 v = ae[(size_t)r * J]; acc[r] = fma(v.x, rr, fma(-v.y, ri, acc[r])); }
+            }
+        }
+        if (mI) {                                   // queries inside this workgroup's span: entry by entry
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                if ((mI >> r) & 1ull) {
+                    const double tau = fabs(tn - tq[r]);
+                    double k = 0.0;
+                    for (int i = 0; i < J; ++i) {
+                        const double *q = co + 4 * i;
+                        double wr, wi;
+                        cross_w(q[2], q[3], tau, wr, wi);
+                        k = fma(q[0], wr, fma(q[1], wi, k));
+                    }
+                    acc[r] = k;
+                }
+            }
+        }
+        if (row) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+                if (r < rt) og[r0 + r] = acc[r];
+        }
     }
 }
 
@@ -5688,11 +5774,17 @@ int gf_cross_covariance(int B, int64_t N, int R, int Jr, int Jc,
     if (Jr < 0 || Jc < 0 || Jr + Jc < 1 || Jr + 2 * Jc > GF_MAX_WIDTH) return set_err("gf_cross_covariance: bad term counts%s", "");
     if (!t || !ts || !out || (Jr && (!ar || !cr)) || (Jc && (!ac || !bc || !cc || !dc)))
         return set_err("gf_cross_covariance: null pointer%s", "");
-    const size_t lds = sizeof(double) * (size_t)(2 * Jr + 4 * Jc + R);
-    int64_t blocks = (N * R + 255) / 256;
-    if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(k_cross, dim3((unsigned)blocks, B), dim3(256), lds, (hipStream_t)stream, N, R, Jr, Jc,
-                       ar, cr, ac, bc, cc, dc, t, t_bs, ts, ts_bs, out);
+    // queries per pass (accumulators per lane) so that the table of (term, query) factors fits 48 KB of LDS
+    const int J = Jr + Jc;
+    const int RT = (J <= 44) ? 64 : (J <= 92) ? 32 : 16;
+    const size_t lds = sizeof(double) * ((size_t)4 * J + (size_t)2 * RT * J + RT);
+    const int64_t blocks = (N + 255) / 256;
+    if (blocks > 0x7fffffffLL) return set_err("gf_cross_covariance: problem too large%s", "");
+    const dim3 grid((unsigned)blocks, B);
+    hipStream_t st = (hipStream_t)stream;
+#define GF_CX(RTv) hipLaunchKernelGGL((k_cross<RTv>), grid, dim3(256), lds, st, N, R, Jr, Jc, ar, cr, ac, bc, cc, dc, t, t_bs, ts, ts_bs, out)
+    if (RT == 64) GF_CX(64); else if (RT == 32) GF_CX(32); else GF_CX(16);
+#undef GF_CX
     return check_launch("gf_cross_covariance");
 }
 
