@@ -3402,6 +3402,97 @@ k_lincombine(const int nch, const int seg_len, const int mode, const int R,
     if (PHASE == 1 && w == 0) *Vg = cur;            // the segment's end state from a zero start
 }
 
+// The segment scans (PHASE 1 / 2 of k_lincombine) for MANY right-hand sides: 64 at a time, the chunk step
+// S <- Fbar_c + Phi_c S (Phi_c^T for the backward solve) as one 64 x 64 x 64 product on the matrix pipe.  One
+// workgroup per (problem, segment, 64 right-hand sides): the state S [j][r] sits in LDS as the B operand, Phi_c is
+// the A operand straight from global -- lane (i, k) of wave w supplies Phi(16 w + i, 4 ks + k) -- fetched one chunk
+// ahead together with the chunk's local end state (in accumulator layout: the MFMAs start from it).  One workgroup
+// per right-hand side re-read every Phi_c 64 times and took 0.38 ms per phase for 64 right-hand sides at 1954
+// chunks (a quarter of predict(return_var=True)); this one streams them once.
+template <int PHASE>
+__global__ void __launch_bounds__(256)
+k_lincombine_R(const int nch, const int seg_len, const int mode, const int R,
+               const double *__restrict__ Phi_, double *__restrict__ F_state, double *__restrict__ Vseg) {
+    constexpr int LDB = 80;                         // (rows k, k + 1 of the B operand 32 banks apart)
+    __shared__ __attribute__((aligned(16))) double Sb[64 * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, k = lane >> 4;
+    const bool up = mode == GF_SOLVE_UPPER;
+    const int nseg = (nch + seg_len - 1) / seg_len;
+    const int pr = blockIdx.x / nseg, sg = blockIdx.x - pr * nseg;
+    const int r0 = 64 * blockIdx.y;
+    const int c_lo = sg * seg_len, c_hi = (c_lo + seg_len < nch) ? c_lo + seg_len : nch, len = c_hi - c_lo;
+    auto chunk_of = [&](int sidx) { return up ? (c_hi - 1 - sidx) : (c_lo + sidx); };
+    // a 64 x 64 block of a state array [64][R] in accumulator layout: x[q][rr] = (row 16 w + k + 4 rr, column r0 + 16 q + i)
+    auto ld_state = [&](const double *base, d4 (&x)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int col = r0 + 16 * q + i;
+                x[q][rr] = (col < R) ? base[(size_t)(16 * w + k + 4 * rr) * R + col] : 0.0;
+            }
+    };
+    auto st_state = [&](double *base, const d4 (&x)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int col = r0 + 16 * q + i;
+                if (col < R) base[(size_t)(16 * w + k + 4 * rr) * R + col] = x[q][rr];
+            }
+    };
+    auto ld_A = [&](double (&a)[16], const int sidx) {
+        if (sidx >= len) return;
+        const double *Pg = Phi_ + ((size_t)pr * nch + chunk_of(sidx)) * 4096;      // Phi(i, j) at [j][i]
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+            a[ks] = up ? Pg[(size_t)(16 * w + i) * 64 + 4 * ks + k] : Pg[(size_t)(4 * ks + k) * 64 + 16 * w + i];
+    };
+    auto slot_of = [&](int sidx) { return F_state + ((size_t)pr * nch + chunk_of(sidx)) * 64 * R; };
+    d4 cur[4];
+    double *Vg = Vseg + ((size_t)pr * nseg + sg) * 64 * R;
+    if (PHASE == 2) ld_state(Vg, cur);
+    else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = d4{0.0, 0.0, 0.0, 0.0};
+    }
+    auto put = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) Sb[(16 * w + k + 4 * rr) * LDB + 16 * q + i] = cur[q][rr];
+    };
+    put();
+    double a0[16], a1[16];
+    d4 l0[4], l1[4];
+    ld_A(a0, 0);
+    ld_state(slot_of(0), l0);
+    __syncthreads();
+    auto step = [&](double (&a)[16], d4 (&loc)[4], double (&an)[16], d4 (&locn)[4], const int sidx) {
+        ld_A(an, sidx + 1);
+        if (sidx + 1 < len) ld_state(slot_of(sidx + 1), locn);
+        if (PHASE == 2) st_state(slot_of(sidx), cur);           // local end state in (above), true start state out
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = loc[q];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const double av = a[ks];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cur[q] = GF_MFMA64(av, Sb[(4 * ks + k) * LDB + 16 * q + i], cur[q]);
+        }
+        __syncthreads();                            // every wave has read the old state
+        put();
+        __syncthreads();
+    };
+    int sidx = 0;
+    for (; sidx + 2 <= len; sidx += 2) {
+        step(a0, l0, a1, l1, sidx);
+        step(a1, l1, a0, l0, sidx + 1);
+    }
+    if (sidx < len) step(a0, l0, a1, l1, sidx);
+    if (PHASE == 1) st_state(Vg, cur);              // the segment's end state from a zero start
+}
+
 // Composed transition of every segment of seg_len chunks:  Psi_s = Phi_{e-1} ... Phi_{b+1} Phi_b
 // (stored [j][i] like Phi).  One workgroup per segment: the running product lives in LDS (B operand
 // of the MFMA tiles), the next chunk's Phi is the A operand straight from global (lanes = rows of a
@@ -5601,12 +5692,17 @@ int gf_chunk_linear_combine_seg(int mode, int B, int nch, int seg_len, int R, co
     if (!Phi || !Psi || !F_state || !V_work) return set_err("gf_chunk_linear_combine_seg: null pointer%s", "");
     const int nseg = (nch + seg_len - 1) / seg_len;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_lincombine<1>, dim3(B * nseg, R), dim3(256), 0, st, nch, seg_len, mode, R, Phi,
-                       (const double *)nullptr, F_state, V_work);
+    // the segment scans: per right-hand side, or 64 right-hand sides at a time on the matrix pipe
+    const bool many = R >= 16;
+    const dim3 gridR(B * nseg, (R + 63) / 64);
+    if (many) hipLaunchKernelGGL(k_lincombine_R<1>, gridR, dim3(256), 0, st, nch, seg_len, mode, R, Phi, F_state, V_work);
+    else hipLaunchKernelGGL(k_lincombine<1>, dim3(B * nseg, R), dim3(256), 0, st, nch, seg_len, mode, R, Phi,
+                            (const double *)nullptr, F_state, V_work);
     hipLaunchKernelGGL(k_lincombine<0>, dim3(B, R), dim3(256), 0, st, nseg, nseg, mode, R, Psi,
                        (const double *)nullptr, V_work, (double *)nullptr);
-    hipLaunchKernelGGL(k_lincombine<2>, dim3(B * nseg, R), dim3(256), 0, st, nch, seg_len, mode, R, Phi,
-                       (const double *)nullptr, F_state, V_work);
+    if (many) hipLaunchKernelGGL(k_lincombine_R<2>, gridR, dim3(256), 0, st, nch, seg_len, mode, R, Phi, F_state, V_work);
+    else hipLaunchKernelGGL(k_lincombine<2>, dim3(B * nseg, R), dim3(256), 0, st, nch, seg_len, mode, R, Phi,
+                            (const double *)nullptr, F_state, V_work);
     return check_launch("gf_chunk_linear_combine_seg");
 }
 

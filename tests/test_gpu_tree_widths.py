@@ -86,3 +86,32 @@ def test_first_failing_row_through_the_combines(hip, J, B):
     ev.engine._tp_chunking = (lambda chunk_len, store=False, _o=ev.engine._tp_chunking: _o(L, store))
     got = ev.evaluate()
     assert np.all(got == -np.inf) and np.all(ev.engine.info.cpu().numpy() == bad + 1)
+
+
+@pytest.mark.parametrize("R", [16, 40, 70], ids=["R16", "R40", "R70"])
+def test_many_right_hand_sides_through_the_segment_scans(hip, R):
+    """Solves with 16 or more right-hand sides stitch their chunks 64 right-hand sides at a time on the matrix pipe
+    (k_lincombine_R): R = 16 (one tile), 40 (a ragged tile), 70 (two tiles), forward and backward sweep, against
+    the oracle's recurrences at 1e-6; two problems, 79 chunks each."""
+    import torch
+    import gadfly_amd
+    from gadfly_amd.engine import StreamingBatch
+    from gadfly_amd.synth import jitter_hyperparameters, solar_like_hyperparameters
+    from oracle import cref, seq
+    J, N, L = 30, 40_000, 512
+    prob = util.solar_problem(J, N, seed=77)
+    t, diag = prob["t"], prob["diag_user"]
+    kernels = [gadfly_amd.StellarOscillatorKernel(jitter_hyperparameters(solar_like_hyperparameters(J), 900 + i),
+                                                  texp=60.0) for i in range(2)]
+    eng = StreamingBatch([k.get_device_coefficients() for k in kernels], t, prob["y"], diag=diag, tile_rows=1024)
+    fac = eng.stored_factor(chunk_len=L)
+    assert fac._segments() is not None          # (the two-level combine, not the plain scan)
+    Y = np.random.default_rng(R).normal(size=(2, N, R))
+    got = fac.apply_inverse(torch.as_tensor(Y).cuda()).cpu().numpy()
+    for b, k in enumerate(kernels):
+        co = k.get_device_coefficients()
+        c, a, U, V = seq.celerite_matrices(co[:6], t, diag + co[6])
+        d_ref, W_ref, info = cref.factor(t, c, a, U, V)
+        assert info == 0
+        want = cref.solve_upper(t, c, U, W_ref, cref.solve_lower(t, c, U, W_ref, Y[b]) / d_ref[:, None])
+        assert np.max(np.abs(got[b] - want)) / np.max(np.abs(want)) < TOL_VEC, (b, R)
