@@ -2615,8 +2615,8 @@ __global__ void __launch_bounds__(256) k_tree_compose(const TreeArgs A) {
         Au[tid * LA + VC] = sacc;
     }
     __syncthreads();
-    cb_gauss_jordan<NS>(Au, M1, tid, n);    // AR = D, the vector column = v   (M1 serves as scratch ...
-    cb_load<NS>(M1, SR.G, tid);  // ... so G2 is loaded again)
+    cb_gauss_jordan<NS>(Au, v1, tid, n);    // AR = D, the vector column = v   (scratch: w | vv | g2v, not yet in use;
+                                            // G2 stays where it is -- with M1 as the scratch it was loaded twice)
     if (tid < 64) vv[tid] = vin ? Au[tid * LA + VC] : 0.0;
     __syncthreads();
     if (tid < 64) {                         // g2v = G2 v ;  m12 pieces need it

@@ -15,7 +15,7 @@ def run(B, N, J):
     out = (ctypes.c_double * 16)()
     lib.gf_debug_read(out, 16)
     ts = np.array(out[:13])
-    names = ["loads a", "product a", "GJ", "reload G2,g2v", "product c", "load Phi2", "2 products d", "S rmw", "load Phi1", "2 products e+store", "2 products f+m", "G store"]
+    names = ["loads a", "product a", "GJ", "g2v", "product c", "load Phi2", "2 products d", "S rmw", "load Phi1", "2 products e+store", "2 products f+m", "G store"]
     print("B=%d N=%d W=%d: top-level compose %d cycles" % (B, N, 2 * J, ts[12]))
     for k, nm in enumerate(names):
         print("   %-20s %8.0f  %5.1f%%" % (nm, ts[k + 1] - ts[k], 100 * (ts[k + 1] - ts[k]) / ts[12]))

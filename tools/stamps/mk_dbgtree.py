@@ -22,7 +22,7 @@ rep('    double *w = v1, *vv = v1 + 64, *g2v = v1 + 128, *tmpv = v1 + 192;\n',
     '#define MK() ts[nts++] = clock64()\n    MK();\n')
 rep('    if (tid < 64) tmpv[tid] = SR.m[tid];\n    __syncthreads();\n',
     '    if (tid < 64) tmpv[tid] = SR.m[tid];\n    __syncthreads();\n    MK(); /*1 loads a*/\n')
-rep('    cb_gauss_jordan<NS>(Au, M1, tid, n);', '    MK(); /*2 product a*/\n    cb_gauss_jordan<NS>(Au, M1, tid, n); MK(); /*3 GJ*/\n')
+rep('    cb_gauss_jordan<NS>(Au, v1, tid, n);', '    MK(); /*2 product a*/\n    cb_gauss_jordan<NS>(Au, v1, tid, n); MK(); /*3 GJ*/\n')
 rep('    // c. AL = D Xbar1\n', '    MK(); /*4 reload G2, g2v*/\n    // c. AL = D Xbar1\n')
 rep('    // d. M0 = Phi2 ;', '    MK(); /*5 product c*/\n    // d. M0 = Phi2 ;')
 rep('    cb_load<NS>(M0, SR.Phi, tid);\n    __syncthreads();\n', '    cb_load<NS>(M0, SR.Phi, tid);\n    __syncthreads();\n    MK(); /*6 load Phi2*/\n')
