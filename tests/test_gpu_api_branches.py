@@ -184,3 +184,51 @@ def test_covariance_of_a_long_series_tail_rows_and_slab_budget(hip):
     assert _relmax(cov, cov_ref) < TOL_COV
     _, var = gp.predict(y, t=ts, return_var=True)
     assert _relmax(var, np.diag(cov_ref)) < TOL_COV
+
+
+@pytest.mark.parametrize("case", ["sorted-J30", "unsorted-mixed-terms", "solar-W172"])
+def test_cross_covariance_blocks_against_the_kernel_function(hip, case):
+    """gf_cross_covariance factors the exponentials per 256-row workgroup (queries beyond the workgroup's time span
+    on either side) and evaluates queries inside the span entry by entry: every entry against ``Term.get_value`` of
+    the coefficient form at 1e-12 of the prior variance -- sorted and unsorted time stamps, queries before, inside,
+    between and after the data, 70 queries (two tiles of 64 / three of 32), real and complex terms, W = 172."""
+    import torch
+    from gadfly_amd import _lib
+    from gadfly_amd.terms import TermSum, SHOTerm, Term
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    if case == "sorted-J30":
+        k = util.solar_problem(30, 10)["kernel"]
+        t = np.sort(rng.uniform(0.0, 0.6, 5000))
+    elif case == "unsorted-mixed-terms":
+        k = util.generic_kernel("mixed")
+        t = rng.uniform(0.0, 40.0, 3000)               # not sorted: the workgroups' spans overlap
+    else:
+        import gadfly_amd
+        k = gadfly_amd.SolarOscillatorKernel(texp=60.0, bandpass="SOHO VIRGO")
+        t = np.arange(2500) * 60e-6
+    span = t.max() - t.min()
+    ts = np.concatenate([t.min() - span * rng.uniform(0.01, 0.5, 10), rng.uniform(t.min(), t.max(), 50),
+                         t.max() + span * rng.uniform(0.01, 0.5, 8), t[[7, 1234]]])
+    co = k.get_device_coefficients()
+    dev = [torch.as_tensor(np.ascontiguousarray(v)).cuda() for v in co[:6]]
+    td, tsd = torch.as_tensor(t).cuda(), torch.as_tensor(ts).cuda()
+    N, R = len(t), len(ts)
+    out = torch.empty((N, R), dtype=torch.float64, device="cuda")
+    p = _lib.ptr
+    rc = lib.gf_cross_covariance(1, N, R, len(co[0]), len(co[2]), *[p(v) if v.numel() else None for v in dev],
+                                 p(td), N, p(tsd), R, p(out), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "gf_cross_covariance")
+    want = Term.get_value(_Coefficients(co), t[:, None] - ts[None, :])
+    scale = Term.get_value(_Coefficients(co), np.zeros(1))[0]
+    assert np.max(np.abs(out.cpu().numpy() - want)) <= 1e-12 * scale
+
+
+class _Coefficients:
+    """A term given by its coefficient arrays (the celerite form ``gf_cross_covariance`` evaluates)."""
+
+    def __init__(self, co):
+        self._co = tuple(np.asarray(v, dtype=np.float64) for v in co[:6])
+
+    def get_coefficients(self):
+        return self._co
