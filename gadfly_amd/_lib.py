@@ -73,8 +73,8 @@ SIGNATURES = {
     "gf_lft_tree_scan": (_int, [_int, _int, _int] + [_vp] * 8 + [_vp]),
     "gf_bgemm": (_int, [_int, _int, _int, _int, _int, _int, _vp, _int, _i64, _vp, _int, _i64,
                         _vp, _int, _i64, _vp, _int, _i64, _vp]),
-    "gf_chunk_segment_transitions": (_int, [_int, _int, _int] + [_vp] * 2 + [_vp]),
-    "gf_chunk_linear_combine_seg": (_int, [_int, _int, _int, _int, _int] + [_vp] * 4 + [_vp]),
+    "gf_chunk_segment_transitions": (_int, [_int, _int, _int] + [_vp] * 4 + [_vp]),
+    "gf_chunk_linear_combine_seg": (_int, [_int, _int, _int, _int, _int] + [_vp] * 6 + [_vp]),
     "gf_chunk_transition": (_int, [_int, _i64, _i64, _int, _int, _int, _int, _int, _int] + [_vp] * 9 + [_vp]),
     "gf_chunk_transition_wide": (_int, [_int, _i64, _i64, _int, _int, _int, _int] + [_vp] * 7 + [_vp]),
     "gf_chunk_combine": (_int, [_int, _int, _int] + [_vp] * 5 + [_vp]),

@@ -3291,6 +3291,17 @@ __global__ void __launch_bounds__(64 * NWV, (NWV == 1 && !NODOT) ? 1 : 2) k_mmR_
 }
 #undef GF_MM_FETCH
 
+constexpr int LC_TRANSPOSED = 0x100;     // (flag on the combine kernels' mode: transitions handed over transposed)
+
+// out[m] = in[m]^T for a batch of 64 x 64 matrices (the transitions' transposes for the backward solve: once per factor)
+__global__ void __launch_bounds__(256) k_transpose64(const double *__restrict__ in, double *__restrict__ out) {
+    __shared__ double tile[64][65];
+    const size_t m = blockIdx.x;
+    for (int e = threadIdx.x; e < 4096; e += 256) tile[e >> 6][e & 63] = in[m * 4096 + e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 4096; e += 256) out[m * 4096 + e] = tile[e & 63][e >> 6];
+}
+
 // Linear combine of the chunk states of a sweep: on entry F_state slot c holds chunk c's end
 // state from a zero start (local pass); on exit it holds the TRUE start state of chunk c.
 //   lower  : F_{c+1} = Fbar_c + Phi_c F_c            (ascending; Phi = true closed-loop transition)
@@ -3307,9 +3318,14 @@ __global__ void __launch_bounds__(64 * NWV, (NWV == 1 && !NODOT) ? 1 : 2) k_mmR_
 // instead of nch.
 template <int PHASE>
 __global__ void __launch_bounds__(256)
-k_lincombine(const int nch, const int seg_len, const int mode, const int R,
+k_lincombine(const int nch, const int seg_len, const int mode_, const int R,
              const double *__restrict__ Phi_, const double *__restrict__ Dch_,
              double *__restrict__ F_state, double *__restrict__ Vseg) {
+    // mode_ | LC_TRANSPOSED: Phi_ holds the TRANSPOSED transitions (backward solve): its loads then run along the
+    // lanes like the forward solve's (a row of Phi^T per lane is one 128-byte run per lane and load: 0.12 against
+    // 0.07 ms for the scan of 1954 chunks)
+    const int mode = mode_ & ~LC_TRANSPOSED;
+    const bool pre_t = (mode_ & LC_TRANSPOSED) != 0;
     // One workgroup of four waves per (problem, right-hand side): the scan is sequential over the
     // chunks only.  Lane i owns state row i; wave w multiplies columns 16w..16w+15 of the chunk's
     // 64 x 64 transition (rows of Phi^T for the backward solve), which it holds in registers and
@@ -3330,9 +3346,9 @@ k_lincombine(const int nch, const int seg_len, const int mode, const int R,
     auto load_phi = [&](double (&buf)[16], int s) {
         if (s >= len) return;
         const double *Pg = Phi_ + ((size_t)pr * nch + chunk_of(s)) * 4096;
-        if (!up) {
+        if (!up || pre_t) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) buf[j] = Pg[(size_t)(16 * w + j) * 64 + i];    // Phi(i, j)
+            for (int j = 0; j < 16; ++j) buf[j] = Pg[(size_t)(16 * w + j) * 64 + i];    // Phi(i, j) (or Phi^T's)
         } else {
             const double2 *row = reinterpret_cast<const double2 *>(Pg + (size_t)i * 64 + 16 * w);
 #pragma unroll
@@ -3411,8 +3427,10 @@ k_lincombine(const int nch, const int seg_len, const int mode, const int R,
 // chunks (a quarter of predict(return_var=True)); this one streams them once.
 template <int PHASE>
 __global__ void __launch_bounds__(256)
-k_lincombine_R(const int nch, const int seg_len, const int mode, const int R,
+k_lincombine_R(const int nch, const int seg_len, const int mode_, const int R,
                const double *__restrict__ Phi_, double *__restrict__ F_state, double *__restrict__ Vseg) {
+    const int mode = mode_ & ~LC_TRANSPOSED;
+    const bool pre_t = (mode_ & LC_TRANSPOSED) != 0;         // (Phi_ holds the transposed transitions)
     constexpr int LDB = 80;                         // (rows k, k + 1 of the B operand 32 banks apart)
     __shared__ __attribute__((aligned(16))) double Sb[64 * LDB];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, k = lane >> 4;
@@ -3446,7 +3464,7 @@ k_lincombine_R(const int nch, const int seg_len, const int mode, const int R,
         const double *Pg = Phi_ + ((size_t)pr * nch + chunk_of(sidx)) * 4096;      // Phi(i, j) at [j][i]
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks)
-            a[ks] = up ? Pg[(size_t)(16 * w + i) * 64 + 4 * ks + k] : Pg[(size_t)(4 * ks + k) * 64 + 16 * w + i];
+            a[ks] = (up && !pre_t) ? Pg[(size_t)(16 * w + i) * 64 + 4 * ks + k] : Pg[(size_t)(4 * ks + k) * 64 + 16 * w + i];
     };
     auto slot_of = [&](int sidx) { return F_state + ((size_t)pr * nch + chunk_of(sidx)) * 64 * R; };
     d4 cur[4];
@@ -5676,18 +5694,28 @@ int gf_chunk_linear_combine(int mode, int B, int64_t N, int64_t chunk_len, int n
     return check_launch("gf_chunk_linear_combine");
 }
 
-int gf_chunk_segment_transitions(int B, int nch, int seg_len, const double *Phi, double *Psi_out, void *stream) {
+int gf_chunk_segment_transitions(int B, int nch, int seg_len, const double *Phi, double *Psi_out,
+                                 double *PhiT_out, double *PsiT_out, void *stream) {
     if (B < 1 || nch < 1 || seg_len < 1) return set_err("gf_chunk_segment_transitions: empty problem%s", "");
-    if (!Phi || !Psi_out) return set_err("gf_chunk_segment_transitions: null pointer%s", "");
+    if (!Phi || !Psi_out || ((PhiT_out != nullptr) != (PsiT_out != nullptr)))
+        return set_err("gf_chunk_segment_transitions: null pointer (PhiT_out and PsiT_out go together)%s", "");
     const int nseg = (nch + seg_len - 1) / seg_len;
-    hipLaunchKernelGGL(k_segment_transition, dim3(B * nseg), dim3(256), 0, (hipStream_t)stream, nch, seg_len, Phi, Psi_out);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_segment_transition, dim3(B * nseg), dim3(256), 0, st, nch, seg_len, Phi, Psi_out);
+    if (PhiT_out) {
+        hipLaunchKernelGGL(k_transpose64, dim3(B * nch), dim3(256), 0, st, Phi, PhiT_out);
+        hipLaunchKernelGGL(k_transpose64, dim3(B * nseg), dim3(256), 0, st, (const double *)Psi_out, PsiT_out);
+    }
     return check_launch("gf_chunk_segment_transitions");
 }
 
 int gf_chunk_linear_combine_seg(int mode, int B, int nch, int seg_len, int R, const double *Phi,
-                                const double *Psi, double *F_state, double *V_work, void *stream) {
+                                const double *Psi, const double *PhiT, const double *PsiT,
+                                double *F_state, double *V_work, void *stream) {
     if (mode != GF_SOLVE_LOWER && mode != GF_SOLVE_UPPER)
         return set_err("gf_chunk_linear_combine_seg: bad mode %s%lld (the solves only)", "", mode);
+    if ((PhiT != nullptr) != (PsiT != nullptr)) return set_err("gf_chunk_linear_combine_seg: PhiT and PsiT go together%s", "");
+    if (mode == GF_SOLVE_UPPER && PhiT) { Phi = PhiT; Psi = PsiT; mode |= LC_TRANSPOSED; }
     if (B < 1 || nch < 1 || R < 1 || seg_len < 1) return set_err("gf_chunk_linear_combine_seg: empty problem%s", "");
     if (!Phi || !Psi || !F_state || !V_work) return set_err("gf_chunk_linear_combine_seg: null pointer%s", "");
     const int nseg = (nch + seg_len - 1) / seg_len;

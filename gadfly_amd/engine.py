@@ -356,6 +356,7 @@ class ScaledFactor:
         self._v1 = None
         self._D, self._D_key = None, None
         self._Psi = None
+        self._PhiT = self._PsiT = None      # (transposes of Phi / Psi for the backward combine: with _Psi)
 
     @_on_device
     def _ensure_transitions(self):
@@ -424,7 +425,7 @@ class ScaledFactor:
                 seg_len, Psi = seg
                 V = torch.empty((B * (-(-nch // seg_len)), 64 * R), **f64)
                 rc = lib.gf_chunk_linear_combine_seg(mode, B, nch, seg_len, R, p(self.Phi), p(Psi),
-                                                     p(F), p(V), st)
+                                                     p(self._PhiT), p(self._PsiT), p(F), p(V), st)
                 _lib.check(rc, "gf_chunk_linear_combine_seg")
             elif mode == _lib.GF_MATMUL_LOWER and not fresh_D:
                 _lib.check(lib.gf_chunk_diag_scan(B, nch, 64, R, p(self._D), p(F), st), "gf_chunk_diag_scan")
@@ -453,9 +454,12 @@ class ScaledFactor:
             seg_len = max(2, int(round(math.sqrt(self.nch / 2.0))))
             nseg = -(-self.nch // seg_len)
             Psi = self.torch.empty((self.B * nseg, 4096), dtype=self.torch.float64, device=self.device)
+            # (and the transposes of both, for the backward solve's combine: its loads then run along the lanes)
+            self._PhiT = self.torch.empty_like(self.Phi)
+            self._PsiT = self.torch.empty_like(Psi)
             st = self.torch.cuda.current_stream(self.device).cuda_stream
             rc = self.lib.gf_chunk_segment_transitions(self.B, self.nch, seg_len, _lib.ptr(self.Phi),
-                                                       _lib.ptr(Psi), st)
+                                                       _lib.ptr(Psi), _lib.ptr(self._PhiT), _lib.ptr(self._PsiT), st)
             _lib.check(rc, "gf_chunk_segment_transitions")
             self._Psi = (seg_len, Psi)
         return self._Psi

@@ -282,12 +282,16 @@ int gf_chunk_linear_combine(int mode, int B, int64_t N, int64_t chunk_len, int n
  * mat-vec per chunk in sequence).  gf_chunk_segment_transitions composes, once per factor, the
  * transitions of every segment of seg_len chunks: Psi_out [B*nseg][64*64], nseg = ceil(nch / seg_len).
  * gf_chunk_linear_combine_seg then does what gf_chunk_linear_combine does with a sequential depth of
- * 2 seg_len + nseg chunks; V_work is [B*nseg][64*R] scratch.
+ * 2 seg_len + nseg chunks; V_work is [B*nseg][64*R] scratch.  PhiT_out / PsiT_out (both or neither; may be
+ * NULL): the transposes of every Phi and Psi, for the backward solve -- handed to gf_chunk_linear_combine_seg as
+ * PhiT / PsiT its loads run along the lanes as the forward solve's do (NULL there: the transposes are read out of
+ * Phi / Psi, one 128-byte run per lane).
  */
 int gf_chunk_segment_transitions(int B, int nch, int seg_len, const double *Phi, double *Psi_out,
-                                 void *stream);
+                                 double *PhiT_out, double *PsiT_out, void *stream);
 int gf_chunk_linear_combine_seg(int mode, int B, int nch, int seg_len, int R, const double *Phi,
-                                const double *Psi, double *F_state, double *V_work, void *stream);
+                                const double *Psi, const double *PhiT, const double *PsiT,
+                                double *F_state, double *V_work, void *stream);
 
 /*
  * Batched dense solve A X = B (Gauss-Jordan with partial pivoting, one launch): A [batch][n][n] row-major

@@ -672,11 +672,18 @@ def test_scaled_factor_two_level_combine(hip, case, L):
     # other segment lengths, including one that leaves a single chunk in the last segment
     for seg_len in (2, 5, fac.nch - 1):
         Psi = torch.empty((-(-fac.nch // seg_len), 4096), dtype=torch.float64, device="cuda")
-        rc = hip.load().gf_chunk_segment_transitions(1, fac.nch, seg_len, hip.ptr(fac.Phi), hip.ptr(Psi), None)
+        PsiT = torch.empty_like(Psi)
+        rc = hip.load().gf_chunk_segment_transitions(1, fac.nch, seg_len, hip.ptr(fac.Phi), hip.ptr(Psi),
+                                                     hip.ptr(fac._PhiT), hip.ptr(PsiT), None)
         hip.check(rc, "gf_chunk_segment_transitions")
-        fac._Psi = (seg_len, Psi)
+        fac._Psi, fac._PsiT = (seg_len, Psi), PsiT
         assert _relmax(fac.solve_lower(Yd)[0].cpu().numpy(), lo) < 1e-11
         assert _relmax(fac.solve_upper(Yd)[0].cpu().numpy(), up) < 1e-11
+        # without the transposed copies the backward combine reads the transposes out of Phi / Psi
+        keep = fac._PhiT, fac._PsiT
+        fac._PhiT = fac._PsiT = None
+        assert _relmax(fac.solve_upper(Yd)[0].cpu().numpy(), up) < 1e-11
+        fac._PhiT, fac._PsiT = keep
 
 
 def test_recompute_refactorises_everything(hip):
